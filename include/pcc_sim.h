@@ -1,0 +1,179 @@
+/*
+ * pcc_sim.h -- C ABI of the MI355X-native batched congestion-control simulator.
+ *
+ * One shared library (pcc-rl_amd/lib/libpcc_sim.so, built by hipcc for gfx950) exports
+ * exactly the entry points below.  They are what a binding for the reference's env path
+ * would call: the reference (PCCproject/PCC-RL) is pure Python and has no native interface,
+ * so every function cites the Python method it replaces ("ns" = src/gym/network_sim.py,
+ * "so" = src/common/sender_obs.py in the reference tree).
+ *
+ * Conventions
+ *   - all functions return 0 on success, a negative PCC_E* code on failure;
+ *     pcc_last_error() returns a thread-local description of the last failure.
+ *   - "device pointer" = memory of the GPU the handle was created on.  The caller (PyTorch,
+ *     through tensor.data_ptr()) owns every in/out buffer; the handle owns the persistent
+ *     structure-of-arrays env state and the per-env in-flight packet rings.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
+ *     enqueue work on it; nothing here synchronizes the device, and no call copies between
+ *     host and device except pcc_create/pcc_set_param_ranges (scalars).
+ *   - a handle is not thread-safe; distinct handles are independent (the reference's module
+ *     globals -- Sender._next_id ns:229, _conn_min_latencies so:158, the global RNG ns:73 --
+ *     have no counterpart here).
+ *   - batched shapes: N = n_envs, S = n_senders, H = history_len, F = n_features.
+ */
+#ifndef PCC_SIM_H
+#define PCC_SIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcc_sim pcc_sim_t;
+
+enum {
+    PCC_OK = 0,
+    PCC_EINVAL = -1,   /* bad argument */
+    PCC_ENODEV = -2,   /* no usable gfx950 device / HIP runtime error at create */
+    PCC_ENOMEM = -3,   /* device allocation failed */
+    PCC_EHIP = -4,     /* HIP runtime error while enqueueing */
+    PCC_ESTATE = -5    /* protocol error: step before reset (ns:368 leaves run_dur None) */
+};
+
+/* metric ids = positions in the reference registry so:193-206 */
+enum {
+    PCC_M_SEND_RATE = 0, PCC_M_RECV_RATE, PCC_M_RECV_DUR, PCC_M_SEND_DUR, PCC_M_AVG_LATENCY,
+    PCC_M_LOSS_RATIO, PCC_M_ACK_LATENCY_INFLATION, PCC_M_SENT_LATENCY_INFLATION,
+    PCC_M_CONN_MIN_LATENCY, PCC_M_LATENCY_INCREASE, PCC_M_LATENCY_RATIO, PCC_M_SEND_RATIO,
+    PCC_N_METRICS
+};
+
+/* columns of the optional per-step record (doubles): the counters and clocks of ns:291-317,
+ * the reward of ns:194,205 and the 12 metrics of so:110-191 */
+enum {
+    PCC_COL_SENT = 0, PCC_COL_ACKED, PCC_COL_LOST, PCC_COL_RATE, PCC_COL_CUR_TIME, PCC_COL_RUN_DUR,
+    PCC_COL_REWARD, PCC_COL_METRIC0, PCC_STEP_COLS = PCC_COL_METRIC0 + PCC_N_METRICS
+};
+
+/* where the per-packet loss uniform (random.random() in ns:73) comes from */
+enum {
+    PCC_RNG_PHILOX = 0, /* Philox4x32-10 keyed by (seed, global env id, episode, MI, packet) */
+    PCC_RNG_TRACE = 1   /* replay u[env][k], k = packets sent so far this episode (parity mode) */
+};
+
+/* fields readable with pcc_get_state (element type, shape) */
+enum {
+    PCC_F_BW = 0,        /* f64 [N]     link bandwidth, packets/s            (ns:59)  */
+    PCC_F_DL,            /* f64 [N]     one-way propagation delay, s         (ns:60)  */
+    PCC_F_LR,            /* f64 [N]     random loss probability              (ns:61)  */
+    PCC_F_MAXQ,          /* f64 [N]     max queue delay = queue/bw           (ns:64)  */
+    PCC_F_QDELAY,        /* f64 [N]     link-0 queue delay                   (ns:62)  */
+    PCC_F_QTIME,         /* f64 [N]     link-0 queue delay update time       (ns:63)  */
+    PCC_F_NOW,           /* f64 [N]     network clock                        (ns:102) */
+    PCC_F_RUN_DUR,       /* f64 [N]     next MI duration                     (ns:437-438,467) */
+    PCC_F_STEPS,         /* u32 [N]     steps taken this episode             (ns:418) */
+    PCC_F_EPISODE,       /* u32 [N]     episodes started (resets)                     */
+    PCC_F_FLAGS,         /* u32 [N]     sticky error bits, PCC_FLAG_*                 */
+    PCC_F_RATE,          /* f64 [S][N]  sending rate, packets/s              (ns:211) */
+    PCC_F_RATE0,         /* f64 [S][N]  starting rate                        (ns:210) */
+    PCC_F_NEXT_SEND,     /* f64 [S][N]  time of the pending SEND event       (ns:111,161) */
+    PCC_F_MIN_LAT,       /* f64 [S][N]  connection min of per-MI mean RTT, 0 = none (so:158-176) */
+    PCC_F_RING_HEAD,     /* u32 [S][N]  packets fully acknowledged/lost this episode  */
+    PCC_F_RING_MID,      /* u32 [S][N]  packets past the first (forward) hop          */
+    PCC_F_RING_TAIL,     /* u32 [S][N]  packets sent this episode                     */
+    PCC_F_EP_RETURN,     /* f64 [S][N]  reward summed over the running episode (ns:442) */
+    PCC_F_LAST_RETURN,   /* f64 [S][N]  return of the last finished episode            */
+    PCC_F_TOTAL_SENT,    /* u64 [N]     packets sent since create (all episodes, all senders) */
+    PCC_N_FIELDS
+};
+
+#define PCC_FLAG_RING_OVERFLOW 1u  /* more packets in flight than ring_capacity: results invalid */
+#define PCC_FLAG_TRACE_OVERRUN 2u  /* PCC_RNG_TRACE ran past trace_stride */
+
+/* last error text of the calling thread ("" if none) */
+const char *pcc_last_error(void);
+
+/*
+ * Create a batch of n_envs independent envs.  Replaces SimulatedNetworkEnv.__init__
+ * (ns:346-394) for a whole batch: history_len and the feature list are its two constructor
+ * arguments (ns:347-351); feature_ids are indices into the metric registry (so:193-206).
+ *   n_senders       1 (the reference env, ns:466) or 2 (two senders on the shared bottleneck).
+ *   seed            Philox key.  env_gid_base: global id of env 0 (rank * n_envs when the
+ *                   batch is sharded over GPUs) so results do not depend on the sharding.
+ *   ring_capacity   power of two, per env per sender, in packets (0 = default 32768, the
+ *                   worst case rate_max * (2*dl_max + queue_max/bw_min) of the default ranges).
+ *   device_id       HIP device ordinal (-1 = current device).
+ * No env is usable before pcc_reset.
+ */
+int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *feature_ids,
+               int n_features, uint64_t seed, uint32_t env_gid_base, uint32_t ring_capacity,
+               int device_id, pcc_sim_t **out);
+
+void pcc_destroy(pcc_sim_t *sim);
+
+/*
+ * Link/sender parameters used by every following reset: replaces the five global-RNG draws
+ * of create_new_links_and_senders (ns:454-467).  Device pointers: bw, dl, queue (packets,
+ * as double), loss are [N]; rate0 is [S][N].  All five NULL = draw them per reset from the
+ * ranges (default), exactly as ns:455-466 does: bw~U, lat~U, queue=1+int(exp(U)), loss~U,
+ * rate0=U*bw.  The arrays are read at reset time and must stay valid until then.
+ */
+int pcc_set_link_params(pcc_sim_t *sim, const double *bw, const double *dl, const double *queue,
+                        const double *loss, const double *rate0);
+
+/* ranges of ns:355-358 and the rate factor of ns:466: {bw, lat, queue exponent, loss, rate0/bw}
+ * (host pointers to 5 doubles each) */
+int pcc_set_param_ranges(pcc_sim_t *sim, const double *lo, const double *hi);
+
+/* loss-uniform source.  trace: device pointer [N][trace_stride] doubles (PCC_RNG_TRACE only) */
+int pcc_set_rng(pcc_sim_t *sim, int mode, const double *trace, int64_t trace_stride);
+
+/* re-key the Philox generator; takes effect for draws made after the call.  (The reference's
+ * seed(), ns:396-398, creates an RNG nothing reads; here it does what a caller expects.) */
+int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
+
+/* DELTA_SCALE (src/common/config.py:17, default 0.025) and MAX_STEPS (ns:41, default 400) */
+int pcc_set_delta_scale(pcc_sim_t *sim, double delta_scale);
+int pcc_set_max_steps(pcc_sim_t *sim, int max_steps);
+
+/*
+ * reset() for the envs whose mask byte is non-zero (mask NULL = all): ns:469-484 -- new
+ * parameters, fresh sender + history, the first SEND at 1/rate, two unrecorded warm-up
+ * monitor intervals of 3*lat.  obs_out (device, f32 [N][S][H*F], may be NULL) receives the
+ * all-empty history observation for the envs that were reset; other rows are untouched.
+ */
+int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream);
+
+/*
+ * step() for every env: ns:406-444 -- apply the rate action (ns:235-241, clamp ns:275-281),
+ * run one monitor interval (Network.run_for_dur, ns:123-205), evaluate the MI metrics and
+ * roll the history (so:44-73), reward (ns:194,205), next run_dur (ns:437-438), done (ns:444).
+ *   actions      device, [N][S], f32 (actions_f64 = 0) or f64 (actions_f64 = 1).
+ *   obs_out      device f32 [N][S][H*F], oldest MI first (ns:400-404).          may be NULL
+ *   reward_out   device f32 [N][S].                                              may be NULL
+ *   done_out     device u8  [N].                                                 may be NULL
+ *   steps_out    device f64 [N][S][PCC_STEP_COLS]: counters, clocks, reward, 12 metrics at
+ *                full precision (the reference's per-step event record ns:422-436 is a
+ *                subset).                                                         may be NULL
+ *   auto_reset   non-zero: envs that finished are reset in the same call and their obs_out
+ *                rows hold the first observation of the next episode.
+ * Returns PCC_ESTATE if pcc_reset was never called on this handle.
+ */
+int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_out, float *reward_out,
+             uint8_t *done_out, double *steps_out, int auto_reset, void *stream);
+
+/* copy one state field into a caller-owned device buffer (see the PCC_F_* table) */
+int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream);
+
+/* bounds and scale of metric `id`: (min_val, max_val, scale) of so:193-206; host pointers.
+ * get_min_obs_vector / get_max_obs_vector (so:95-108) are these tiled H times. */
+int pcc_metric_info(int id, double *min_val, double *max_val, double *scale);
+
+/* bytes of device memory the handle owns */
+int64_t pcc_device_bytes(const pcc_sim_t *sim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCC_SIM_H */

@@ -1,0 +1,337 @@
+"""Env surface of the MI355X-native simulator.
+
+Two classes:
+
+* ``BatchedNetworkEnv`` -- N independent envs advanced in lockstep on one GPU, torch tensors
+  in and out, no host round trips in ``step``.  This is the fast path.
+* ``SimulatedNetworkEnv`` -- the reference's old-gym single-env protocol
+  (src/gym/network_sim.py:344-496: ``reset() -> obs``, ``step(a) -> (obs, reward, done, {})``,
+  ``seed``, ``render``, ``close``, ``observation_space``, ``action_space``, constructor
+  arguments ``history_len`` and ``features``) as a view onto a batch of one, so agent code
+  written against the reference runs unchanged.
+
+All simulation runs in the HIP library behind include/pcc_sim.h; this file only owns the
+output tensors and argument checking.  There is no CPU implementation to fall back to.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import native
+from .config import DELTA_SCALE, arg_or_default
+from .metrics import DEFAULT_FEATURES, feature_ids, get_max_obs_vector, get_min_obs_vector
+from .native import PccError, check, lib
+from .spaces import Box
+
+MAX_STEPS = 400          # ns:41
+DEFAULT_RING_CAPACITY = 32768
+
+_TORCH_DTYPES = {"float64": torch.float64, "int32": torch.int32, "int64": torch.int64}
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class BatchedNetworkEnv(object):
+    """N single-bottleneck congestion-control envs on one MI355X.
+
+    Parameters mirror the reference constructor (``history_len``, ``features``) plus what a
+    batch needs.  ``link_params`` = None draws (bw, latency, queue, loss, rate0) per episode
+    from the reference's ranges (ns:355-358, 455-466); otherwise a dict/tuple of five tensors
+    or scalars ``(bw, dl, queue, loss, rate0)`` fixes them.
+
+    Shapes (S = n_senders): actions ``[N]``/``[N, 1]`` (S=1) or ``[N, 2]``; obs ``[N, H*F]``
+    (S=1) or ``[N, S, H*F]`` float32, oldest monitor interval first; reward ``[N]`` or
+    ``[N, S]`` float32; done ``[N]`` bool.  With ``auto_reset`` (default) an env that reaches
+    ``max_steps`` is reset inside the same ``step`` call and its obs row is the first
+    observation of the next episode; ``info["episode_return"]`` then holds the finished return.
+
+    The tensors returned by ``reset``/``step`` are the env's own output buffers: they are
+    overwritten by the next call (pass ``new_tensors=True`` to get fresh ones each call).
+    """
+
+    def __init__(self, n_envs, device="cuda", history_len=None, features=None, seed=0, n_senders=1,
+                 link_params=None, env_gid_base=0, ring_capacity=0, auto_reset=True, delta_scale=None,
+                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False):
+        if history_len is None:
+            history_len = arg_or_default("--history-len", default=10)
+        if features is None:
+            features = arg_or_default("--input-features", default=DEFAULT_FEATURES)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("BatchedNetworkEnv runs on an MI355X only (device=%r); there is no CPU path" % (device,))
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the simulator is a HIP library for gfx950 and has no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_envs, self.n_senders = int(n_envs), int(n_senders)
+        self.history_len = int(history_len)
+        self.features = features.split(",") if isinstance(features, str) else list(features)
+        self.feature_ids = feature_ids(self.features)
+        self.obs_dim = self.history_len * len(self.feature_ids)
+        self.auto_reset, self.record_steps, self.new_tensors = bool(auto_reset), bool(record_steps), bool(new_tensors)
+        self.max_steps = int(max_steps)
+        self.seed_value = int(seed)
+
+        L = lib()
+        fids = (ctypes.c_int32 * len(self.feature_ids))(*self.feature_ids)
+        handle = ctypes.c_void_p()
+        check(L.pcc_create(self.n_envs, self.n_senders, self.history_len, fids, len(self.feature_ids),
+                           self.seed_value & (2 ** 64 - 1), int(env_gid_base), int(ring_capacity),
+                           self.device.index, ctypes.byref(handle)))
+        self._h = handle
+        self._L = L
+        check(L.pcc_set_delta_scale(self._h, float(DELTA_SCALE if delta_scale is None else delta_scale)))
+        check(L.pcc_set_max_steps(self._h, self.max_steps))
+
+        N, S, D = self.n_envs, self.n_senders, self.obs_dim
+        with torch.cuda.device(self.device):
+            self._obs = torch.empty((N, S, D), dtype=torch.float32, device=self.device)
+            self._reward = torch.empty((N, S), dtype=torch.float32, device=self.device)
+            self._done = torch.empty((N,), dtype=torch.uint8, device=self.device)
+            self._steps = (torch.empty((N, S, native.PCC_STEP_COLS), dtype=torch.float64, device=self.device)
+                           if self.record_steps else None)
+        self._params = None
+        self._trace = None
+        self._was_reset = False
+        if link_params is not None:
+            self.set_link_params(*(link_params.values() if isinstance(link_params, dict) else link_params))
+
+        single = get_min_obs_vector(self.features), get_max_obs_vector(self.features)
+        self.single_observation_space = Box(np.tile(single[0], self.history_len), np.tile(single[1], self.history_len),
+                                            dtype=np.float32)                       # ns:382-388
+        self.single_action_space = Box(np.array([-1e12] * 1), np.array([1e12] * 1), dtype=np.float32)  # ns:379
+        self.observation_space = self.single_observation_space
+        self.action_space = self.single_action_space
+        self.num_envs = self.n_envs
+
+    # ------------------------------------------------------------------ configuration
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _as_param(self, x, per_sender=False):
+        shape = (self.n_senders, self.n_envs) if per_sender else (self.n_envs,)
+        t = torch.as_tensor(x, dtype=torch.float64, device=self.device)
+        if t.ndim == 0:
+            t = t.expand(shape)
+        elif per_sender and t.shape == (self.n_envs,) and self.n_senders == 1:
+            t = t.reshape(shape)
+        elif per_sender and t.shape == (self.n_envs, self.n_senders):
+            t = t.t()
+        if tuple(t.shape) != shape:
+            raise ValueError("link parameter has shape %s, expected %s" % (tuple(t.shape), shape))
+        return t.contiguous().clone()
+
+    def set_link_params(self, bw, dl, queue, loss, rate0):
+        """Fix (bandwidth pkt/s, one-way delay s, queue packets, loss prob, starting rate pkt/s)
+        for every following reset (scalars or [N] tensors; rate0 [N] / [N, S])."""
+        p = (self._as_param(bw), self._as_param(dl), self._as_param(queue), self._as_param(loss),
+             self._as_param(rate0, per_sender=True))
+        check(self._L.pcc_set_link_params(self._h, *[_ptr(t) for t in p]))
+        self._params = p  # keep alive: the library reads them at reset time
+
+    def randomize_link_params(self, ranges=None):
+        """Back to per-episode random parameters; ``ranges`` optionally overrides
+        {bw, lat, queue exponent, loss, rate0/bw} as ((lo...), (hi...))."""
+        check(self._L.pcc_set_link_params(self._h, None, None, None, None, None))
+        self._params = None
+        if ranges is not None:
+            lo = (ctypes.c_double * 5)(*[float(v) for v in ranges[0]])
+            hi = (ctypes.c_double * 5)(*[float(v) for v in ranges[1]])
+            check(self._L.pcc_set_param_ranges(self._h, lo, hi))
+
+    def set_loss_trace(self, u):
+        """Parity mode: replay per-packet loss uniforms u[env, k] (k = k-th packet sent in the
+        episode) instead of Philox.  ``None`` switches back."""
+        if u is None:
+            check(self._L.pcc_set_rng(self._h, native.PCC_RNG_PHILOX, None, 0))
+            self._trace = None
+            return
+        t = torch.as_tensor(u, dtype=torch.float64, device=self.device).contiguous()
+        if t.ndim != 2 or t.shape[0] != self.n_envs:
+            raise ValueError("loss trace must be [n_envs, K]")
+        check(self._L.pcc_set_rng(self._h, native.PCC_RNG_TRACE, _ptr(t), t.shape[1]))
+        self._trace = t
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self.seed_value = int(seed)
+            check(self._L.pcc_set_seed(self._h, self.seed_value & (2 ** 64 - 1)))
+        return [seed]
+
+    # ------------------------------------------------------------------ protocol
+    def _out(self, t):
+        if t is None:
+            return None
+        t = t.clone() if self.new_tensors else t
+        return t[:, 0] if self.n_senders == 1 else t
+
+    def reset(self, mask=None):
+        """Reset all envs (or those where ``mask`` is true); returns the observation tensor."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            if m.shape != (self.n_envs,):
+                raise ValueError("mask must be [n_envs]")
+        check(self._L.pcc_reset(self._h, _ptr(m), _ptr(self._obs), self._stream()))
+        self._was_reset = True
+        return self._out(self._obs)
+
+    def step(self, actions):
+        a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions), device=self.device)
+        if a.device != self.device:
+            a = a.to(self.device)
+        if a.dtype not in (torch.float32, torch.float64):
+            a = a.to(torch.float32)
+        if a.numel() != self.n_envs * self.n_senders:
+            raise ValueError("actions has %d elements, expected n_envs*n_senders = %d"
+                             % (a.numel(), self.n_envs * self.n_senders))
+        a = a.reshape(self.n_envs, self.n_senders).contiguous()
+        check(self._L.pcc_step(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, _ptr(self._obs),
+                               _ptr(self._reward), _ptr(self._done), _ptr(self._steps),
+                               1 if self.auto_reset else 0, self._stream()))
+        info = {}
+        if self._steps is not None:
+            info["steps"] = self._out(self._steps)
+        return self._out(self._obs), self._out(self._reward), self._done.bool(), info
+
+    # ------------------------------------------------------------------ introspection
+    def state(self, name):
+        """Copy of one internal state field as a tensor (see native.FIELDS)."""
+        fid, dtype, per_sender = native.FIELDS[name]
+        shape = (self.n_senders, self.n_envs) if per_sender else (self.n_envs,)
+        out = torch.empty(shape, dtype=_TORCH_DTYPES[dtype], device=self.device)
+        check(self._L.pcc_get_state(self._h, fid, _ptr(out), self._stream()))
+        return out
+
+    def episode_returns(self):
+        """Return of the last finished episode per env ([N] or [S, N]), float64."""
+        r = self.state("last_return")
+        return r[0] if self.n_senders == 1 else r
+
+    def check_flags(self):
+        """Raise if any env overflowed its in-flight ring or ran out of loss trace."""
+        flags = self.state("flags")
+        bad = int((flags != 0).sum().item())
+        if bad:
+            over = int(((flags & native.PCC_FLAG_RING_OVERFLOW) != 0).sum().item())
+            tr = int(((flags & native.PCC_FLAG_TRACE_OVERRUN) != 0).sum().item())
+            raise PccError(-6, "%d envs overflowed the in-flight ring, %d ran past the loss trace" % (over, tr))
+
+    @property
+    def device_bytes(self):
+        return int(self._L.pcc_device_bytes(self._h))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.pcc_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, mode="human"):
+        pass
+
+
+class SimulatedNetworkEnv(object):
+    """Drop-in for the reference's ``SimulatedNetworkEnv`` (src/gym/network_sim.py:344-496).
+
+    Same constructor arguments, spaces, ``reset``/``step``/``seed``/``render``/``close``
+    signatures and return types (numpy observation of shape ``(history_len * n_features,)``,
+    Python float reward, bool done, empty info dict).  One env = a batch of one on the GPU, so
+    this adapter is for compatibility, not speed: use ``BatchedNetworkEnv`` to train.
+
+    Differences from the reference, all deliberate: ``seed()`` really seeds the simulator (the
+    reference's creates an RNG nothing reads, ns:396-398); nothing is printed; the JSON event
+    log is written only when ``dump_events_to_file`` is called (the reference writes
+    ``pcc_env_log_run_N.json`` into the CWD every 100 episodes, ns:475-476).
+    """
+
+    metadata = {"render.modes": []}
+
+    def __init__(self, history_len=None, features=None, device="cuda", seed=0, link_params=None):
+        self._env = BatchedNetworkEnv(1, device=device, history_len=history_len, features=features, seed=seed,
+                                      link_params=link_params, auto_reset=False, record_steps=True)
+        self.history_len = self._env.history_len
+        self.features = self._env.features
+        self.observation_space = self._env.single_observation_space
+        self.action_space = self._env.single_action_space
+        self.max_steps = MAX_STEPS
+        self.steps_taken = 0
+        self.reward_sum = 0.0
+        self.reward_ewma = 0.0
+        self.episodes_run = -1
+        self.event_record = {"Events": []}
+        self.run_dur = None
+        self.viewer = None
+
+    def seed(self, seed=None):
+        self._env.seed(seed)
+        return [seed]
+
+    def reset(self):
+        obs = self._env.reset()
+        self.steps_taken = 0
+        self.episodes_run += 1
+        self.event_record = {"Events": []}
+        self.reward_ewma = 0.99 * self.reward_ewma + 0.01 * self.reward_sum   # ns:480-481
+        self.reward_sum = 0.0
+        self.run_dur = float(self._env.state("run_dur")[0].item())
+        return obs[0].cpu().numpy()
+
+    def step(self, actions):
+        if self.run_dur is None:
+            raise TypeError("step() called before reset(): run_dur is None")  # what ns:368,416 raises
+        a = float(np.asarray(actions, dtype=np.float64).reshape(-1)[0])       # ns:409-412: only action[0]
+        act = torch.tensor([[a]], dtype=torch.float64, device=self._env.device)
+        obs, reward, done, info = self._env.step(act)
+        row = info["steps"][0].cpu().numpy()
+        reward = float(row[native.STEP_COLUMNS.index("reward")])
+        self.steps_taken += 1
+        col = native.STEP_COLUMNS.index
+        self.event_record["Events"].append({                                   # ns:422-436
+            "Name": "Step", "Time": self.steps_taken, "Reward": reward,
+            "Send Rate": float(row[col("send rate")]), "Throughput": float(row[col("recv rate")]),
+            "Latency": float(row[col("avg latency")]), "Loss Rate": float(row[col("loss ratio")]),
+            "Latency Inflation": float(row[col("sent latency inflation")]),
+            "Latency Ratio": float(row[col("latency ratio")]), "Send Ratio": float(row[col("send ratio")])})
+        self.run_dur = float(row[col("run_dur")])
+        self.reward_sum += reward
+        return obs[0].cpu().numpy(), reward, bool(done[0].item()), {}
+
+    def render(self, mode="human"):
+        pass
+
+    def close(self):
+        self._env.close()
+
+    def dump_events_to_file(self, filename):
+        import json
+        with open(filename, "w") as f:
+            json.dump(self.event_record, f, indent=4)
+
+
+def make(env_id="PccNs-v0", **kwargs):
+    """``gym.make('PccNs-v0')`` without gym (ns:498 registers that id)."""
+    if env_id != "PccNs-v0":
+        raise KeyError("unknown env id %r (only 'PccNs-v0' is provided)" % (env_id,))
+    return SimulatedNetworkEnv(**kwargs)
+
+
+def register_gym():
+    """Register 'PccNs-v0' with gym/gymnasium when one of them is installed (ns:498)."""
+    done = []
+    for mod in ("gymnasium", "gym"):
+        try:
+            reg = __import__(mod + ".envs.registration", fromlist=["register"]).register
+            reg(id="PccNs-v0", entry_point="pcc_rl_amd:SimulatedNetworkEnv")
+            done.append(mod)
+        except Exception:
+            continue
+    return done

@@ -1,0 +1,85 @@
+"""ctypes binding of the C ABI declared in include/pcc_sim.h.
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded, importing the
+binding's entry points raises, loudly, with the build command to run."""
+import ctypes
+import os
+
+from .build import library_path
+
+PCC_RNG_PHILOX, PCC_RNG_TRACE = 0, 1
+PCC_FLAG_RING_OVERFLOW, PCC_FLAG_TRACE_OVERRUN = 1, 2
+PCC_STEP_COLS = 19
+STEP_COLUMNS = ["sent", "acked", "lost", "rate", "cur_time", "run_dur", "reward",
+                "send rate", "recv rate", "recv dur", "send dur", "avg latency", "loss ratio",
+                "ack latency inflation", "sent latency inflation", "conn min latency",
+                "latency increase", "latency ratio", "send ratio"]
+
+# name -> (field id, torch dtype name, per-sender?)
+FIELDS = {
+    "bw": (0, "float64", False), "dl": (1, "float64", False), "lr": (2, "float64", False),
+    "maxq": (3, "float64", False), "queue_delay": (4, "float64", False), "queue_time": (5, "float64", False),
+    "now": (6, "float64", False), "run_dur": (7, "float64", False), "steps": (8, "int32", False),
+    "episode": (9, "int32", False), "flags": (10, "int32", False), "rate": (11, "float64", True),
+    "rate0": (12, "float64", True), "next_send": (13, "float64", True), "min_lat": (14, "float64", True),
+    "ring_head": (15, "int32", True), "ring_mid": (16, "int32", True), "ring_tail": (17, "int32", True),
+    "ep_return": (18, "float64", True), "last_return": (19, "float64", True), "total_sent": (20, "int64", False),
+}
+
+# every symbol include/pcc_sim.h declares
+SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
+           "pcc_set_rng", "pcc_set_seed", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step",
+           "pcc_get_state", "pcc_metric_info", "pcc_device_bytes"]
+
+
+class PccError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("pcc_sim error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """The loaded HIP library (loads it on first use; never falls back to anything else)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback." % path)
+    L = ctypes.CDLL(path)
+    vp, i32, i64, u32, u64, dbl = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32,
+                                   ctypes.c_uint64, ctypes.c_double)
+    L.pcc_last_error.restype = ctypes.c_char_p
+    L.pcc_last_error.argtypes = []
+    L.pcc_create.argtypes = [i64, i32, i32, ctypes.POINTER(ctypes.c_int32), i32, u64, u32, u32, i32,
+                             ctypes.POINTER(vp)]
+    L.pcc_destroy.restype = None
+    L.pcc_destroy.argtypes = [vp]
+    L.pcc_set_link_params.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.pcc_set_param_ranges.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
+    L.pcc_set_rng.argtypes = [vp, i32, vp, i64]
+    L.pcc_set_seed.argtypes = [vp, u64]
+    L.pcc_set_delta_scale.argtypes = [vp, dbl]
+    L.pcc_set_max_steps.argtypes = [vp, i32]
+    L.pcc_reset.argtypes = [vp, vp, vp, vp]
+    L.pcc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
+    L.pcc_get_state.argtypes = [vp, i32, vp, vp]
+    L.pcc_metric_info.argtypes = [i32, ctypes.POINTER(dbl), ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
+    L.pcc_device_bytes.restype = i64
+    L.pcc_device_bytes.argtypes = [vp]
+    for fn in ("pcc_create", "pcc_set_link_params", "pcc_set_param_ranges", "pcc_set_rng", "pcc_set_seed",
+               "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_get_state",
+               "pcc_metric_info"):
+        getattr(L, fn).restype = i32
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != 0:
+        raise PccError(code, lib().pcc_last_error().decode("utf-8", "replace"))

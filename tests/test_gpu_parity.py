@@ -1,0 +1,214 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes -> libpcc_sim.so), against
+(1) the golden vectors generated from the reference and (2) the CPU oracle on seeded inputs.
+Integer counts must be equal; every float (clock, run_dur, reward, all 12 metrics) is
+compared bit-for-bit; float32 observations must equal the float32 cast of the oracle's."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import pcc_rl_amd
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+def load(name):
+    with np.load(os.path.join(G, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def run_gpu(env, actions, n_steps):
+    """actions [N, T(, S)] float64 numpy; returns steps [N, (S,) T, 19], obs [N, (S,) T, HF]."""
+    acts = torch.as_tensor(actions, dtype=torch.float64, device=DEV)
+    rows, obs, dones = [], [], []
+    for t in range(n_steps):
+        o, r, d, info = env.step(acts[:, t])
+        rows.append(info["steps"].clone())
+        obs.append(o.clone())
+        dones.append(d.clone())
+    torch.cuda.synchronize()
+    env.check_flags()
+    ax = 1 if env.n_senders == 1 else 2
+    return (torch.stack(rows, ax).cpu().numpy(), torch.stack(obs, ax).cpu().numpy(),
+            torch.stack(dones, 1).cpu().numpy())
+
+
+def golden_env(d, history_len=10, features=None, n_senders=1):
+    """Batch of the golden cases in trace mode: parameters from the fixture, loss uniforms =
+    the MT19937 stream random.Random(seed) continues with after the parameter draws."""
+    n = d["seed"].shape[0]
+    feats = [str(f) for f in d["features"]] if features is None and "features" in d else (features or pcc_rl_amd.DEFAULT_FEATURES)
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, history_len=history_len, features=feats,
+                                       n_senders=n_senders, record_steps=True, auto_reset=False)
+    p = d["params"]
+    if n_senders == 1:
+        env.set_link_params(p[:, 0], p[:, 1], np.round(p[:, 2]), p[:, 3], p[:, 4])
+    else:
+        env.set_link_params(p[:, 0], p[:, 1], np.round(p[:, 2]), p[:, 3], p[:, 4:6])
+    k = int((d["rng"][:, 1] - d["rng"][:, 0]).max())
+    trace = np.stack([oracle.mt_uniforms(int(s), k, skip=int(o)) for s, o in zip(d["seed"], d["rng"][:, 0])])
+    env.set_loss_trace(trace)
+    return env
+
+
+@pytest.mark.parametrize("name", ["default_pm1", "saturating_0_2", "clamp_pm30", "allfeat_h3", "fixed_cfg2",
+                                  "fixed_q1", "fixed_lossy", "fixed_deepq"])
+def test_golden_vectors_bit_exact(name):
+    d = load(name)
+    if name == "two_episodes":
+        pytest.skip("covered separately")
+    env = golden_env(d, history_len=int(d["history_len"]))
+    obs0 = env.reset().cpu().numpy()
+    assert np.array_equal(obs0, d["obs0"].astype(np.float32))
+    assert np.array_equal(env.state("now").cpu().numpy(), d["warm"][:, 0])
+    in_flight = (env.state("ring_tail") - env.state("ring_head"))[0].cpu().numpy()
+    # heap length after warm-up = packets in flight + the pending SEND
+    assert np.array_equal(in_flight + 1, d["warm"][:, 1].astype(np.int64))
+    T = d["actions"].shape[1]
+    steps, obs, done = run_gpu(env, d["actions"], T)
+    assert np.array_equal(steps[..., :3], d["steps"][..., :3]), "sent/acked/lost"
+    assert np.array_equal(steps, d["steps"]), "clocks, reward, metrics"
+    nf = d["obs_tail"].shape[2]
+    assert np.array_equal(obs[..., -nf:], d["obs_tail"].astype(np.float32))
+    k = d["obs_full"].shape[0]
+    assert np.array_equal(obs[:k], d["obs_full"].astype(np.float32))
+    assert np.array_equal(done, d["done"])
+    env.close()
+
+
+def test_two_sender_golden_bit_exact():
+    d = load("two_sender")
+    d["features"] = np.array(pcc_rl_amd.DEFAULT_FEATURES.split(","))
+    env = golden_env(d, n_senders=2)
+    env.reset()
+    assert np.array_equal(env.state("now").cpu().numpy(), d["warm"][:, 0])
+    T = d["actions"].shape[1]
+    steps, obs, _ = run_gpu(env, d["actions"], T)
+    assert np.array_equal(steps[..., :3], d["steps"][..., :3])
+    assert np.array_equal(steps, d["steps"])
+    assert np.array_equal(obs[..., -3:], d["obs_tail"].astype(np.float32))
+    env.close()
+
+
+@pytest.mark.parametrize("n_envs,n_steps,seed", [(4096, 60, 11), (777, 400, 5)])
+def test_philox_batches_match_oracle(n_envs, n_steps, seed):
+    """Randomized parameters drawn on the device vs the oracle drawing them on the host from the
+    same Philox stream; N not a multiple of the wavefront exercises the ragged tail."""
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, env_gid_base=1000, record_steps=True,
+                                       auto_reset=False)
+    obs0 = env.reset().cpu().numpy()
+    rs = np.random.RandomState(seed)
+    acts = rs.uniform(-1, 1, (n_envs, n_steps))
+    steps, obs, done = run_gpu(env, acts, n_steps)
+    ref = oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=seed, env_gid_base=1000)
+    # parameters (bw, dl, queue, lr, rate0)
+    assert np.array_equal(env.state("bw").cpu().numpy(), ref["params"][:, 0])
+    assert np.array_equal(env.state("dl").cpu().numpy(), ref["params"][:, 1])
+    assert np.array_equal(env.state("lr").cpu().numpy(), ref["params"][:, 3])
+    assert np.array_equal(env.state("rate0")[0].cpu().numpy(), ref["params"][:, 4])
+    assert np.array_equal(obs0, ref["obs0"].astype(np.float32))
+    bad = np.argwhere((steps[..., :3] != ref["steps"][..., :3]).any(axis=(1, 2)))
+    assert bad.size == 0, "envs with count mismatches: %s" % bad[:10].ravel()
+    assert np.array_equal(steps, ref["steps"])
+    assert np.array_equal(obs, ref["obs"].astype(np.float32))
+    assert done[:, -1].all() == (n_steps >= 400)
+    env.close()
+
+
+def test_config2_fixed_params_all_envs_identical():
+    """BASELINE.json configs[1]: 4096 envs, fixed link (200 pkt/s, 30 ms, queue 5, no loss),
+    rate0 60: deterministic, so every env must reproduce the golden episode exactly."""
+    d = load("fixed_cfg2")
+    N = 4096
+    env = pcc_rl_amd.BatchedNetworkEnv(N, device=DEV, record_steps=True, auto_reset=False,
+                                       link_params=(200.0, 0.03, 5.0, 0.0, 60.0))
+    env.reset()
+    acts = np.tile(d["actions"][0][None, :], (N, 1))
+    steps, obs, _ = run_gpu(env, acts, 400)
+    assert np.array_equal(steps[0], d["steps"][0])
+    assert (steps == steps[0:1]).all()
+    env.close()
+
+
+def test_auto_reset_and_second_episode_match_oracle():
+    n_envs, seed = 256, 3
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=True,
+                                       max_steps=25)
+    env.reset()
+    rs = np.random.RandomState(1)
+    acts = rs.uniform(-1, 1, (n_envs, 50))
+    steps, obs, done = run_gpu(env, acts, 50)
+    assert done[:, 24].all() and done[:, 49].all() and done.sum() == 2 * n_envs
+    # oracle: same env objects run two 25-step episodes (MAX_STEPS is 400 there, so drive resets by hand)
+    ref1 = oracle.run_batch(acts[:, :25], rng_mode=oracle.RNG_PHILOX, seed=seed)
+    assert np.array_equal(steps[:, :25], ref1["steps"])
+    # after the auto-reset the observation row is the fresh-episode observation
+    assert np.array_equal(obs[:, 24], ref1["obs0"].astype(np.float32))
+    ref2 = oracle.run_batch(np.concatenate([acts[:, 25:], acts[:, 25:]], 0)[:n_envs], rng_mode=oracle.RNG_PHILOX,
+                            seed=seed, n_episodes=2)
+    # episode index 1 of the same envs (run_batch returns the last episode)
+    ref2 = oracle.run_batch(acts[:, 25:], rng_mode=oracle.RNG_PHILOX, seed=seed, n_episodes=2)
+    assert np.array_equal(steps[:, 25:, :3], ref2["steps"][..., :3])
+    ret = env.episode_returns().cpu().numpy()
+    assert np.allclose(ret, ref2["steps"][..., 6].sum(1), rtol=1e-12)
+    env.close()
+
+
+def test_conservation_and_queue_bounds_at_full_size():
+    """Size-independent properties at BASELINE's 65 536 envs: every packet sent is acked, lost
+    or still in flight; the queue never exceeds its limit; clocks only move forward."""
+    N = 65536
+    env = pcc_rl_amd.BatchedNetworkEnv(N, device=DEV, seed=0, record_steps=True, auto_reset=False)
+    env.reset()
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    sent0 = env.state("ring_tail")[0].clone().long()
+    head0 = env.state("ring_head")[0].clone().long()
+    acked = torch.zeros(N, dtype=torch.float64, device=DEV)
+    sent = torch.zeros_like(acked)
+    now_prev = env.state("now").clone()
+    for t in range(40):
+        a = torch.rand((N,), generator=gen, device=DEV) * 2 - 1
+        o, r, d, info = env.step(a)
+        s = info["steps"]
+        sent += s[:, 0]
+        acked += s[:, 1] + s[:, 2]
+        now = env.state("now")
+        assert bool((now > now_prev).all())
+        now_prev = now.clone()
+        assert bool((env.state("queue_delay") <= env.state("maxq")).all())
+        assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(r).all())
+    env.check_flags()
+    tail, head = env.state("ring_tail")[0].long(), env.state("ring_head")[0].long()
+    assert bool(((tail - sent0).double() == sent).all())
+    assert bool(((head - head0).double() == acked).all())
+    assert bool((tail >= env.state("ring_mid")[0].long()).all()) and bool((env.state("ring_mid")[0].long() >= head).all())
+    env.close()
+
+
+def test_old_gym_adapter_drop_in():
+    """An agent loop written against the reference env (reset / step([a]) / done) runs unchanged."""
+    d = load("default_pm1")
+    p = d["params"][0]
+    env = pcc_rl_amd.SimulatedNetworkEnv(device=DEV, link_params=(p[0], p[1], round(p[2]), p[3], p[4]))
+    with pytest.raises(TypeError):
+        env.step([0.0])
+    assert env.seed(5) == [5]
+    env._env.set_loss_trace(oracle.mt_uniforms(0, int(d["rng"][0, 1]), skip=10)[None, :])
+    obs = env.reset()
+    assert obs.shape == (30,) and obs.dtype == np.float32
+    assert env.observation_space.shape == (30,) and env.action_space.shape == (1,)
+    assert np.array_equal(obs, np.tile([0.0, 1.0, 1.0], 10).astype(np.float32))
+    total, done, t = 0.0, False, 0
+    while not done:
+        obs, rew, done, info = env.step([d["actions"][0, t]])
+        assert isinstance(rew, float) and isinstance(done, bool) and info == {}
+        assert rew == d["steps"][0, t, 6]
+        total += rew
+        t += 1
+    assert t == 400 and total == 625.6196947931776   # SURVEY.md section 8(c) KAT
+    assert len(env.event_record["Events"]) == 400
+    env.close()
