@@ -170,6 +170,11 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream);
  * get_min_obs_vector / get_max_obs_vector (so:95-108) are these tiled H times. */
 int pcc_metric_info(int id, double *min_val, double *max_val, double *scale);
 
+/* diagnostics: when buf (device, u64 [N][8]) is non-NULL every pcc_step stores per env the shader-
+ * clock stamps {MI start, SEND stream start, SEND stream end, streams done, MI done, step done} and
+ * the counts {packets sent, packets retired}.  NULL (default) turns it off. */
+int pcc_set_profile_buffer(pcc_sim_t *sim, uint64_t *buf);
+
 /* bytes of device memory the handle owns */
 int64_t pcc_device_bytes(const pcc_sim_t *sim);
 

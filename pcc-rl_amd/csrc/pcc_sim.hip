@@ -92,6 +92,7 @@ struct Dev {
     uint32_t *h2, *h1, *tail;
     float *hist;    // [N][S][HF]
     double2 *ring;  // [N][S][cap]
+    unsigned long long *prof;  // optional [N][8] cycle stamps per step (diagnostics), else null
 };
 
 // --------------------------------------------------------------------------------------
@@ -252,7 +253,7 @@ __device__ __forceinline__ void hop1_event(Env<NS> &e, uint32_t mask, double2 re
 // c.from[s] is where they started.
 template <int NS>
 __device__ __forceinline__ void run_mi(Env<NS> &e, Rng<NS> &rng, double dur, uint32_t mask, uint32_t cap,
-                                       MiCounts<NS> &c) {
+                                       MiCounts<NS> &c, unsigned long long *ts = nullptr) {
     const double end = e.now + dur;  // ns:124
     c.start = e.now;                 // ns:319-324 reset_obs
     double gap[NS];
@@ -263,52 +264,63 @@ __device__ __forceinline__ void run_mi(Env<NS> &e, Rng<NS> &rng, double dur, uin
         gap[s] = 1.0 / e.rate[s];
         rng.j[s] = 0;
     }
+    if (ts) ts[0] = clock64();
     if (!(e.now < end)) return;  // ns:128 loop never entered
 
-    // ---- SEND stream: every SEND with time < end
-    Last last[NS];
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        last[s].have = e.tail[s] > e.h1[s];
-        if (last[s].have) last[s].rec = e.ring[s][(e.tail[s] - 1) & mask];
-    }
-    if (NS == 1) {
-        while (e.nsend[0] < end) send_packet<NS, 0>(e, rng, gap, mask, cap, last[0], c);
-    } else {
-        for (;;) {
-            // (time, sender id): lower id first on equal times
-            const bool pick1 = e.nsend[NS - 1] < e.nsend[0];
-            const double t = pick1 ? e.nsend[NS - 1] : e.nsend[0];
-            if (!(t < end)) break;
-            if (pick1) send_packet<NS, NS - 1>(e, rng, gap, mask, cap, last[NS - 1], c);
-            else send_packet<NS, 0>(e, rng, gap, mask, cap, last[0], c);
-        }
-    }
-
-    // ---- hop-1 stream, then hop-2 stream, per sender
+    // Two passes keep ring occupancy at the true in-flight count: pass 0 retires what was already in
+    // flight (hop-1 then hop-2 events before `end`), pass 1 runs the SEND stream and then the events
+    // those sends produced inside this MI.  Order between streams is free (see file header).
     double t1[NS], t2[NS];
     double2 r1[NS], r2[NS];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) {
+            if (ts) ts[1] = clock64();
+            // ---- SEND stream: every SEND with time < end
+            Last last[NS];
 #pragma unroll
-    for (int s = 0; s < NS; s++) {
-        Last last2;
-        last2.have = e.h1[s] > e.h2[s];
-        if (last2.have) last2.rec = e.ring[s][(e.h1[s] - 1) & mask];
-        t1[s] = INFINITY;
-        while (e.h1[s] < e.tail[s]) {
-            const double2 rec = e.ring[s][e.h1[s] & mask];
-            if (!(rec.x < end)) { t1[s] = rec.x; r1[s] = rec; break; }
-            if (s == 0) hop1_event<NS, 0>(e, mask, rec, last2);
-            else hop1_event<NS, NS - 1>(e, mask, rec, last2);
+            for (int s = 0; s < NS; s++) {
+                last[s].have = e.tail[s] > e.h1[s];
+                if (last[s].have) last[s].rec = e.ring[s][(e.tail[s] - 1) & mask];
+            }
+            if (NS == 1) {
+                while (e.nsend[0] < end) send_packet<NS, 0>(e, rng, gap, mask, cap, last[0], c);
+            } else {
+                for (;;) {
+                    // (time, sender id): lower id first on equal times
+                    const bool pick1 = e.nsend[NS - 1] < e.nsend[0];
+                    const double t = pick1 ? e.nsend[NS - 1] : e.nsend[0];
+                    if (!(t < end)) break;
+                    if (pick1) send_packet<NS, NS - 1>(e, rng, gap, mask, cap, last[NS - 1], c);
+                    else send_packet<NS, 0>(e, rng, gap, mask, cap, last[0], c);
+                }
+            }
+            if (ts) ts[2] = clock64();
         }
-        t2[s] = INFINITY;
-        while (e.h2[s] < e.h1[s]) {
-            const double2 rec = e.ring[s][e.h2[s] & mask];
-            if (!(rec.x < end)) { t2[s] = rec.x; r2[s] = rec; break; }
-            if (rec_dropped(rec)) c.lost[s]++;   // ns:141-143
-            else c.acked[s]++;                   // ns:144-146
-            e.h2[s]++;
+        // ---- hop-1 stream, then hop-2 stream, per sender
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            Last last2;
+            last2.have = e.h1[s] > e.h2[s];
+            if (last2.have) last2.rec = e.ring[s][(e.h1[s] - 1) & mask];
+            t1[s] = INFINITY;
+            while (e.h1[s] < e.tail[s]) {
+                const double2 rec = e.ring[s][e.h1[s] & mask];
+                if (!(rec.x < end)) { t1[s] = rec.x; r1[s] = rec; break; }
+                if (s == 0) hop1_event<NS, 0>(e, mask, rec, last2);
+                else hop1_event<NS, NS - 1>(e, mask, rec, last2);
+            }
+            t2[s] = INFINITY;
+            while (e.h2[s] < e.h1[s]) {
+                const double2 rec = e.ring[s][e.h2[s] & mask];
+                if (!(rec.x < end)) { t2[s] = rec.x; r2[s] = rec; break; }
+                if (rec_dropped(rec)) c.lost[s]++;   // ns:141-143
+                else c.acked[s]++;                   // ns:144-146
+                e.h2[s]++;
+            }
         }
     }
+    if (ts) ts[3] = clock64();
 
     // ---- the event that ends the MI: smallest (time, sender, type 'A'<'S', hop) among the
     // stream heads; all of them are >= end here
@@ -628,7 +640,9 @@ __global__ __launch_bounds__(kWave) void step_kernel(Dev D, const void *actions,
     Rng<NS> rng;
     init_rng<NS>(D, i, D.episode[i] - 1, steps + 2, rng);
     MiCounts<NS> c;
-    run_mi<NS>(e, rng, run_dur, D.cap_mask, D.cap, c);
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    run_mi<NS>(e, rng, run_dur, D.cap_mask, D.cap, c, D.prof ? ts : nullptr);
+    if (D.prof) ts[4] = clock64();
     const double dur = e.now - c.start;  // ns:311-314
 
     // ---- metrics, history, reward
@@ -697,6 +711,13 @@ __global__ __launch_bounds__(kWave) void step_kernel(Dev D, const void *actions,
     const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
     D.done[i] = done;
     if (done_out) done_out[i] = done;
+    if (D.prof) {
+        ts[5] = clock64();
+        ts[6] = c.sent[0];
+        ts[7] = c.acked[0] + c.lost[0];
+#pragma unroll
+        for (int k = 0; k < 8; k++) D.prof[i * 8 + k] = ts[k];
+    }
 }
 
 }  // namespace
@@ -888,6 +909,12 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     sim->d.key0 = (uint32_t)seed;
     sim->d.key1 = (uint32_t)(seed >> 32);
+    return PCC_OK;
+}
+
+int pcc_set_profile_buffer(pcc_sim_t *sim, uint64_t *buf) {
+    if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    sim->d.prof = reinterpret_cast<unsigned long long *>(buf);
     return PCC_OK;
 }
 
