@@ -80,7 +80,7 @@ enum {
     PCC_F_NEXT_SEND,     /* f64 [S][N]  time of the pending SEND event       (ns:111,161) */
     PCC_F_MIN_LAT,       /* f64 [S][N]  connection min of per-MI mean RTT, 0 = none (so:158-176) */
     PCC_F_RING_HEAD,     /* u32 [S][N]  packets fully acknowledged/lost this episode  */
-    PCC_F_RING_MID,      /* u32 [S][N]  packets past the first (forward) hop          */
+    PCC_F_RING_MID,      /* u32 [S][N]  lower bound of the packets past the forward hop */
     PCC_F_RING_TAIL,     /* u32 [S][N]  packets sent this episode                     */
     PCC_F_EP_RETURN,     /* f64 [S][N]  reward summed over the running episode (ns:442) */
     PCC_F_LAST_RETURN,   /* f64 [S][N]  return of the last finished episode            */
@@ -101,8 +101,9 @@ const char *pcc_last_error(void);
  *   n_senders       1 (the reference env, ns:466) or 2 (two senders on the shared bottleneck).
  *   seed            Philox key.  env_gid_base: global id of env 0 (rank * n_envs when the
  *                   batch is sharded over GPUs) so results do not depend on the sharding.
- *   ring_capacity   power of two, per env per sender, in packets (0 = default 32768, the
- *                   worst case rate_max * (2*dl_max + queue_max/bw_min) of the default ranges).
+ *   ring_capacity   power of two, per env per sender, in packets (0 = default 65536: the
+ *                   worst case of the default ranges is rate_max * (RTT_max + one MI) =
+ *                   1000 * (30.8 + 15.4) = 46.2k packets between two retire passes).
  *   device_id       HIP device ordinal (-1 = current device).
  * No env is usable before pcc_reset.
  */
@@ -169,11 +170,6 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream);
 /* bounds and scale of metric `id`: (min_val, max_val, scale) of so:193-206; host pointers.
  * get_min_obs_vector / get_max_obs_vector (so:95-108) are these tiled H times. */
 int pcc_metric_info(int id, double *min_val, double *max_val, double *scale);
-
-/* diagnostics: when buf (device, u64 [N][8]) is non-NULL every pcc_step stores per env the shader-
- * clock stamps {MI start, SEND stream start, SEND stream end, streams done, MI done, step done} and
- * the counts {packets sent, packets retired}.  NULL (default) turns it off. */
-int pcc_set_profile_buffer(pcc_sim_t *sim, uint64_t *buf);
 
 /* bytes of device memory the handle owns */
 int64_t pcc_device_bytes(const pcc_sim_t *sim);

@@ -5,30 +5,35 @@
 // Network.run_for_dur (ns:123-205) with its Link queue model (ns:56-96) and Sender
 // accounting (ns:207-342), the monitor-interval metrics + history (so:20-206) and the env
 // protocol around them (ns:344-496) -- for N independent envs advanced one monitor interval
-// (MI) per launch.
+// (MI) per step.
 //
-// Formulation (NOT the reference's heap):
-//   * For one sender the heap only ever holds three kinds of events: the single pending SEND,
-//     packets on the forward hop ("hop-1" events) and packets on the return hop ("hop-2"
-//     events).  Heap pop order == global order of each kind by the tuple key
-//     (time, ..., latency, dropped), so each kind is a key-sorted FIFO.
-//   * Link state and the loss RNG are touched only by SEND events, and the rate is constant
-//     inside an MI, so an MI can be processed stream by stream: all SENDs before the MI end,
-//     then all hop-1 events, then all hop-2 events, then the single event that ends the MI
-//     (the first event with time >= end, which the reference still processes, ns:128-131).
-//   * In-flight packets live in one HBM ring per env per sender: 16-byte records
-//     (fp64 event time, fp64 accumulated latency with the drop flag in its sign bit).  The
-//     ring is [head, mid) = hop-2 region, [mid, tail) = hop-1 region; a hop-1 event is
-//     converted in place.  Records are kept key-sorted by insertion from the back (float
-//     rounding makes a dropped packet and its successor arrive "at the same time", and the
-//     tuple tie-break decides who ends an MI).
-//   * Every floating-point operation on the timeline is IEEE binary64 in the reference's
-//     order (compile with -ffp-contract=off); the per-MI RTT means replicate numpy's
-//     pairwise summation, because run_dur = 0.5 * mean feeds back into the event boundaries.
+// Formulation (NOT the reference's heap; DESIGN.md section 3 has the arguments):
+//   * For one sender the heap only ever holds the single pending SEND, packets on the forward
+//     hop ("hop-1" events, time t1) and packets on the return hop ("hop-2" events, time
+//     t2 = t1 + dl).  Link state and the loss RNG are touched only by SEND events and the rate
+//     is constant inside an MI, so an MI splits into (1) the SEND stream -- a sequential
+//     recurrence per env -- and (2) retiring the packets whose events fall before the MI end.
+//   * In-flight packets live in one HBM ring per env per sender, appended in send order as
+//     16-byte records (fp64 t1, fp64 forward latency with the drop flag in its sign bit).
+//     Records are never rewritten: t2 and the RTT are t1 + dl and latency + dl, recomputed.
+//   * Send order IS event order except inside a "drop run" (a run of dropped packets plus the
+//     packet that ends it): those arrive at mathematically equal times, so float rounding and
+//     the heap's tuple tie-break (time, latency, dropped) decide their order.  Runs are
+//     separated by >= 1/bw, acknowledged packets are always in send order, and only the MI
+//     boundary can cut through a run -- so exactness needs order only inside the one run at
+//     each boundary, handled by a small serial path.
+//   * Every floating-point operation on the timeline is IEEE binary64 in the reference's order
+//     (compile with -ffp-contract=off).  The per-MI RTT means replicate numpy's pairwise
+//     summation bit for bit, because run_dur = 0.5 * mean feeds back into event boundaries.
 //
-// Mapping: one lane per env, one 64-lane wavefront per workgroup; SoA state so that lane i
-// of a wave touches element i of every array (coalesced); no LDS, no MFMA (there is no
-// contraction anywhere on this path).
+// Kernels per step:
+//   send_kernel    one lane per env: apply the action, run the SEND recurrence up to the MI end,
+//                  append records (no loads in the loop).
+//   retire_kernel  16 lanes per env: coalesced scans of the ring for the hop-2 / hop-1
+//                  boundaries (ballots + popcounts), the MI-ending event, RTT sums through an
+//                  LDS-staged stream with numpy's pairwise tree laid over 8-lane groups,
+//                  metrics, history, observation, reward, done.
+// No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -45,6 +50,9 @@ namespace {
 constexpr int kMaxFeatures = 16;
 constexpr int kMaxSenders = 2;
 constexpr int kWave = 64;
+constexpr int kGroup = 16;            // lanes per env in retire_kernel
+constexpr int kRetireBlock = 256;     // 16 envs per workgroup
+constexpr int kStage = 64;            // LDS-staged RTT samples per env (doubles)
 constexpr double kMaxRate = 1000.0;      // ns:36
 constexpr double kMinRate = 40.0;        // ns:37
 constexpr double kRewardScale = 0.001;   // ns:39
@@ -85,14 +93,13 @@ struct Dev {
     // link + env state, [N]
     double *bw, *dl, *lr, *maxq, *ebw, *q, *tu, *now, *run_dur;
     uint32_t *steps, *episode, *flags;
-    uint8_t *done;
+    uint8_t *done, *resetting;
     unsigned long long *total_sent;
     // per sender, [S][N]
     double *rate, *rate0, *next_send, *min_lat, *ep_return, *last_return;
-    uint32_t *h2, *h1, *tail;
+    uint32_t *h2, *c1, *tail, *mi_sent;
     float *hist;    // [N][S][HF]
     double2 *ring;  // [N][S][cap]
-    unsigned long long *prof;  // optional [N][8] cycle stamps per step (diagnostics), else null
 };
 
 // --------------------------------------------------------------------------------------
@@ -102,24 +109,13 @@ __device__ __forceinline__ double max0(double x) { return x > 0.0 ? x : 0.0; }  
 
 __device__ __forceinline__ bool rec_dropped(double2 r) { return __double_as_longlong(r.y) < 0; }
 
-// Python tuple order on (time, latency, dropped) -- the fields that can differ inside one
-// stream of one sender (ns:111,161,178)
-__device__ __forceinline__ bool key_less(double2 a, double2 b) {
-    if (a.x != b.x) return a.x < b.x;
-    const double la = fabs(a.y), lb = fabs(b.y);
+// Python tuple order on (time, latency, dropped): the fields that can differ between two events
+// of the same kind of one sender (ns:111,161,178).  y carries the drop flag in its sign.
+__device__ __forceinline__ bool key_less(double ta, double ya, double tb, double yb) {
+    if (ta != tb) return ta < tb;
+    const double la = fabs(ya), lb = fabs(yb);
     if (la != lb) return la < lb;
-    return !rec_dropped(a) && rec_dropped(b);
-}
-
-__device__ __forceinline__ void insert_sorted(double2 *ring, uint32_t mask, uint32_t lo, uint32_t pos,
-                                              double2 rec) {
-    while (pos > lo) {
-        const double2 prev = ring[(pos - 1) & mask];
-        if (!key_less(rec, prev)) break;
-        ring[pos & mask] = prev;
-        pos--;
-    }
-    ring[pos & mask] = rec;
+    return (__double_as_longlong(ya) >= 0) && (__double_as_longlong(yb) < 0);
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -137,338 +133,426 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __device__ __forceinline__ double u32_to_unit(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
 
-// --------------------------------------------------------------------------------------
-// one env in registers
-// --------------------------------------------------------------------------------------
-template <int NS>
-struct Env {
-    double dl, lr, maxq, ebw;  // link parameters (ns:59-64); ebw = 1.0 / bw (ns:77)
-    double q, tu;              // link-0 queue delay and its update time (ns:62-63)
-    double now;                // network clock (ns:102)
-    double rate[NS], nsend[NS];
-    uint32_t h2[NS], h1[NS], tail[NS];
-    double2 *ring[NS];
-    uint32_t flags;
-};
-
-template <int NS>
-struct Rng {
-    int mode;
-    const double *trace;  // this env's row
-    int64_t trace_n;
-    uint32_t k0, k1, gid, episode, mi;
-    uint32_t j[NS];
-    uint32_t w[NS][4];
-};
-
-template <int NS>
-struct MiCounts {
-    uint32_t sent[NS], acked[NS], lost[NS], from[NS];
-    double start;
-};
-
-// hop-1 region tail bookkeeping for the sorted push
-struct Last {
-    double2 rec;
-    bool have;
-};
-
-template <int NS, int s>
-__device__ __forceinline__ double packet_uniform(Env<NS> &e, Rng<NS> &r) {
-    if (r.mode == PCC_RNG_TRACE) {
-        uint64_t pos = e.tail[0];
-        if (NS > 1) pos += e.tail[NS - 1];
-        if ((int64_t)pos >= r.trace_n) { e.flags |= PCC_FLAG_TRACE_OVERRUN; return 1.0; }
-        return r.trace[pos];
-    }
-    const uint32_t jj = r.j[s]++;
-    if ((jj & 3u) == 0u) philox4x32_10(jj >> 2, r.mi + ((uint32_t)s << 24), r.episode, r.gid, r.k0, r.k1, r.w[s]);
-    const uint32_t i = jj & 3u;
-    const uint32_t x = i == 0 ? r.w[s][0] : i == 1 ? r.w[s][1] : i == 2 ? r.w[s][2] : r.w[s][3];
-    return u32_to_unit(x);
+// loss uniform of the j-th SEND of sender s in monitor interval mi (the draw of ns:73)
+__device__ __forceinline__ double philox_packet_uniform(const Dev &D, uint32_t gid, uint32_t episode, uint32_t mi,
+                                                        int s, uint32_t j) {
+    uint32_t w[4];
+    philox4x32_10(j >> 2, mi + ((uint32_t)s << 24), episode, gid, D.key0, D.key1, w);
+    const uint32_t i = j & 3u;
+    return u32_to_unit(i == 0 ? w[0] : i == 1 ? w[1] : i == 2 ? w[2] : w[3]);
 }
 
-// SEND event at time t for sender s: ns:155-178 with Link.packet_enters_link ns:72-84
-template <int NS, int s>
-__device__ __forceinline__ void send_packet(Env<NS> &e, Rng<NS> &rng, const double (&gap)[NS], uint32_t mask,
-                                            uint32_t cap, Last &last, MiCounts<NS> &c) {
-    const double t = e.nsend[s];
-    c.sent[s]++;                                   // ns:260-262
-    e.nsend[s] = t + gap[s];                       // ns:161
-    const double qcur = max0(e.q - (t - e.tu));    // ns:66-67
-    const double lat0 = e.dl + qcur;               // ns:170 (latency before this packet queues)
-    const double u = packet_uniform<NS, s>(e, rng);
+// Link.packet_enters_link + latency sampling for one SEND at time t: ns:66-84, 170-175.
+// Returns the record (t + lat0, +-lat0).
+__device__ __forceinline__ double2 link_send(double t, double u, double dl, double lr, double maxq, double ebw,
+                                             double &q, double &tu) {
+    const double qcur = max0(q - (t - tu));  // ns:66-67
+    const double lat0 = dl + qcur;           // ns:170: latency before this packet queues
     bool dropped;
-    if (u < e.lr) {                                // ns:73-74: random loss leaves the queue untouched
+    if (u < lr) {                            // ns:73-74: random loss leaves the queue untouched
         dropped = true;
     } else {
-        e.q = qcur;                                // ns:75-76
-        e.tu = t;
-        if (e.ebw + e.q > e.maxq) {                // ns:79-81 tail drop
+        q = qcur;                            // ns:75-76
+        tu = t;
+        if (ebw + q > maxq) {                // ns:79-81 tail drop
             dropped = true;
         } else {
-            e.q += e.ebw;                          // ns:82
+            q += ebw;                        // ns:82
             dropped = false;
         }
     }
     double2 rec;
-    rec.x = t + lat0;                              // ns:174
-    rec.y = dropped ? -lat0 : lat0;                // ns:173 (0.0 + lat0), ns:175
-    if (e.tail[s] - e.h2[s] >= cap) {              // ring full: never silent
-        e.flags |= PCC_FLAG_RING_OVERFLOW;
-        return;
-    }
-    double2 *ring = e.ring[s];
-    if (!last.have || !key_less(rec, last.rec)) {
-        ring[e.tail[s] & mask] = rec;
-        last.rec = rec;
-    } else {
-        insert_sorted(ring, mask, e.h1[s], e.tail[s], rec);  // last stays the region maximum
-    }
-    last.have = true;
-    e.tail[s]++;
+    rec.x = t + lat0;                        // ns:174
+    rec.y = dropped ? -lat0 : lat0;          // ns:173 (0.0 + lat0), ns:175
+    return rec;
 }
 
-// hop-1 event of sender s (ns:147-154): link 1 is never entered by a packet, so its latency is
-// dl + max(0, 0 - (t - 0)) = dl exactly; the record becomes a hop-2 event in place.
-template <int NS, int s>
-__device__ __forceinline__ void hop1_event(Env<NS> &e, uint32_t mask, double2 rec, Last &last2) {
-    double2 conv;
-    conv.x = rec.x + e.dl;
-    const double l2 = fabs(rec.y) + e.dl;
-    conv.y = rec_dropped(rec) ? -l2 : l2;
-    double2 *ring = e.ring[s];
-    if (!last2.have || !key_less(conv, last2.rec)) {
-        ring[e.h1[s] & mask] = conv;
-        last2.rec = conv;
-    } else {
-        insert_sorted(ring, mask, e.h2[s], e.h1[s], conv);
-    }
-    last2.have = true;
-    e.h1[s]++;
-}
-
-// One monitor interval for one env: Network.run_for_dur, ns:123-178 (reward is computed by the
-// caller from the counts).  On return e.h2[s] has advanced past the hop-2 events consumed;
-// c.from[s] is where they started.
+// ======================================================================================
+// send_kernel: one lane per env.  apply_rate_delta (ns:235-241, 275-281) + every SEND event
+// with time < end of the coming MI (ns:155-178).
+// ======================================================================================
 template <int NS>
-__device__ __forceinline__ void run_mi(Env<NS> &e, Rng<NS> &rng, double dur, uint32_t mask, uint32_t cap,
-                                       MiCounts<NS> &c, unsigned long long *ts = nullptr) {
-    const double end = e.now + dur;  // ns:124
-    c.start = e.now;                 // ns:319-324 reset_obs
-    double gap[NS];
+__global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t warm_mi, const void *actions,
+                                                     int actions_f64) {
+    const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    if (i >= D.n) return;
+    if (warm && !D.resetting[i]) return;
+
+    const double dl = D.dl[i], lr = D.lr[i], maxq = D.maxq[i], ebw = D.ebw[i];
+    double q = D.q[i], tu = D.tu[i];
+    const double now = D.now[i];
+    const double end = now + D.run_dur[i];  // ns:124
+    const uint32_t episode = D.episode[i] - 1;
+    const uint32_t mi = warm ? warm_mi : D.steps[i] + 2;
+    const uint32_t gid = D.gid_base + (uint32_t)i;
+    uint32_t flags = 0;
+
+    double gap[NS], nsend[NS];
+    uint32_t tail[NS], h2[NS], sent[NS];
+    double2 *ring[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        c.sent[s] = c.acked[s] = c.lost[s] = 0;
-        c.from[s] = e.h2[s];
-        gap[s] = 1.0 / e.rate[s];
-        rng.j[s] = 0;
+        const int64_t k = (int64_t)s * D.n + i;
+        double rate = D.rate[k];
+        if (!warm) {
+            const int64_t a = i * NS + s;
+            double delta = actions_f64 ? ((const double *)actions)[a] : (double)((const float *)actions)[a];
+            delta *= D.delta_scale;
+            rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
+            if (rate > kMaxRate) rate = kMaxRate;
+            if (rate < kMinRate) rate = kMinRate;
+            D.rate[k] = rate;
+        }
+        gap[s] = 1.0 / rate;  // ns:161
+        nsend[s] = D.next_send[k];
+        tail[s] = D.tail[k];
+        h2[s] = D.h2[k];
+        sent[s] = 0;
+        ring[s] = D.ring + ((int64_t)i * NS + s) * D.cap;
     }
-    if (ts) ts[0] = clock64();
-    if (!(e.now < end)) return;  // ns:128 loop never entered
+    const double *trace = D.rng_mode == PCC_RNG_TRACE ? D.trace + i * D.trace_stride : nullptr;
 
-    // Two passes keep ring occupancy at the true in-flight count: pass 0 retires what was already in
-    // flight (hop-1 then hop-2 events before `end`), pass 1 runs the SEND stream and then the events
-    // those sends produced inside this MI.  Order between streams is free (see file header).
-    double t1[NS], t2[NS];
-    double2 r1[NS], r2[NS];
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        if (pass == 1) {
-            if (ts) ts[1] = clock64();
-            // ---- SEND stream: every SEND with time < end
-            Last last[NS];
+    if (now < end) {
+        uint32_t w[NS][4];
+        for (;;) {
+            // next SEND in (time, sender id) order
+            int s = 0;
+            if (NS > 1 && nsend[NS - 1] < nsend[0]) s = NS - 1;
+            const double t = (NS > 1 && s) ? nsend[NS - 1] : nsend[0];
+            if (!(t < end)) break;
 #pragma unroll
-            for (int s = 0; s < NS; s++) {
-                last[s].have = e.tail[s] > e.h1[s];
-                if (last[s].have) last[s].rec = e.ring[s][(e.tail[s] - 1) & mask];
-            }
-            if (NS == 1) {
-                while (e.nsend[0] < end) send_packet<NS, 0>(e, rng, gap, mask, cap, last[0], c);
-            } else {
-                for (;;) {
-                    // (time, sender id): lower id first on equal times
-                    const bool pick1 = e.nsend[NS - 1] < e.nsend[0];
-                    const double t = pick1 ? e.nsend[NS - 1] : e.nsend[0];
-                    if (!(t < end)) break;
-                    if (pick1) send_packet<NS, NS - 1>(e, rng, gap, mask, cap, last[NS - 1], c);
-                    else send_packet<NS, 0>(e, rng, gap, mask, cap, last[0], c);
+            for (int ss = 0; ss < NS; ss++) {
+                if (ss != s) continue;
+                double u;
+                if (trace) {
+                    uint64_t pos = tail[0];
+                    if (NS > 1) pos += tail[NS - 1];
+                    if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
+                    else u = trace[pos];
+                } else {
+                    const uint32_t j = sent[ss];
+                    if ((j & 3u) == 0u) philox4x32_10(j >> 2, mi + ((uint32_t)ss << 24), episode, gid, D.key0, D.key1, w[ss]);
+                    const uint32_t x = (j & 3u) == 0 ? w[ss][0] : (j & 3u) == 1 ? w[ss][1] : (j & 3u) == 2 ? w[ss][2] : w[ss][3];
+                    u = u32_to_unit(x);
+                }
+                sent[ss]++;                       // ns:260-262
+                nsend[ss] = t + gap[ss];          // ns:161
+                const double2 rec = link_send(t, u, dl, lr, maxq, ebw, q, tu);
+                if (tail[ss] - h2[ss] >= D.cap) {
+                    flags |= PCC_FLAG_RING_OVERFLOW;  // never silent; the packet is not recorded
+                } else {
+                    ring[ss][tail[ss] & D.cap_mask] = rec;
+                    tail[ss]++;
                 }
             }
-            if (ts) ts[2] = clock64();
-        }
-        // ---- hop-1 stream, then hop-2 stream, per sender
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            Last last2;
-            last2.have = e.h1[s] > e.h2[s];
-            if (last2.have) last2.rec = e.ring[s][(e.h1[s] - 1) & mask];
-            t1[s] = INFINITY;
-            while (e.h1[s] < e.tail[s]) {
-                const double2 rec = e.ring[s][e.h1[s] & mask];
-                if (!(rec.x < end)) { t1[s] = rec.x; r1[s] = rec; break; }
-                if (s == 0) hop1_event<NS, 0>(e, mask, rec, last2);
-                else hop1_event<NS, NS - 1>(e, mask, rec, last2);
-            }
-            t2[s] = INFINITY;
-            while (e.h2[s] < e.h1[s]) {
-                const double2 rec = e.ring[s][e.h2[s] & mask];
-                if (!(rec.x < end)) { t2[s] = rec.x; r2[s] = rec; break; }
-                if (rec_dropped(rec)) c.lost[s]++;   // ns:141-143
-                else c.acked[s]++;                   // ns:144-146
-                e.h2[s]++;
-            }
         }
     }
-    if (ts) ts[3] = clock64();
 
-    // ---- the event that ends the MI: smallest (time, sender, type 'A'<'S', hop) among the
-    // stream heads; all of them are >= end here
-    int best = 0;  // 3*s + {0: hop-1, 1: hop-2, 2: SEND}
-    double tb = t1[0];
+    D.q[i] = q; D.tu[i] = tu;
+    if (flags) D.flags[i] |= flags;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        if (s > 0 && t1[s] < tb) { tb = t1[s]; best = 3 * s; }
-        if (t2[s] < tb) { tb = t2[s]; best = 3 * s + 1; }
-        if (e.nsend[s] < tb) { tb = e.nsend[s]; best = 3 * s + 2; }
-    }
-    e.now = tb;  // ns:131
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        if (best == 3 * s) {
-            Last l2;
-            l2.have = e.h1[s] > e.h2[s];
-            if (l2.have) l2.rec = e.ring[s][(e.h1[s] - 1) & mask];
-            if (s == 0) hop1_event<NS, 0>(e, mask, r1[s], l2);
-            else hop1_event<NS, NS - 1>(e, mask, r1[s], l2);
-        } else if (best == 3 * s + 1) {
-            if (rec_dropped(r2[s])) c.lost[s]++;
-            else c.acked[s]++;
-            e.h2[s]++;
-        } else if (best == 3 * s + 2) {
-            Last l1;
-            l1.have = e.tail[s] > e.h1[s];
-            if (l1.have) l1.rec = e.ring[s][(e.tail[s] - 1) & mask];
-            if (s == 0) send_packet<NS, 0>(e, rng, gap, mask, cap, l1, c);
-            else send_packet<NS, NS - 1>(e, rng, gap, mask, cap, l1, c);
-        }
+        const int64_t k = (int64_t)s * D.n + i;
+        D.next_send[k] = nsend[s];
+        D.tail[k] = tail[s];
+        D.mi_sent[k] = sent[s];
     }
 }
 
-// --------------------------------------------------------------------------------------
-// np.mean over the RTTs acknowledged in this MI (so:119-122, 138-142), numpy-exact.
-// The samples are the non-dropped records of ring[from, to) in order.
-// --------------------------------------------------------------------------------------
-struct RttStream {
-    const double2 *ring;
-    uint32_t mask, pos;
-    __device__ __forceinline__ double next() {
-        double2 r;
-        do { r = ring[pos++ & mask]; } while (rec_dropped(r));
-        return r.y;
-    }
+// ======================================================================================
+// retire_kernel: 16 lanes per env
+// ======================================================================================
+struct Group {
+    uint32_t lane;   // 0..15 inside the env's group
+    uint32_t shift;  // bit position of the group's lane 0 in a wave ballot
 };
 
-// numpy DOUBLE_pairwise_sum for n <= 128 (one leaf of the recursion)
-__device__ __forceinline__ double pw_leaf(RttStream &st, uint32_t n) {
-    if (n < 8) {
-        double res = 0.;
-        for (uint32_t i = 0; i < n; i++) res += st.next();
-        return res;
-    }
-    double r0 = st.next(), r1 = st.next(), r2 = st.next(), r3 = st.next();
-    double r4 = st.next(), r5 = st.next(), r6 = st.next(), r7 = st.next();
-    const uint32_t lim = n - (n % 8);
-    uint32_t i = 8;
-    for (; i < lim; i += 8) {
-        r0 += st.next(); r1 += st.next(); r2 += st.next(); r3 += st.next();
-        r4 += st.next(); r5 += st.next(); r6 += st.next(); r7 += st.next();
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += st.next();
-    return res;
+__device__ __forceinline__ uint32_t gballot(const Group &g, bool p) {
+    return (uint32_t)(__ballot(p) >> g.shift) & 0xFFFFu;
 }
 
-// numpy DOUBLE_pairwise_sum for n <= 8192: the recursion n -> (n2 = n/2 - (n/2)%8, n - n2)
-// unrolled into a left-to-right walk over its leaves with an explicit stack (depth <= 6)
-__device__ __forceinline__ double pw_sum(RttStream &st, uint32_t n) {
-    uint32_t right_n[8];
-    double left_sum[8];
-    uint32_t have_left = 0;
-    int sp = 0;
-    uint32_t cur = n;
-    double val;
-    for (;;) {
-        while (cur > 128) {
-            uint32_t n2 = cur / 2;
-            n2 -= n2 % 8;
-            right_n[sp] = cur - n2;
-            have_left &= ~(1u << sp);
-            sp++;
-            cur = n2;
+__device__ __forceinline__ double gbcast(double v, uint32_t src) { return __shfl(v, (int)src, kGroup); }
+__device__ __forceinline__ uint32_t gbcast(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, kGroup); }
+
+// Cooperative scan of ring[from, tail): first index whose record fails `time + add < end`
+// (add = dl: hop-2 events, add = 0: hop-1 events).  Counts the acked / dropped records of the
+// passing prefix and returns the failing record (stop.x = INFINITY if the scan hit the tail).
+__device__ __forceinline__ uint32_t scan_prefix(const Group &g, const double2 *ring, uint32_t mask, uint32_t from,
+                                                uint32_t tail, double add, double end, uint32_t &acked,
+                                                uint32_t &lost, double2 &stop) {
+    uint32_t i = from;
+    stop.x = INFINITY;
+    stop.y = 1.0;
+    while (i < tail) {
+        const uint32_t k = i + g.lane;
+        const bool valid = k < tail;
+        double2 r;
+        r.x = 0.0; r.y = 1.0;
+        if (valid) r = ring[k & mask];
+        const bool pass = valid && (r.x + add < end);
+        const uint32_t mvalid = gballot(g, valid), mpass = gballot(g, pass);
+        const uint32_t mdrop = gballot(g, valid && rec_dropped(r));
+        const uint32_t mfail = mvalid & ~mpass;
+        if (mfail) {
+            const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
+            const uint32_t pre = (1u << f) - 1u;
+            acked += __popc(pre & ~mdrop);
+            lost += __popc(pre & mdrop);
+            stop.x = gbcast(r.x, f);
+            stop.y = gbcast(r.y, f);
+            return i + f;
         }
-        val = pw_leaf(st, cur);
-        bool descend = false;
-        while (sp > 0) {
-            const int top = sp - 1;
-            if (!(have_left & (1u << top))) {
-                left_sum[top] = val;
-                have_left |= 1u << top;
-                cur = right_n[top];
-                descend = true;
+        acked += __popc(mvalid & ~mdrop);
+        lost += __popc(mvalid & mdrop);
+        i += kGroup;
+    }
+    return tail;
+}
+
+// ---- serial paths (one lane), only entered when the record at a boundary is a dropped one --
+
+// ring[p] is a dropped record with t2 >= end.  Its drop run continues while the previous record
+// (send order) is dropped; members of the run with t2 < end were still popped by the heap, so
+// move each of them in front of p (others keep their order) and count it.
+__device__ __noinline__ uint32_t fix_pop_run(double2 *ring, uint32_t mask, uint32_t p, uint32_t tail, double dl,
+                                             double end, uint32_t &acked, uint32_t &lost) {
+    uint32_t k = p + 1;
+    bool prev_dropped = true;
+    while (k < tail && prev_dropped) {
+        const double2 r = ring[k & mask];
+        prev_dropped = rec_dropped(r);
+        if (r.x + dl < end) {
+            for (uint32_t m = k; m > p; m--) ring[m & mask] = ring[(m - 1) & mask];
+            ring[p & mask] = r;
+            if (rec_dropped(r)) lost++;
+            else acked++;
+            p++;
+        }
+        k++;
+    }
+    return p;
+}
+
+// smallest hop-2 key (t1+dl, lat+dl, dropped) among the records of the drop run starting at p
+// that are already past the forward hop (t1 < end).  Returns its index or 0xFFFFFFFF.
+__device__ __noinline__ uint32_t min_hop2_in_run(const double2 *ring, uint32_t mask, uint32_t p, uint32_t tail,
+                                                 double dl, double end, double2 &best) {
+    uint32_t kb = 0xFFFFFFFFu, k = p;
+    bool prev_dropped = true;
+    double bt = 0.0, by = 0.0;
+    while (k < tail && prev_dropped) {
+        const double2 r = ring[k & mask];
+        prev_dropped = rec_dropped(r);
+        if (r.x < end) {
+            const double t2 = r.x + dl;
+            const double l2 = fabs(r.y) + dl;
+            const double y2 = rec_dropped(r) ? -l2 : l2;
+            if (kb == 0xFFFFFFFFu || key_less(t2, y2, bt, by)) { kb = k; bt = t2; by = y2; best = r; }
+        }
+        k++;
+    }
+    return kb;
+}
+
+// smallest hop-1 key (t1, lat, dropped) among the records of the drop run starting at c that
+// are still on the forward hop (t1 >= end).
+__device__ __noinline__ double min_hop1_in_run(const double2 *ring, uint32_t mask, uint32_t c, uint32_t tail,
+                                               double end) {
+    uint32_t k = c;
+    bool prev_dropped = true, have = false;
+    double bt = INFINITY, by = 1.0;
+    while (k < tail && prev_dropped) {
+        const double2 r = ring[k & mask];
+        prev_dropped = rec_dropped(r);
+        if (!(r.x < end) && (!have || key_less(r.x, r.y, bt, by))) { have = true; bt = r.x; by = r.y; }
+        k++;
+    }
+    return bt;
+}
+
+// move ring[k] in front of ring[p] (p <= k), keeping the order of the records in between
+__device__ __noinline__ void rotate_to_front(double2 *ring, uint32_t mask, uint32_t p, uint32_t k) {
+    const double2 r = ring[k & mask];
+    for (uint32_t m = k; m > p; m--) ring[m & mask] = ring[(m - 1) & mask];
+    ring[p & mask] = r;
+}
+
+// --------------------------------------------------------------------------------------
+// numpy-exact np.mean pieces.  np.add.reduce splits the samples into 8192-element chunks
+// summed left to right; each chunk is DOUBLE_pairwise_sum: split n -> (n/2 rounded down to a
+// multiple of 8, rest) until <= 128, a leaf keeps 8 strided accumulators r[j] += a[8b + j],
+// folds them ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds the < 8 leftover samples one by one.
+// Every leaf but the last of a chunk is a multiple of 8 long, so a walker consumes its sequence
+// in aligned blocks of 8: lane j of an 8-lane subgroup owns r[j].
+// --------------------------------------------------------------------------------------
+struct Walker {
+    uint32_t base;       // stream index of this sequence's first sample
+    uint32_t consumed;   // samples consumed so far
+    uint32_t remaining;  // samples not yet assigned to a chunk
+    uint32_t nblk, blk, rem;  // current leaf: full blocks, blocks done, leftover samples
+    uint32_t right_n[6];
+    double left_sum[6];
+    uint32_t have_left;
+    int sp;
+    double r, tot;
+    bool done;
+};
+
+__device__ __forceinline__ void walker_descend(Walker &w, uint32_t cur) {
+    while (cur > 128) {
+        uint32_t n2 = cur / 2;
+        n2 -= n2 % 8;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (k == w.sp) w.right_n[k] = cur - n2;
+        w.have_left &= ~(1u << w.sp);
+        w.sp++;
+        cur = n2;
+    }
+    w.nblk = cur / 8;
+    w.rem = cur % 8;
+    w.blk = 0;
+}
+
+__device__ __forceinline__ void walker_start_chunk(Walker &w) {
+    const uint32_t m = w.remaining < kNpBufsize ? w.remaining : kNpBufsize;
+    w.remaining -= m;
+    w.sp = 0;
+    w.have_left = 0;
+    walker_descend(w, m);
+}
+
+__device__ __forceinline__ void walker_begin(Walker &w, uint32_t base, uint32_t n) {
+    w.base = base;
+    w.consumed = 0;
+    w.remaining = n;
+    w.tot = 0.0;
+    w.r = 0.0;
+    w.done = (n == 0);
+    w.nblk = w.blk = w.rem = 0;
+    w.sp = 0;
+    w.have_left = 0;
+    if (n) walker_start_chunk(w);
+}
+
+// consume whatever the stage holds for this walker; `produced` = samples staged so far.
+// sl = lane inside the 8-lane subgroup.
+__device__ __forceinline__ void walker_drain(Walker &w, const double *stage, uint32_t produced, uint32_t sl) {
+    while (!w.done) {
+        const uint32_t pos = w.base + w.consumed;
+        const uint32_t avail = produced > pos ? produced - pos : 0u;
+        if (w.blk < w.nblk) {
+            if (avail < 8) return;
+            const double v = stage[(pos + sl) & (kStage - 1)];
+            w.r = (w.blk == 0) ? v : w.r + v;
+            w.blk++;
+            w.consumed += 8;
+            continue;
+        }
+        if (avail < w.rem) return;
+        double val = 0.;
+        if (w.nblk > 0) {
+            double x = w.r;
+            x = x + __shfl_xor(x, 1, 8);
+            x = x + __shfl_xor(x, 2, 8);
+            x = x + __shfl_xor(x, 4, 8);
+            val = x;
+        }
+        for (uint32_t e = 0; e < w.rem; e++) val += stage[(pos + e) & (kStage - 1)];
+        w.consumed += w.rem;
+        // unwind the recursion: the leaf just finished is a left or a right child
+        bool descended = false;
+        while (w.sp > 0) {
+            const int top = w.sp - 1;
+            if (!(w.have_left & (1u << top))) {
+                uint32_t rn = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    if (k == top) { w.left_sum[k] = val; rn = w.right_n[k]; }
+                }
+                w.have_left |= 1u << top;
+                walker_descend(w, rn);
+                descended = true;
                 break;
             }
-            val = left_sum[top] + val;
-            sp--;
+            double ls = 0.;
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                if (k == top) ls = w.left_sum[k];
+            val = ls + val;
+            w.sp--;
         }
-        if (!descend) return val;
+        if (descended) continue;
+        w.tot += val;  // chunk complete
+        if (w.remaining) walker_start_chunk(w);
+        else w.done = true;
     }
 }
 
-// np.add.reduce: per-8192 chunk pairwise sums accumulated left to right
-__device__ __forceinline__ double np_sum(RttStream &st, uint32_t n) {
-    double tot = 0.;
-    for (uint32_t i = 0; i < n; i += kNpBufsize) {
-        const uint32_t m = n - i < kNpBufsize ? n - i : kNpBufsize;
-        tot += pw_sum(st, m);
+// Means over the RTTs (= forward latency + dl) of the acknowledged records of ring[from, to):
+// the whole list (so:119-122) and, when asked, mean(second half) - mean(first half)
+// (so:138-142).  n = number of acknowledged records in the range (> 0).
+__device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, uint32_t mask, uint32_t from,
+                                          uint32_t to, uint32_t n, double dl, bool need_halves, double *stage,
+                                          double &mean_all, double &lat_inc) {
+    const uint32_t sub = g.lane >> 3, sl = g.lane & 7u;
+    const uint32_t half = n / 2;
+    Walker w;
+    bool second = false;
+    if (sub == 0) walker_begin(w, 0, n);
+    else walker_begin(w, 0, (need_halves && half >= 1) ? half : 0);
+    double first_mean = 0.0;
+    uint32_t produced = 0;
+    for (uint32_t i = from; i < to; i += kGroup) {
+        const uint32_t k = i + g.lane;
+        const bool valid = k < to;
+        double2 r;
+        r.x = 0.0; r.y = -1.0;
+        if (valid) r = ring[k & mask];
+        const bool ack = valid && !rec_dropped(r);
+        const uint32_t mack = gballot(g, ack);
+        if (ack) stage[(produced + __popc(mack & ((1u << g.lane) - 1u))) & (kStage - 1)] = r.y + dl;
+        produced += __popc(mack);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        walker_drain(w, stage, produced, sl);
+        if (sub == 1 && w.done && !second && need_halves && half >= 1) {
+            first_mean = w.tot / (double)half;
+            second = true;
+            walker_begin(w, half, n - half);
+            walker_drain(w, stage, produced, sl);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    return tot;
+    // sub 0 now holds the full sum, sub 1 the second-half sum
+    const double tot = gbcast(w.tot, 0);
+    const double tot2 = gbcast(w.tot, 8);
+    const double fm = gbcast(first_mean, 8);
+    mean_all = tot / (double)n;
+    lat_inc = (need_halves && half >= 1) ? tot2 / (double)(n - half) - fm : 0.0;
 }
 
-// the 12 metrics of one MI (so:110-191).  min_lat: connection minimum, 0.0 = no entry yet.
-__device__ __forceinline__ void mi_metrics(uint32_t sent, uint32_t acked, uint32_t lost, double dur,
-                                           const double2 *ring, uint32_t mask, uint32_t from, double &min_lat,
-                                           bool update_min, bool need_halves, double (&m)[PCC_N_METRICS]) {
+// the 12 metrics of one MI (so:110-191) from its counts and RTT means
+__device__ __forceinline__ void mi_metrics(uint32_t sent, uint32_t acked, uint32_t lost, double dur, double lat,
+                                           double inc, double &min_lat, double (&m)[PCC_N_METRICS]) {
     const int64_t bs = (int64_t)sent * kBytesPerPacket, ba = (int64_t)acked * kBytesPerPacket,
                   bl = (int64_t)lost * kBytesPerPacket;
     m[PCC_M_RECV_DUR] = dur;
     m[PCC_M_SEND_DUR] = dur;
     m[PCC_M_SEND_RATE] = dur > 0.0 ? 8.0 * (double)bs / dur : 0.0;
     m[PCC_M_RECV_RATE] = dur > 0.0 ? 8.0 * (double)(ba - kBytesPerPacket) / dur : 0.0;
-    double lat = 0.0, inc = 0.0;
-    if (acked > 0) {
-        RttStream st{ring, mask, from};
-        lat = np_sum(st, acked) / (double)acked;
-        const uint32_t half = acked / 2;
-        if (need_halves && half >= 1) {
-            RttStream sh{ring, mask, from};
-            const double first = np_sum(sh, half) / (double)half;
-            const double second = np_sum(sh, acked - half) / (double)(acked - half);
-            inc = second - first;
-        }
-    }
     m[PCC_M_AVG_LATENCY] = lat;
     m[PCC_M_LOSS_RATIO] = (bl + ba > 0) ? (double)bl / (double)(bl + ba) : 0.0;
     m[PCC_M_LATENCY_INCREASE] = inc;
     m[PCC_M_ACK_LATENCY_INFLATION] = dur > 0.0 ? inc / dur : 0.0;
     m[PCC_M_SENT_LATENCY_INFLATION] = dur > 0.0 ? inc / dur : 0.0;
-    double cm;
+    double cm;  // so:158-176; min_lat == 0.0 <=> no entry for this sender yet
     if (min_lat > 0.0) {
         if (lat == 0.0) cm = min_lat;
-        else if (lat < min_lat) { cm = lat; if (update_min) min_lat = lat; }
+        else if (lat < min_lat) { cm = lat; min_lat = lat; }
         else cm = min_lat;
     } else {
-        if (lat > 0.0) { cm = lat; if (update_min) min_lat = lat; }
+        if (lat > 0.0) { cm = lat; min_lat = lat; }
         else cm = 0.0;
     }
     m[PCC_M_CONN_MIN_LATENCY] = cm;
@@ -484,68 +568,251 @@ __device__ __forceinline__ double select_metric(const double (&m)[PCC_N_METRICS]
     return v;
 }
 
-// --------------------------------------------------------------------------------------
-// state load/store
-// --------------------------------------------------------------------------------------
 template <int NS>
-__device__ __forceinline__ void load_env(const Dev &D, int64_t i, Env<NS> &e) {
-    e.dl = D.dl[i]; e.lr = D.lr[i]; e.maxq = D.maxq[i]; e.ebw = D.ebw[i];
-    e.q = D.q[i]; e.tu = D.tu[i]; e.now = D.now[i];
-    e.flags = D.flags[i];
+__global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, uint32_t warm_mi, int last_warm,
+                                                              float *obs_out, float *reward_out, uint8_t *done_out,
+                                                              double *steps_out) {
+    __shared__ double s_stage[kRetireBlock / kGroup][kStage];
+    const uint32_t tid = threadIdx.x;
+    Group g;
+    g.lane = tid & (kGroup - 1);
+    g.shift = (tid & (kWave - 1)) & ~(uint32_t)(kGroup - 1);
+    const int64_t i = (int64_t)blockIdx.x * (kRetireBlock / kGroup) + (tid / kGroup);
+    if (i >= D.n) return;
+    if (warm && !D.resetting[i]) return;
+    double *stage = s_stage[tid / kGroup];
+    const bool lead = g.lane == 0;
+    const uint32_t mask = D.cap_mask;
+
+    const double dl = D.dl[i];
+    const double start = D.now[i];
+    const double run_dur = D.run_dur[i];
+    const double end = start + run_dur;  // ns:124
+    const uint32_t steps = D.steps[i];
+    double now = start;
+
+    double nsend[NS];
+    uint32_t h2[NS], c1[NS], tail[NS], sent[NS], acked[NS], lost[NS], from[NS];
+    double2 *ring[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
-        e.rate[s] = D.rate[k]; e.nsend[s] = D.next_send[k];
-        e.h2[s] = D.h2[k]; e.h1[s] = D.h1[k]; e.tail[s] = D.tail[k];
-        e.ring[s] = D.ring + ((int64_t)i * NS + s) * D.cap;
+        nsend[s] = D.next_send[k];
+        h2[s] = D.h2[k]; c1[s] = D.c1[k]; tail[s] = D.tail[k];
+        sent[s] = D.mi_sent[k];
+        acked[s] = lost[s] = 0;
+        from[s] = h2[s];
+        ring[s] = D.ring + ((int64_t)i * NS + s) * D.cap;
     }
-}
+    uint32_t flags = 0;
 
-template <int NS>
-__device__ __forceinline__ void store_env(const Dev &D, int64_t i, const Env<NS> &e) {
-    D.q[i] = e.q; D.tu[i] = e.tu; D.now[i] = e.now;
-    D.flags[i] = e.flags;
+    if (start < end) {  // ns:128: otherwise the loop body never runs
+        double t_h1[NS], t_h2[NS];
+        uint32_t k_h2[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            // ---- hop-2 events before `end` (ns:140-146): a prefix of the ring
+            double2 stop;
+            uint32_t p = scan_prefix(g, ring[s], mask, h2[s], tail[s], dl, end, acked[s], lost[s], stop);
+            if (p < tail[s] && rec_dropped(stop)) {  // the boundary cuts a drop run: rare serial path
+                uint32_t a = acked[s], l = lost[s];
+                if (lead) p = fix_pop_run(ring[s], mask, p, tail[s], dl, end, a, l);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                p = gbcast(p, 0); acked[s] = gbcast(a, 0); lost[s] = gbcast(l, 0);
+                stop.x = INFINITY; stop.y = -1.0;
+                if (p < tail[s]) stop = ring[s][p & mask];
+            }
+            h2[s] = p;
+            // ---- hop-2 candidate for the MI-ending event: the first unretired record, if it is
+            // already past the forward hop (otherwise a hop-1 event precedes it)
+            t_h2[s] = INFINITY;
+            k_h2[s] = p;
+            if (p < tail[s]) {
+                if (!rec_dropped(stop)) {
+                    if (stop.x < end) t_h2[s] = stop.x + dl;
+                } else {
+                    uint32_t kb = 0xFFFFFFFFu;
+                    double2 best;
+                    best.x = 0.0; best.y = 1.0;
+                    if (lead) kb = min_hop2_in_run(ring[s], mask, p, tail[s], dl, end, best);
+                    kb = gbcast(kb, 0);
+                    if (kb != 0xFFFFFFFFu) { t_h2[s] = gbcast(best.x, 0) + dl; k_h2[s] = kb; }
+                }
+            }
+            // ---- hop-1 events before `end` (ns:147-154) only move the cursor: the record is reused
+            if (c1[s] < h2[s]) c1[s] = h2[s];
+            uint32_t na = 0, nl = 0;
+            const uint32_t c = scan_prefix(g, ring[s], mask, c1[s], tail[s], 0.0, end, na, nl, stop);
+            c1[s] = c;
+            t_h1[s] = stop.x;  // INFINITY if none
+            if (c < tail[s] && rec_dropped(stop)) {
+                double tb = stop.x;
+                if (lead) tb = min_hop1_in_run(ring[s], mask, c, tail[s], end);
+                t_h1[s] = gbcast(tb, 0);
+            }
+        }
+        // ---- the event that ends the MI: smallest (time, sender, 'A' < 'S', hop) among the stream
+        // heads, all >= end here; the reference still processes it (ns:128-131)
+        int best = 0;
+        double tb = t_h1[0];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (s > 0 && t_h1[s] < tb) { tb = t_h1[s]; best = 3 * s; }
+            if (t_h2[s] < tb) { tb = t_h2[s]; best = 3 * s + 1; }
+            if (nsend[s] < tb) { tb = nsend[s]; best = 3 * s + 2; }
+        }
+        now = tb;  // ns:131
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (best == 3 * s + 1) {  // hop-2: acknowledge / lose one more packet
+                double2 r = ring[s][k_h2[s] & mask];
+                if (k_h2[s] != h2[s]) {
+                    if (lead) rotate_to_front(ring[s], mask, h2[s], k_h2[s]);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+                if (rec_dropped(r)) lost[s]++;
+                else acked[s]++;
+                h2[s]++;
+                if (c1[s] < h2[s]) c1[s] = h2[s];
+            } else if (best == 3 * s + 2) {  // SEND: one more packet leaves (ns:155-178)
+                const double t = nsend[s];
+                double q = D.q[i], tu = D.tu[i];
+                double u;
+                if (D.rng_mode == PCC_RNG_TRACE) {
+                    uint64_t pos = tail[0];
+                    if (NS > 1) pos += tail[NS - 1];
+                    if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
+                    else u = D.trace[i * D.trace_stride + pos];
+                } else {
+                    u = philox_packet_uniform(D, D.gid_base + (uint32_t)i, D.episode[i] - 1,
+                                              warm ? warm_mi : steps + 2, s, sent[s]);
+                }
+                const double rate = D.rate[(int64_t)s * D.n + i];
+                sent[s]++;
+                nsend[s] = t + 1.0 / rate;
+                const double2 rec = link_send(t, u, dl, D.lr[i], D.maxq[i], D.ebw[i], q, tu);
+                if (tail[s] - h2[s] >= D.cap) {
+                    flags |= PCC_FLAG_RING_OVERFLOW;
+                } else {
+                    if (lead) ring[s][tail[s] & mask] = rec;
+                    tail[s]++;
+                }
+                if (lead) { D.q[i] = q; D.tu[i] = tu; }
+            }
+        }
+    }
+
+    // ---- state
+    unsigned long long sent_total = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) sent_total += sent[s];
+    if (lead) {
+        D.now[i] = now;
+        if (flags) D.flags[i] |= flags;
+        D.total_sent[i] += sent_total;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int64_t k = (int64_t)s * D.n + i;
+            D.next_send[k] = nsend[s];
+            D.h2[k] = h2[s]; D.c1[k] = c1[s]; D.tail[k] = tail[s];
+        }
+    }
+    if (warm) {  // reset(): the two warm-up MIs are not recorded (ns:478-479)
+        if (lead && last_warm) D.resetting[i] = 0;
+        return;
+    }
+
+    // ---- metrics, history, observation, reward: ns:416-438 with so:44-73
+    bool need_halves = steps_out != nullptr;
+    for (int f = 0; f < D.F; f++) {
+        const int id = D.fid[f];
+        need_halves |= (id == PCC_M_LATENCY_INCREASE || id == PCC_M_ACK_LATENCY_INFLATION ||
+                        id == PCC_M_SENT_LATENCY_INFLATION);
+    }
+    const double dur = now - start;  // ns:311-314
+    double new_run_dur = run_dur;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
-        D.rate[k] = e.rate[s]; D.next_send[k] = e.nsend[s];
-        D.h2[k] = e.h2[s]; D.h1[k] = e.h1[s]; D.tail[k] = e.tail[s];
+        double lat = 0.0, inc = 0.0;
+        if (acked[s] > 0)
+            rtt_means(g, ring[s], mask, from[s], h2[s], acked[s], dl, need_halves, stage, lat, inc);
+        double min_lat = D.min_lat[k];
+        double m[PCC_N_METRICS];
+        mi_metrics(sent[s], acked[s], lost[s], dur, lat, inc, min_lat, m);
+        const double reward =  // ns:194,205
+            (10.0 * m[PCC_M_RECV_RATE] / (double)(8 * kBytesPerPacket) - 1e3 * m[PCC_M_AVG_LATENCY] -
+             2e3 * m[PCC_M_LOSS_RATIO]) * kRewardScale;
+        if (s == 0 && m[PCC_M_AVG_LATENCY] > 0.0) new_run_dur = 0.5 * m[PCC_M_AVG_LATENCY];  // ns:437-438
+
+        // history roll (so:64-66) + observation (ns:400-404, so:68-73), 16 lanes wide
+        float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
+        float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
+        const int keep = D.HF - D.F;
+        for (int base = 0; base < D.HF; base += kGroup) {
+            const int x = base + (int)g.lane;
+            float v = 0.f;
+            if (x < keep) v = hist[x + D.F];
+            else if (x < D.HF) {
+                const int id = D.fid[x - keep];
+                v = (float)(select_metric(m, id) / c_metric_scale[id]);
+            }
+            if (x < D.HF) {
+                hist[x] = v;
+                if (obs) obs[x] = v;
+            }
+        }
+        if (lead) {
+            D.min_lat[k] = min_lat;
+            if (reward_out) reward_out[i * NS + s] = (float)reward;
+            const double ret = D.ep_return[k] + reward;
+            D.ep_return[k] = ret;
+            if (steps + 1 >= D.max_steps) D.last_return[k] = ret;
+        }
+        if (steps_out && g.lane < PCC_N_METRICS)
+            steps_out[(i * NS + s) * PCC_STEP_COLS + PCC_COL_METRIC0 + g.lane] = select_metric(m, (int)g.lane);
+        if (steps_out && lead) {
+            double *row = steps_out + (i * NS + s) * PCC_STEP_COLS;
+            row[PCC_COL_SENT] = (double)sent[s];
+            row[PCC_COL_ACKED] = (double)acked[s];
+            row[PCC_COL_LOST] = (double)lost[s];
+            row[PCC_COL_RATE] = D.rate[k];
+            row[PCC_COL_CUR_TIME] = now;
+            row[PCC_COL_REWARD] = reward;
+        }
+    }
+    if (lead) {
+        if (steps_out)
+            for (int s = 0; s < NS; s++) steps_out[(i * NS + s) * PCC_STEP_COLS + PCC_COL_RUN_DUR] = new_run_dur;
+        D.run_dur[i] = new_run_dur;
+        D.steps[i] = steps + 1;
+        const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
+        D.done[i] = done;
+        if (done_out) done_out[i] = done;
     }
 }
 
+// ======================================================================================
+// reset_init_kernel: ns:454-477 -- parameters, fresh link/sender/history state.  The two warm-up
+// MIs (ns:478-479) are run by send_kernel / retire_kernel in warm mode on the marked envs.
+// ======================================================================================
 template <int NS>
-__device__ __forceinline__ void init_rng(const Dev &D, int64_t i, uint32_t episode, uint32_t mi, Rng<NS> &r) {
-    r.mode = D.rng_mode;
-    r.trace = D.trace ? D.trace + i * D.trace_stride : nullptr;
-    r.trace_n = D.trace_stride;
-    r.k0 = D.key0; r.k1 = D.key1;
-    r.gid = D.gid_base + (uint32_t)i;
-    r.episode = episode;
-    r.mi = mi;
-#pragma unroll
-    for (int s = 0; s < NS; s++) r.j[s] = 0;
-}
-
-// --------------------------------------------------------------------------------------
-// reset kernel: ns:454-484
-// --------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(kWave) void reset_kernel(Dev D, const uint8_t *mask, int use_done, float *obs_out) {
+__global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t *mask, int use_done, float *obs_out) {
     const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
     if (i >= D.n) return;
-    if (mask && !mask[i]) return;
-    if (use_done && !D.done[i]) return;
+    const bool sel = (!mask || mask[i]) && (!use_done || D.done[i]);
+    D.resetting[i] = sel ? 1 : 0;
+    if (!sel) return;
 
     const uint32_t episode = D.episode[i];
     D.episode[i] = episode + 1;
 
-    // ---- parameters: ns:455-466
     double bw, lat, queue, loss, rate0[NS];
     if (D.p_bw) {
         bw = D.p_bw[i]; lat = D.p_dl[i]; queue = D.p_queue[i]; loss = D.p_loss[i];
 #pragma unroll
         for (int s = 0; s < NS; s++) rate0[s] = D.p_rate0[(int64_t)s * D.n + i];
-    } else {
+    } else {  // ns:455-466
         uint32_t w0[4], w1[4];
         const uint32_t gid = D.gid_base + (uint32_t)i;
         philox4x32_10(0u, kParamTag, episode, gid, D.key0, D.key1, w0);
@@ -557,46 +824,23 @@ __global__ __launch_bounds__(kWave) void reset_kernel(Dev D, const uint8_t *mask
 #pragma unroll
         for (int s = 0; s < NS; s++) rate0[s] = (D.lo[4] + (D.hi[4] - D.lo[4]) * u32_to_unit(w1[s])) * bw;
     }
-
-    Env<NS> e;
-    e.dl = lat; e.lr = loss; e.maxq = queue / bw; e.ebw = 1.0 / bw;  // ns:58-64,77
-    e.q = 0.0; e.tu = 0.0; e.now = 0.0;
-    e.flags = D.flags[i];
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        e.rate[s] = rate0[s];
-        e.nsend[s] = 1.0 / rate0[s];  // ns:111
-        e.h2[s] = e.h1[s] = e.tail[s] = 0;
-        e.ring[s] = D.ring + ((int64_t)i * NS + s) * D.cap;
-    }
-    const double run_dur = 3 * lat;  // ns:467
-
-    // ---- two unrecorded warm-up MIs: ns:478-479
-    Rng<NS> rng;
-    init_rng<NS>(D, i, episode, 0, rng);
-    unsigned long long sent_total = 0;
-    for (int w = 0; w < 2; w++) {
-        rng.mi = (uint32_t)w;
-        MiCounts<NS> c;
-        run_mi<NS>(e, rng, run_dur, D.cap_mask, D.cap, c);
-#pragma unroll
-        for (int s = 0; s < NS; s++) sent_total += c.sent[s];
-    }
-
-    D.bw[i] = bw; D.dl[i] = e.dl; D.lr[i] = e.lr; D.maxq[i] = e.maxq; D.ebw[i] = e.ebw;
-    D.run_dur[i] = run_dur;
+    D.bw[i] = bw; D.dl[i] = lat; D.lr[i] = loss;
+    D.maxq[i] = queue / bw;   // ns:64
+    D.ebw[i] = 1.0 / bw;      // ns:77
+    D.q[i] = 0.0; D.tu[i] = 0.0; D.now[i] = 0.0;
+    D.run_dur[i] = 3 * lat;   // ns:467
     D.steps[i] = 0;
     D.done[i] = 0;
-    D.total_sent[i] += sent_total;
-    store_env<NS>(D, i, e);
-
-    // ---- fresh sender: empty history (so:57-62) and no connection minimum (so:158)
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
+        D.rate[k] = rate0[s];
         D.rate0[k] = rate0[s];
-        D.min_lat[k] = 0.0;
+        D.next_send[k] = 1.0 / rate0[s];  // ns:111
+        D.h2[k] = 0; D.c1[k] = 0; D.tail[k] = 0; D.mi_sent[k] = 0;
+        D.min_lat[k] = 0.0;   // fresh sender id => no connection minimum yet (ns:229-233, so:158)
         D.ep_return[k] = 0.0;
+        // all-empty history (so:57-62): every metric of an empty MI is 0 except the two ratios
         float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
         float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
         for (int h = 0; h < D.H; h++)
@@ -607,116 +851,6 @@ __global__ __launch_bounds__(kWave) void reset_kernel(Dev D, const uint8_t *mask
                 hist[h * D.F + f] = x;
                 if (obs) obs[h * D.F + f] = x;
             }
-    }
-}
-
-// --------------------------------------------------------------------------------------
-// step kernel: ns:406-444
-// --------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(kWave) void step_kernel(Dev D, const void *actions, int actions_f64, float *obs_out,
-                                                     float *reward_out, uint8_t *done_out, double *steps_out) {
-    const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
-    if (i >= D.n) return;
-
-    Env<NS> e;
-    load_env<NS>(D, i, e);
-    const uint32_t steps = D.steps[i];
-    const double run_dur = D.run_dur[i];
-
-    // ---- apply_rate_delta + set_rate: ns:235-241, 275-281
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        const int64_t a = i * NS + s;
-        double delta = actions_f64 ? ((const double *)actions)[a] : (double)((const float *)actions)[a];
-        delta *= D.delta_scale;
-        double r = delta >= 0.0 ? e.rate[s] * (1.0 + delta) : e.rate[s] / (1.0 - delta);
-        if (r > kMaxRate) r = kMaxRate;
-        if (r < kMinRate) r = kMinRate;
-        e.rate[s] = r;
-    }
-
-    // ---- one monitor interval
-    Rng<NS> rng;
-    init_rng<NS>(D, i, D.episode[i] - 1, steps + 2, rng);
-    MiCounts<NS> c;
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    run_mi<NS>(e, rng, run_dur, D.cap_mask, D.cap, c, D.prof ? ts : nullptr);
-    if (D.prof) ts[4] = clock64();
-    const double dur = e.now - c.start;  // ns:311-314
-
-    // ---- metrics, history, reward
-    bool need_halves = steps_out != nullptr;
-    for (int f = 0; f < D.F; f++) {
-        const int id = D.fid[f];
-        need_halves |= (id == PCC_M_LATENCY_INCREASE || id == PCC_M_ACK_LATENCY_INFLATION ||
-                        id == PCC_M_SENT_LATENCY_INFLATION);
-    }
-    double new_run_dur = run_dur;
-    unsigned long long sent_total = 0;
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + i;
-        double min_lat = D.min_lat[k];
-        double m[PCC_N_METRICS];
-        mi_metrics(c.sent[s], c.acked[s], c.lost[s], dur, e.ring[s], D.cap_mask, c.from[s], min_lat, true,
-                   need_halves, m);
-        D.min_lat[k] = min_lat;
-        sent_total += c.sent[s];
-        // ns:194,205
-        const double reward =
-            (10.0 * m[PCC_M_RECV_RATE] / (double)(8 * kBytesPerPacket) - 1e3 * m[PCC_M_AVG_LATENCY] -
-             2e3 * m[PCC_M_LOSS_RATIO]) * kRewardScale;
-        if (s == 0 && m[PCC_M_AVG_LATENCY] > 0.0) new_run_dur = 0.5 * m[PCC_M_AVG_LATENCY];  // ns:437-438
-
-        // history roll (so:64-66) + observation (ns:400-404, so:68-73)
-        float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
-        float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
-        const int keep = D.HF - D.F;
-        for (int x = 0; x < keep; x++) {
-            const float v = hist[x + D.F];
-            hist[x] = v;
-            if (obs) obs[x] = v;
-        }
-        for (int f = 0; f < D.F; f++) {
-            const int id = D.fid[f];
-            const float v = (float)(select_metric(m, id) / c_metric_scale[id]);
-            hist[keep + f] = v;
-            if (obs) obs[keep + f] = v;
-        }
-        if (reward_out) reward_out[i * NS + s] = (float)reward;
-        const double ret = D.ep_return[k] + reward;
-        D.ep_return[k] = ret;
-        if (steps + 1 >= D.max_steps) D.last_return[k] = ret;
-        if (steps_out) {
-            double *row = steps_out + (i * NS + s) * PCC_STEP_COLS;
-            row[PCC_COL_SENT] = (double)c.sent[s];
-            row[PCC_COL_ACKED] = (double)c.acked[s];
-            row[PCC_COL_LOST] = (double)c.lost[s];
-            row[PCC_COL_RATE] = e.rate[s];
-            row[PCC_COL_CUR_TIME] = e.now;
-            row[PCC_COL_RUN_DUR] = 0.0;  // patched below once sender 0 is known
-            row[PCC_COL_REWARD] = reward;
-#pragma unroll
-            for (int k2 = 0; k2 < PCC_N_METRICS; k2++) row[PCC_COL_METRIC0 + k2] = m[k2];
-        }
-    }
-    if (steps_out)
-        for (int s = 0; s < NS; s++) steps_out[(i * NS + s) * PCC_STEP_COLS + PCC_COL_RUN_DUR] = new_run_dur;
-
-    store_env<NS>(D, i, e);
-    D.run_dur[i] = new_run_dur;
-    D.steps[i] = steps + 1;
-    D.total_sent[i] += sent_total;
-    const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
-    D.done[i] = done;
-    if (done_out) done_out[i] = done;
-    if (D.prof) {
-        ts[5] = clock64();
-        ts[6] = c.sent[0];
-        ts[7] = c.acked[0] + c.lost[0];
-#pragma unroll
-        for (int k = 0; k < 8; k++) D.prof[i * 8 + k] = ts[k];
     }
 }
 
@@ -770,11 +904,12 @@ size_t carve_state(Dev &d, char *base) {
     d.maxq = c.take<double>(n); d.ebw = c.take<double>(n); d.q = c.take<double>(n);
     d.tu = c.take<double>(n); d.now = c.take<double>(n); d.run_dur = c.take<double>(n);
     d.steps = c.take<uint32_t>(n); d.episode = c.take<uint32_t>(n); d.flags = c.take<uint32_t>(n);
-    d.done = c.take<uint8_t>(n);
+    d.done = c.take<uint8_t>(n); d.resetting = c.take<uint8_t>(n);
     d.total_sent = c.take<unsigned long long>(n);
     d.rate = c.take<double>(sn); d.rate0 = c.take<double>(sn); d.next_send = c.take<double>(sn);
     d.min_lat = c.take<double>(sn); d.ep_return = c.take<double>(sn); d.last_return = c.take<double>(sn);
-    d.h2 = c.take<uint32_t>(sn); d.h1 = c.take<uint32_t>(sn); d.tail = c.take<uint32_t>(sn);
+    d.h2 = c.take<uint32_t>(sn); d.c1 = c.take<uint32_t>(sn); d.tail = c.take<uint32_t>(sn);
+    d.mi_sent = c.take<uint32_t>(sn);
     d.hist = c.take<float>(sn * d.HF);
     return (c.off + 255) & ~(size_t)255;
 }
@@ -782,6 +917,39 @@ size_t carve_state(Dev &d, char *base) {
 int check_hip(hipError_t err, const char *what) {
     if (err == hipSuccess) return PCC_OK;
     return fail(PCC_EHIP, "%s: %s", what, hipGetErrorString(err));
+}
+
+dim3 lane_grid(const Dev &d) { return dim3((unsigned)((d.n + kWave - 1) / kWave)); }
+dim3 group_grid(const Dev &d) {
+    const int64_t per_block = kRetireBlock / kGroup;
+    return dim3((unsigned)((d.n + per_block - 1) / per_block));
+}
+
+// one monitor interval for all envs (warm = 0) or for the envs being reset (warm = 1)
+int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, const void *actions, int actions_f64,
+              float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
+    const Dev &d = sim->d;
+    if (d.ns == 1) {
+        hipLaunchKernelGGL(send_kernel<1>, lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        hipLaunchKernelGGL(retire_kernel<1>, group_grid(d), dim3(kRetireBlock), 0, st, d, warm, warm_mi, last_warm,
+                           obs_out, reward_out, done_out, steps_out);
+    } else {
+        hipLaunchKernelGGL(send_kernel<2>, lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        hipLaunchKernelGGL(retire_kernel<2>, group_grid(d), dim3(kRetireBlock), 0, st, d, warm, warm_mi, last_warm,
+                           obs_out, reward_out, done_out, steps_out);
+    }
+    return check_hip(hipGetLastError(), "monitor-interval kernel launch");
+}
+
+// reset(): parameters + state, then the two unrecorded warm-up MIs (ns:469-484)
+int launch_reset(pcc_sim_t *sim, const uint8_t *mask, int use_done, float *obs_out, hipStream_t st) {
+    const Dev &d = sim->d;
+    if (d.ns == 1) hipLaunchKernelGGL(reset_init_kernel<1>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, obs_out);
+    else hipLaunchKernelGGL(reset_init_kernel<2>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, obs_out);
+    int rc = check_hip(hipGetLastError(), "reset kernel launch");
+    for (uint32_t w = 0; w < 2 && rc == PCC_OK; w++)
+        rc = launch_mi(sim, 1, w, w == 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, st);
+    return rc;
 }
 
 }  // namespace
@@ -810,7 +978,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     for (int f = 0; f < n_features; f++)
         if (feature_ids[f] < 0 || feature_ids[f] >= PCC_N_METRICS)
             return fail(PCC_EINVAL, "feature id %d out of range", feature_ids[f]);
-    if (ring_capacity == 0) ring_capacity = 32768;
+    if (ring_capacity == 0) ring_capacity = 65536;
     if (ring_capacity < 16 || (ring_capacity & (ring_capacity - 1)))
         return fail(PCC_EINVAL, "ring_capacity must be a power of two >= 16");
 
@@ -844,8 +1012,9 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     sim->state_bytes = carve_state(d, nullptr);
     sim->ring_bytes = (size_t)n_envs * n_senders * ring_capacity * sizeof(double2);
     if (hipMalloc(&sim->state_blob, sim->state_bytes) != hipSuccess) {
+        const size_t want = sim->state_bytes;
         delete sim;
-        return fail(PCC_ENOMEM, "hipMalloc(%zu) for env state failed", sim->state_bytes);
+        return fail(PCC_ENOMEM, "hipMalloc(%zu) for env state failed", want);
     }
     if (hipMalloc(&sim->ring_blob, sim->ring_bytes) != hipSuccess) {
         (void)hipFree(sim->state_blob);
@@ -912,12 +1081,6 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed) {
     return PCC_OK;
 }
 
-int pcc_set_profile_buffer(pcc_sim_t *sim, uint64_t *buf) {
-    if (!sim) return fail(PCC_EINVAL, "sim is NULL");
-    sim->d.prof = reinterpret_cast<unsigned long long *>(buf);
-    return PCC_OK;
-}
-
 int pcc_set_delta_scale(pcc_sim_t *sim, double delta_scale) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     sim->d.delta_scale = delta_scale;
@@ -928,14 +1091,6 @@ int pcc_set_max_steps(pcc_sim_t *sim, int max_steps) {
     if (!sim || max_steps < 1) return fail(PCC_EINVAL, "max_steps must be >= 1");
     sim->d.max_steps = (uint32_t)max_steps;
     return PCC_OK;
-}
-
-static int launch_reset(pcc_sim_t *sim, const uint8_t *mask, int use_done, float *obs_out, hipStream_t st) {
-    const Dev &d = sim->d;
-    const dim3 grid((unsigned)((d.n + kWave - 1) / kWave)), block(kWave);
-    if (d.ns == 1) hipLaunchKernelGGL(reset_kernel<1>, grid, block, 0, st, d, mask, use_done, obs_out);
-    else hipLaunchKernelGGL(reset_kernel<2>, grid, block, 0, st, d, mask, use_done, obs_out);
-    return check_hip(hipGetLastError(), "reset kernel launch");
 }
 
 int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream) {
@@ -960,17 +1115,12 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
     DeviceGuard guard(sim->device);
     const Dev &d = sim->d;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((d.n + kWave - 1) / kWave)), block(kWave);
-    if (d.ns == 1)
-        hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, st, d, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
-    else
-        hipLaunchKernelGGL(step_kernel<2>, grid, block, 0, st, d, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
-    int rc = check_hip(hipGetLastError(), "step kernel launch");
+    int rc = launch_mi(sim, 0, 0, 0, actions, actions_f64, obs_out, reward_out, done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
     sim->host_steps++;
     if (auto_reset) {
         // when every env is in lockstep the host knows which step finishes the episode and
-        // skips the (otherwise no-op) masked reset launch
+        // skips the (otherwise no-op) masked reset launches
         const bool may_be_done = !sim->lockstep || sim->host_steps >= d.max_steps;
         if (may_be_done) {
             rc = launch_reset(sim, nullptr, 1, obs_out, st);
@@ -1006,7 +1156,7 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {
         case PCC_F_NEXT_SEND: src = d.next_send; bytes = sn * 8; break;
         case PCC_F_MIN_LAT: src = d.min_lat; bytes = sn * 8; break;
         case PCC_F_RING_HEAD: src = d.h2; bytes = sn * 4; break;
-        case PCC_F_RING_MID: src = d.h1; bytes = sn * 4; break;
+        case PCC_F_RING_MID: src = d.c1; bytes = sn * 4; break;
         case PCC_F_RING_TAIL: src = d.tail; bytes = sn * 4; break;
         case PCC_F_EP_RETURN: src = d.ep_return; bytes = sn * 8; break;
         case PCC_F_LAST_RETURN: src = d.last_return; bytes = sn * 8; break;

@@ -29,7 +29,7 @@ FIELDS = {
 # every symbol include/pcc_sim.h declares
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
            "pcc_set_rng", "pcc_set_seed", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step",
-           "pcc_get_state", "pcc_metric_info", "pcc_set_profile_buffer", "pcc_device_bytes"]
+           "pcc_get_state", "pcc_metric_info", "pcc_device_bytes"]
 
 
 class PccError(RuntimeError):
@@ -70,8 +70,6 @@ def lib():
     L.pcc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
     L.pcc_get_state.argtypes = [vp, i32, vp, vp]
     L.pcc_metric_info.argtypes = [i32, ctypes.POINTER(dbl), ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
-    L.pcc_set_profile_buffer.argtypes = [vp, vp]
-    L.pcc_set_profile_buffer.restype = i32
     L.pcc_device_bytes.restype = i64
     L.pcc_device_bytes.argtypes = [vp]
     for fn in ("pcc_create", "pcc_set_link_params", "pcc_set_param_ranges", "pcc_set_rng", "pcc_set_seed",
