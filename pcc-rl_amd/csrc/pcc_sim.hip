@@ -143,27 +143,21 @@ __device__ __forceinline__ double philox_packet_uniform(const Dev &D, uint32_t g
 }
 
 // Link.packet_enters_link + latency sampling for one SEND at time t: ns:66-84, 170-175.
-// Returns the record (t + lat0, +-lat0).
+// Returns the record (t + lat0, +-lat0).  Branch-free: the three outcomes (random loss: queue
+// untouched, ns:73-74; tail drop: queue drained but not grown, ns:75-81; accepted: ns:82) are
+// selects over values computed in the reference's operation order.
 __device__ __forceinline__ double2 link_send(double t, double u, double dl, double lr, double maxq, double ebw,
                                              double &q, double &tu) {
     const double qcur = max0(q - (t - tu));  // ns:66-67
     const double lat0 = dl + qcur;           // ns:170: latency before this packet queues
-    bool dropped;
-    if (u < lr) {                            // ns:73-74: random loss leaves the queue untouched
-        dropped = true;
-    } else {
-        q = qcur;                            // ns:75-76
-        tu = t;
-        if (ebw + q > maxq) {                // ns:79-81 tail drop
-            dropped = true;
-        } else {
-            q += ebw;                        // ns:82
-            dropped = false;
-        }
-    }
+    const bool rnd = u < lr;                 // ns:73
+    const bool full = ebw + qcur > maxq;     // ns:79 (with queue_delay already = qcur)
+    const double grown = qcur + ebw;         // ns:82
+    q = rnd ? q : (full ? qcur : grown);
+    tu = rnd ? tu : t;                       // ns:76
     double2 rec;
     rec.x = t + lat0;                        // ns:174
-    rec.y = dropped ? -lat0 : lat0;          // ns:173 (0.0 + lat0), ns:175
+    rec.y = (rnd || full) ? -lat0 : lat0;    // ns:173 (0.0 + lat0), ns:175
     return rec;
 }
 
@@ -171,7 +165,7 @@ __device__ __forceinline__ double2 link_send(double t, double u, double dl, doub
 // send_kernel: one lane per env.  apply_rate_delta (ns:235-241, 275-281) + every SEND event
 // with time < end of the coming MI (ns:155-178).
 // ======================================================================================
-template <int NS>
+template <int NS, bool TRACE>
 __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t warm_mi, const void *actions,
                                                      int actions_f64) {
     const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
@@ -210,7 +204,7 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
         sent[s] = 0;
         ring[s] = D.ring + ((int64_t)i * NS + s) * D.cap;
     }
-    const double *trace = D.rng_mode == PCC_RNG_TRACE ? D.trace + i * D.trace_stride : nullptr;
+    const double *trace = TRACE ? D.trace + i * D.trace_stride : nullptr;
 
     if (now < end) {
         uint32_t w[NS][4];
@@ -224,7 +218,7 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
             for (int ss = 0; ss < NS; ss++) {
                 if (ss != s) continue;
                 double u;
-                if (trace) {
+                if (TRACE) {
                     uint64_t pos = tail[0];
                     if (NS > 1) pos += tail[NS - 1];
                     if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
@@ -238,12 +232,10 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
                 sent[ss]++;                       // ns:260-262
                 nsend[ss] = t + gap[ss];          // ns:161
                 const double2 rec = link_send(t, u, dl, lr, maxq, ebw, q, tu);
-                if (tail[ss] - h2[ss] >= D.cap) {
-                    flags |= PCC_FLAG_RING_OVERFLOW;  // never silent; the packet is not recorded
-                } else {
-                    ring[ss][tail[ss] & D.cap_mask] = rec;
-                    tail[ss]++;
-                }
+                const bool room = tail[ss] - h2[ss] < D.cap;
+                if (room) ring[ss][tail[ss] & D.cap_mask] = rec;
+                tail[ss] += room ? 1u : 0u;
+                flags |= room ? 0u : PCC_FLAG_RING_OVERFLOW;  // never silent; the packet is not recorded
             }
         }
     }
@@ -929,12 +921,15 @@ dim3 group_grid(const Dev &d) {
 int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, const void *actions, int actions_f64,
               float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
     const Dev &d = sim->d;
+    const bool tr = d.rng_mode == PCC_RNG_TRACE;
     if (d.ns == 1) {
-        hipLaunchKernelGGL(send_kernel<1>, lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<1, false>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
         hipLaunchKernelGGL(retire_kernel<1>, group_grid(d), dim3(kRetireBlock), 0, st, d, warm, warm_mi, last_warm,
                            obs_out, reward_out, done_out, steps_out);
     } else {
-        hipLaunchKernelGGL(send_kernel<2>, lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<2, false>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
         hipLaunchKernelGGL(retire_kernel<2>, group_grid(d), dim3(kRetireBlock), 0, st, d, warm, warm_mi, last_warm,
                            obs_out, reward_out, done_out, steps_out);
     }

@@ -195,7 +195,7 @@ class BatchedNetworkEnv(object):
         info = {}
         if self._steps is not None:
             info["steps"] = self._out(self._steps)
-        return self._out(self._obs), self._out(self._reward), self._done.bool(), info
+        return self._out(self._obs), self._out(self._reward), self._done.view(torch.bool), info
 
     # ------------------------------------------------------------------ introspection
     def state(self, name):
