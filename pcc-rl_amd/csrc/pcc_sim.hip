@@ -53,6 +53,7 @@ constexpr int kWave = 64;
 constexpr int kGroup = 16;            // lanes per env in retire_kernel
 constexpr int kRetireBlock = 256;     // 16 envs per workgroup
 constexpr int kStage = 64;            // LDS-staged RTT samples per env (doubles)
+constexpr int kScanDepth = 4;         // 16-record chunks requested ahead in the ring scans
 constexpr double kMaxRate = 1000.0;      // ns:36
 constexpr double kMinRate = 40.0;        // ns:37
 constexpr double kRewardScale = 0.001;   // ns:39
@@ -146,11 +147,10 @@ __device__ __forceinline__ double philox_packet_uniform(const Dev &D, uint32_t g
 // Returns the record (t + lat0, +-lat0).  Branch-free: the three outcomes (random loss: queue
 // untouched, ns:73-74; tail drop: queue drained but not grown, ns:75-81; accepted: ns:82) are
 // selects over values computed in the reference's operation order.
-__device__ __forceinline__ double2 link_send(double t, double u, double dl, double lr, double maxq, double ebw,
-                                             double &q, double &tu) {
+__device__ __forceinline__ double2 link_send(double t, bool rnd /* random.random() < lr, ns:73 */, double dl,
+                                             double maxq, double ebw, double &q, double &tu) {
     const double qcur = max0(q - (t - tu));  // ns:66-67
     const double lat0 = dl + qcur;           // ns:170: latency before this packet queues
-    const bool rnd = u < lr;                 // ns:73
     const bool full = ebw + qcur > maxq;     // ns:79 (with queue_delay already = qcur)
     const double grown = qcur + ebw;         // ns:82
     q = rnd ? q : (full ? qcur : grown);
@@ -206,10 +206,41 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
     }
     const double *trace = TRACE ? D.trace + i * D.trace_stride : nullptr;
 
-    if (now < end) {
+    if (NS == 1 && !TRACE) {
+        // Hot loop of the whole simulator: one sender, Philox uniforms.  Four packets per Philox
+        // block, no loads, no data-dependent branches besides the loop exits.
+        // u32_to_unit(x) < lr  <=>  x < ceil(lr * 2^32) for integer x (the scaling is exact).
+        const double thr_d = ceil(lr * 4294967296.0);
+        const bool always = thr_d >= 4294967296.0;
+        const uint32_t thr = always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
+        double t = nsend[0];
+        uint32_t tb = tail[0];
+        uint32_t blk = 0;
+        char *base = reinterpret_cast<char *>(ring[0]);
+        const uint32_t mask_b = D.cap_mask << 4;
+        if (now < end) {
+            while (t < end) {
+                uint32_t w[4];
+                philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                blk++;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k > 0 && !(t < end)) break;
+                    const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu);
+                    *reinterpret_cast<double2 *>(base + ((tb << 4) & mask_b)) = rec;
+                    tb++;
+                    t += gap[0];  // ns:161
+                }
+            }
+        }
+        nsend[0] = t;
+        sent[0] = tb - tail[0];
+        tail[0] = tb;
+        if (tb - h2[0] > D.cap) flags |= PCC_FLAG_RING_OVERFLOW;  // never silent (records were overwritten)
+    } else if (now < end) {
+        // general loop: two senders merged in (time, sender id) order, or replayed loss uniforms
         uint32_t w[NS][4];
         for (;;) {
-            // next SEND in (time, sender id) order
             int s = 0;
             if (NS > 1 && nsend[NS - 1] < nsend[0]) s = NS - 1;
             const double t = (NS > 1 && s) ? nsend[NS - 1] : nsend[0];
@@ -231,7 +262,7 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
                 }
                 sent[ss]++;                       // ns:260-262
                 nsend[ss] = t + gap[ss];          // ns:161
-                const double2 rec = link_send(t, u, dl, lr, maxq, ebw, q, tu);
+                const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu);
                 const bool room = tail[ss] - h2[ss] < D.cap;
                 if (room) ring[ss][tail[ss] & D.cap_mask] = rec;
                 tail[ss] += room ? 1u : 0u;
@@ -276,27 +307,37 @@ __device__ __forceinline__ uint32_t scan_prefix(const Group &g, const double2 *r
     stop.x = INFINITY;
     stop.y = 1.0;
     while (i < tail) {
-        const uint32_t k = i + g.lane;
-        const bool valid = k < tail;
-        double2 r;
-        r.x = 0.0; r.y = 1.0;
-        if (valid) r = ring[k & mask];
-        const bool pass = valid && (r.x + add < end);
-        const uint32_t mvalid = gballot(g, valid), mpass = gballot(g, pass);
-        const uint32_t mdrop = gballot(g, valid && rec_dropped(r));
-        const uint32_t mfail = mvalid & ~mpass;
-        if (mfail) {
-            const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
-            const uint32_t pre = (1u << f) - 1u;
-            acked += __popc(pre & ~mdrop);
-            lost += __popc(pre & mdrop);
-            stop.x = gbcast(r.x, f);
-            stop.y = gbcast(r.y, f);
-            return i + f;
+        // kScanDepth chunks of 16 records are requested before the first is looked at: the scan is a
+        // chain of dependent round trips to HBM/L2 otherwise
+        double2 r[kScanDepth];
+#pragma unroll
+        for (int c = 0; c < kScanDepth; c++) {
+            const uint32_t k = i + c * kGroup + g.lane;
+            r[c].x = 0.0; r[c].y = 1.0;
+            if (k < tail) r[c] = ring[k & mask];
         }
-        acked += __popc(mvalid & ~mdrop);
-        lost += __popc(mvalid & mdrop);
-        i += kGroup;
+#pragma unroll
+        for (int c = 0; c < kScanDepth; c++) {
+            const uint32_t i0 = i + c * kGroup;
+            if (i0 >= tail) return tail;
+            const bool valid = i0 + g.lane < tail;
+            const bool pass = valid && (r[c].x + add < end);
+            const uint32_t mvalid = gballot(g, valid), mpass = gballot(g, pass);
+            const uint32_t mdrop = gballot(g, valid && rec_dropped(r[c]));
+            const uint32_t mfail = mvalid & ~mpass;
+            if (mfail) {
+                const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
+                const uint32_t pre = (1u << f) - 1u;
+                acked += __popc(pre & ~mdrop);
+                lost += __popc(pre & mdrop);
+                stop.x = gbcast(r[c].x, f);
+                stop.y = gbcast(r[c].y, f);
+                return i0 + f;
+            }
+            acked += __popc(mvalid & ~mdrop);
+            lost += __popc(mvalid & mdrop);
+        }
+        i += kScanDepth * kGroup;
     }
     return tail;
 }
@@ -495,26 +536,33 @@ __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, u
     else walker_begin(w, 0, (need_halves && half >= 1) ? half : 0);
     double first_mean = 0.0;
     uint32_t produced = 0;
-    for (uint32_t i = from; i < to; i += kGroup) {
-        const uint32_t k = i + g.lane;
-        const bool valid = k < to;
-        double2 r;
-        r.x = 0.0; r.y = -1.0;
-        if (valid) r = ring[k & mask];
-        const bool ack = valid && !rec_dropped(r);
-        const uint32_t mack = gballot(g, ack);
-        if (ack) stage[(produced + __popc(mack & ((1u << g.lane) - 1u))) & (kStage - 1)] = r.y + dl;
-        produced += __popc(mack);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        walker_drain(w, stage, produced, sl);
-        if (sub == 1 && w.done && !second && need_halves && half >= 1) {
-            first_mean = w.tot / (double)half;
-            second = true;
-            walker_begin(w, half, n - half);
-            walker_drain(w, stage, produced, sl);
+    for (uint32_t i = from; i < to; i += kScanDepth * kGroup) {
+        double2 rr[kScanDepth];
+#pragma unroll
+        for (int c = 0; c < kScanDepth; c++) {
+            const uint32_t k = i + c * kGroup + g.lane;
+            rr[c].x = 0.0; rr[c].y = -1.0;
+            if (k < to) rr[c] = ring[k & mask];
         }
-        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < kScanDepth; c++) {
+            if (i + c * kGroup >= to) break;
+            const double2 r = rr[c];
+            const bool ack = (i + c * kGroup + g.lane < to) && !rec_dropped(r);
+            const uint32_t mack = gballot(g, ack);
+            if (ack) stage[(produced + __popc(mack & ((1u << g.lane) - 1u))) & (kStage - 1)] = r.y + dl;
+            produced += __popc(mack);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            walker_drain(w, stage, produced, sl);
+            if (sub == 1 && w.done && !second && need_halves && half >= 1) {
+                first_mean = w.tot / (double)half;
+                second = true;
+                walker_begin(w, half, n - half);
+                walker_drain(w, stage, produced, sl);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     // sub 0 now holds the full sum, sub 1 the second-half sum
     const double tot = gbcast(w.tot, 0);
@@ -682,7 +730,7 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
                 const double rate = D.rate[(int64_t)s * D.n + i];
                 sent[s]++;
                 nsend[s] = t + 1.0 / rate;
-                const double2 rec = link_send(t, u, dl, D.lr[i], D.maxq[i], D.ebw[i], q, tu);
+                const double2 rec = link_send(t, u < D.lr[i], dl, D.maxq[i], D.ebw[i], q, tu);
                 if (tail[s] - h2[s] >= D.cap) {
                     flags |= PCC_FLAG_RING_OVERFLOW;
                 } else {
