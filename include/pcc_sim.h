@@ -79,16 +79,17 @@ enum {
     PCC_F_RATE0,         /* f64 [S][N]  starting rate                        (ns:210) */
     PCC_F_NEXT_SEND,     /* f64 [S][N]  time of the pending SEND event       (ns:111,161) */
     PCC_F_MIN_LAT,       /* f64 [S][N]  connection min of per-MI mean RTT, 0 = none (so:158-176) */
-    PCC_F_RING_HEAD,     /* u32 [S][N]  packets fully acknowledged/lost this episode  */
-    PCC_F_RING_MID,      /* u32 [S][N]  lower bound of the packets past the forward hop */
-    PCC_F_RING_TAIL,     /* u32 [S][N]  packets sent this episode                     */
+    PCC_F_ACC_HEAD,      /* u32 [S][N]  accepted packets acknowledged this episode    */
+    PCC_F_ACC_TAIL,      /* u32 [S][N]  packets accepted by the queue this episode    */
+    PCC_F_DROP_HEAD,     /* u32 [S][N]  dropped packets whose loss was reported       */
+    PCC_F_DROP_TAIL,     /* u32 [S][N]  packets dropped (random loss or tail drop)    */
     PCC_F_EP_RETURN,     /* f64 [S][N]  reward summed over the running episode (ns:442) */
     PCC_F_LAST_RETURN,   /* f64 [S][N]  return of the last finished episode            */
     PCC_F_TOTAL_SENT,    /* u64 [N]     packets sent since create (all episodes, all senders) */
     PCC_N_FIELDS
 };
 
-#define PCC_FLAG_RING_OVERFLOW 1u  /* more packets in flight than ring_capacity: results invalid */
+#define PCC_FLAG_RING_OVERFLOW 1u  /* more accepted or dropped packets in flight than ring_capacity: results invalid */
 #define PCC_FLAG_TRACE_OVERRUN 2u  /* PCC_RNG_TRACE ran past trace_stride */
 
 /* last error text of the calling thread ("" if none) */
@@ -101,9 +102,12 @@ const char *pcc_last_error(void);
  *   n_senders       1 (the reference env, ns:466) or 2 (two senders on the shared bottleneck).
  *   seed            Philox key.  env_gid_base: global id of env 0 (rank * n_envs when the
  *                   batch is sharded over GPUs) so results do not depend on the sharding.
- *   ring_capacity   power of two, per env per sender, in packets (0 = default 65536: the
- *                   worst case of the default ranges is rate_max * (RTT_max + one MI) =
- *                   1000 * (30.8 + 15.4) = 46.2k packets between two retire passes).
+ *   ring_capacity   power of two, per env per sender, in packets (0 = default 32768) of the
+ *                   ring of accepted packets; the ring of dropped packets holds twice as many.
+ *                   The worst case of the default ranges is rate_max * (RTT_max + one MI) =
+ *                   1000 * (30.8 + 15.4) = 46.2k packets in flight between two retire passes
+ *                   (nearly all of them drops), of which at most bw_max * that time = 23k are
+ *                   accepted.  Device memory = n_envs * n_senders * 3 * ring_capacity * 16 B.
  *   device_id       HIP device ordinal (-1 = current device).
  * No env is usable before pcc_reset.
  */

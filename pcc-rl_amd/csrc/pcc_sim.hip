@@ -13,15 +13,16 @@
 //     t2 = t1 + dl).  Link state and the loss RNG are touched only by SEND events and the rate
 //     is constant inside an MI, so an MI splits into (1) the SEND stream -- a sequential
 //     recurrence per env -- and (2) retiring the packets whose events fall before the MI end.
-//   * In-flight packets live in one HBM ring per env per sender, appended in send order as
-//     16-byte records (fp64 t1, fp64 forward latency with the drop flag in its sign bit).
+//   * In-flight packets live in two HBM rings per env per sender -- accepted packets and dropped
+//     packets -- appended in send order as 16-byte records (fp64 t1, fp64 forward latency).
 //     Records are never rewritten: t2 and the RTT are t1 + dl and latency + dl, recomputed.
-//   * Send order IS event order except inside a "drop run" (a run of dropped packets plus the
-//     packet that ends it): those arrive at mathematically equal times, so float rounding and
-//     the heap's tuple tie-break (time, latency, dropped) decide their order.  Runs are
-//     separated by >= 1/bw, acknowledged packets are always in send order, and only the MI
-//     boundary can cut through a run -- so exactness needs order only inside the one run at
-//     each boundary, handled by a small serial path.
+//   * Accepted packets leave the queue >= 1/bw apart, so their send order IS event order and
+//     every MI boundary on that ring is a monotone search; the RTT samples of an MI are a
+//     contiguous slice of it.  Dropped packets between two accepted ones arrive at
+//     mathematically equal times, so float rounding and the heap's tuple tie-break
+//     (time, latency, dropped) decide their order: the dropped ring is in event order only up
+//     to groups of near-equal times, and a small serial path orders the one group at each
+//     boundary exactly.
 //   * Every floating-point operation on the timeline is IEEE binary64 in the reference's order
 //     (compile with -ffp-contract=off).  The per-MI RTT means replicate numpy's pairwise
 //     summation bit for bit, because run_dur = 0.5 * mean feeds back into event boundaries.
@@ -29,10 +30,10 @@
 // Kernels per step:
 //   send_kernel    one lane per env: apply the action, run the SEND recurrence up to the MI end,
 //                  append records (no loads in the loop).
-//   retire_kernel  16 lanes per env: coalesced scans of the ring for the hop-2 / hop-1
-//                  boundaries (ballots + popcounts), the MI-ending event, RTT sums through an
-//                  LDS-staged stream with numpy's pairwise tree laid over 8-lane groups,
-//                  metrics, history, observation, reward, done.
+//   retire_kernel  16 lanes per env: 16-ary searches of the rings for the hop-2 / hop-1
+//                  boundaries, the MI-ending event, RTT sums through an LDS-staged stream with
+//                  numpy's pairwise tree laid over 8-lane groups, metrics, history,
+//                  observation, reward, done.
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
@@ -82,7 +83,8 @@ struct Dev {
     int64_t n;
     int ns, H, F, HF;
     int32_t fid[kMaxFeatures];
-    uint32_t cap, cap_mask;
+    uint32_t cap, cap_mask;      // accepted ring (records)
+    uint32_t dcap, dcap_mask;    // dropped ring = 2 * cap: under overload ~90 % of the packets are drops
     uint32_t key0, key1, gid_base;
     double delta_scale;
     uint32_t max_steps;
@@ -98,9 +100,9 @@ struct Dev {
     unsigned long long *total_sent;
     // per sender, [S][N]
     double *rate, *rate0, *next_send, *min_lat, *ep_return, *last_return;
-    uint32_t *h2, *c1, *tail, *mi_sent;
+    uint32_t *ha, *hd, *ta, *td, *mi_sent;  // accepted/dropped ring heads and tails
     float *hist;    // [N][S][HF]
-    double2 *ring;  // [N][S][cap]
+    double2 *ring;  // [N][S][2][cap]: accepted ring, dropped ring
 };
 
 // --------------------------------------------------------------------------------------
@@ -144,21 +146,45 @@ __device__ __forceinline__ double philox_packet_uniform(const Dev &D, uint32_t g
 }
 
 // Link.packet_enters_link + latency sampling for one SEND at time t: ns:66-84, 170-175.
-// Returns the record (t + lat0, +-lat0).  Branch-free: the three outcomes (random loss: queue
-// untouched, ns:73-74; tail drop: queue drained but not grown, ns:75-81; accepted: ns:82) are
-// selects over values computed in the reference's operation order.
+// Returns the record (t + lat0, lat0) and whether the packet was dropped.  Branch-free: the three
+// outcomes (random loss: queue untouched, ns:73-74; tail drop: queue drained but not grown,
+// ns:75-81; accepted: ns:82) are selects over values computed in the reference's operation order.
 __device__ __forceinline__ double2 link_send(double t, bool rnd /* random.random() < lr, ns:73 */, double dl,
-                                             double maxq, double ebw, double &q, double &tu) {
+                                             double maxq, double ebw, double &q, double &tu, bool &dropped) {
     const double qcur = max0(q - (t - tu));  // ns:66-67
     const double lat0 = dl + qcur;           // ns:170: latency before this packet queues
     const bool full = ebw + qcur > maxq;     // ns:79 (with queue_delay already = qcur)
     const double grown = qcur + ebw;         // ns:82
     q = rnd ? q : (full ? qcur : grown);
     tu = rnd ? tu : t;                       // ns:76
+    dropped = rnd || full;                   // ns:175
     double2 rec;
     rec.x = t + lat0;                        // ns:174
-    rec.y = (rnd || full) ? -lat0 : lat0;    // ns:173 (0.0 + lat0), ns:175
+    rec.y = lat0;                            // ns:173 (0.0 + lat0)
     return rec;
+}
+
+// ======================================================================================
+// In-flight packet storage.  Per env and sender two rings of 16-byte records (t1, lat0):
+//   accepted ring  packets that entered the queue, in send order.  Their arrival times grow
+//                  by >= 1/bw per packet, so send order IS event order (exactly), every
+//                  boundary is a monotone search, and the RTT samples of an MI are a
+//                  contiguous slice.
+//   dropped ring   packets lost at random or tail-dropped, in send order.  Consecutive drops
+//                  with no accepted packet in between arrive at mathematically equal times
+//                  (a dropped packet does not delay its successor), so rounding decides their
+//                  order: send order is event order only up to "near groups" (neighbours
+//                  within kNearTol relative time), which a serial path orders exactly.
+// ======================================================================================
+constexpr double kNearTol = 1e-12;  // >> the few-ulp spread of a tie group, << any 1/bw
+
+__device__ __forceinline__ bool near_time(double a, double b) {
+    return fabs(a - b) <= kNearTol * fmax(1.0, fabs(b));
+}
+
+template <int NS>
+__device__ __forceinline__ double2 *ring_of(const Dev &D, int64_t i, int s, int dropped) {
+    return D.ring + ((int64_t)i * NS + s) * ((int64_t)D.cap + D.dcap) + (dropped ? D.cap : 0u);
 }
 
 // ======================================================================================
@@ -182,8 +208,7 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
     uint32_t flags = 0;
 
     double gap[NS], nsend[NS];
-    uint32_t tail[NS], h2[NS], sent[NS];
-    double2 *ring[NS];
+    uint32_t ta[NS], td[NS], ha[NS], hd[NS], sent[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
@@ -199,12 +224,12 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
         }
         gap[s] = 1.0 / rate;  // ns:161
         nsend[s] = D.next_send[k];
-        tail[s] = D.tail[k];
-        h2[s] = D.h2[k];
+        ta[s] = D.ta[k]; td[s] = D.td[k];
+        ha[s] = D.ha[k]; hd[s] = D.hd[k];
         sent[s] = 0;
-        ring[s] = D.ring + ((int64_t)i * NS + s) * D.cap;
     }
     const double *trace = TRACE ? D.trace + i * D.trace_stride : nullptr;
+    const uint32_t mask_b = D.cap_mask << 4, dmask_b = D.dcap_mask << 4, cap_b = D.cap << 4;
 
     if (NS == 1 && !TRACE) {
         // Hot loop of the whole simulator: one sender, Philox uniforms.  Four packets per Philox
@@ -214,10 +239,9 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
         const bool always = thr_d >= 4294967296.0;
         const uint32_t thr = always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
         double t = nsend[0];
-        uint32_t tb = tail[0];
+        uint32_t a = ta[0], d = td[0];
         uint32_t blk = 0;
-        char *base = reinterpret_cast<char *>(ring[0]);
-        const uint32_t mask_b = D.cap_mask << 4;
+        char *base = reinterpret_cast<char *>(ring_of<NS>(D, i, 0, 0));
         if (now < end) {
             while (t < end) {
                 uint32_t w[4];
@@ -226,17 +250,19 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (k > 0 && !(t < end)) break;
-                    const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu);
-                    *reinterpret_cast<double2 *>(base + ((tb << 4) & mask_b)) = rec;
-                    tb++;
+                    bool dropped;
+                    const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
+                    const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
+                    *reinterpret_cast<double2 *>(base + off) = rec;
+                    a += dropped ? 0u : 1u;
+                    d += dropped ? 1u : 0u;
                     t += gap[0];  // ns:161
                 }
             }
         }
         nsend[0] = t;
-        sent[0] = tb - tail[0];
-        tail[0] = tb;
-        if (tb - h2[0] > D.cap) flags |= PCC_FLAG_RING_OVERFLOW;  // never silent (records were overwritten)
+        sent[0] = (a - ta[0]) + (d - td[0]);
+        ta[0] = a; td[0] = d;
     } else if (now < end) {
         // general loop: two senders merged in (time, sender id) order, or replayed loss uniforms
         uint32_t w[NS][4];
@@ -250,8 +276,9 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
                 if (ss != s) continue;
                 double u;
                 if (TRACE) {
-                    uint64_t pos = tail[0];
-                    if (NS > 1) pos += tail[NS - 1];
+                    uint64_t pos = 0;
+#pragma unroll
+                    for (int x = 0; x < NS; x++) pos += (uint64_t)ta[x] + td[x];
                     if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
                     else u = trace[pos];
                 } else {
@@ -262,24 +289,28 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
                 }
                 sent[ss]++;                       // ns:260-262
                 nsend[ss] = t + gap[ss];          // ns:161
-                const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu);
-                const bool room = tail[ss] - h2[ss] < D.cap;
-                if (room) ring[ss][tail[ss] & D.cap_mask] = rec;
-                tail[ss] += room ? 1u : 0u;
-                flags |= room ? 0u : PCC_FLAG_RING_OVERFLOW;  // never silent; the packet is not recorded
+                bool dropped;
+                const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
+                char *base = reinterpret_cast<char *>(ring_of<NS>(D, i, ss, 0));
+                const uint32_t off = dropped ? cap_b + ((td[ss] << 4) & dmask_b) : ((ta[ss] << 4) & mask_b);
+                *reinterpret_cast<double2 *>(base + off) = rec;
+                ta[ss] += dropped ? 0u : 1u;
+                td[ss] += dropped ? 1u : 0u;
             }
         }
     }
 
     D.q[i] = q; D.tu[i] = tu;
-    if (flags) D.flags[i] |= flags;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
+        // never silent: more packets in flight than a ring holds means records were overwritten
+        if (ta[s] - ha[s] > D.cap || td[s] - hd[s] > D.dcap) flags |= PCC_FLAG_RING_OVERFLOW;
         const int64_t k = (int64_t)s * D.n + i;
         D.next_send[k] = nsend[s];
-        D.tail[k] = tail[s];
+        D.ta[k] = ta[s]; D.td[k] = td[s];
         D.mi_sent[k] = sent[s];
     }
+    if (flags) D.flags[i] |= flags;
 }
 
 // ======================================================================================
@@ -297,117 +328,113 @@ __device__ __forceinline__ uint32_t gballot(const Group &g, bool p) {
 __device__ __forceinline__ double gbcast(double v, uint32_t src) { return __shfl(v, (int)src, kGroup); }
 __device__ __forceinline__ uint32_t gbcast(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, kGroup); }
 
-// Cooperative scan of ring[from, tail): first index whose record fails `time + add < end`
-// (add = dl: hop-2 events, add = 0: hop-1 events).  Counts the acked / dropped records of the
-// passing prefix and returns the failing record (stop.x = INFINITY if the scan hit the tail).
-__device__ __forceinline__ uint32_t scan_prefix(const Group &g, const double2 *ring, uint32_t mask, uint32_t from,
-                                                uint32_t tail, double add, double end, uint32_t &acked,
-                                                uint32_t &lost, double2 &stop) {
-    uint32_t i = from;
-    stop.x = INFINITY;
-    stop.y = 1.0;
-    while (i < tail) {
-        // kScanDepth chunks of 16 records are requested before the first is looked at: the scan is a
-        // chain of dependent round trips to HBM/L2 otherwise
-        double2 r[kScanDepth];
-#pragma unroll
-        for (int c = 0; c < kScanDepth; c++) {
-            const uint32_t k = i + c * kGroup + g.lane;
-            r[c].x = 0.0; r[c].y = 1.0;
-            if (k < tail) r[c] = ring[k & mask];
-        }
-#pragma unroll
-        for (int c = 0; c < kScanDepth; c++) {
-            const uint32_t i0 = i + c * kGroup;
-            if (i0 >= tail) return tail;
-            const bool valid = i0 + g.lane < tail;
-            const bool pass = valid && (r[c].x + add < end);
-            const uint32_t mvalid = gballot(g, valid), mpass = gballot(g, pass);
-            const uint32_t mdrop = gballot(g, valid && rec_dropped(r[c]));
-            const uint32_t mfail = mvalid & ~mpass;
-            if (mfail) {
-                const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
-                const uint32_t pre = (1u << f) - 1u;
-                acked += __popc(pre & ~mdrop);
-                lost += __popc(pre & mdrop);
-                stop.x = gbcast(r[c].x, f);
-                stop.y = gbcast(r[c].y, f);
-                return i0 + f;
-            }
-            acked += __popc(mvalid & ~mdrop);
-            lost += __popc(mvalid & mdrop);
-        }
-        i += kScanDepth * kGroup;
+// First index k in [lo, hi) whose record fails `t1 + add < end` (hi if none), by 16-ary search:
+// every round the 16 lanes sample the ends of 16 equal sub-ranges.  Exact for a monotone
+// predicate; on the dropped ring the answer can be off inside one near group, which the caller
+// repairs (fix_drop_boundary).
+__device__ __forceinline__ uint32_t search_boundary(const Group &g, const double2 *ring, uint32_t mask, uint32_t lo,
+                                                    uint32_t hi, double add, double end) {
+    while (hi - lo > kGroup) {
+        const uint32_t stride = (hi - lo + kGroup - 1) / kGroup;
+        uint32_t sidx = lo + (g.lane + 1) * stride;
+        if (sidx > hi) sidx = hi;
+        sidx -= 1;
+        const bool pass = ring[sidx & mask].x + add < end;
+        const uint32_t mfail = ~gballot(g, pass) & 0xFFFFu;
+        if (!mfail) return hi;  // the last sample is record hi-1
+        const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
+        const uint32_t s_f = gbcast(sidx, f);
+        if (f) lo = gbcast(sidx, f - 1) + 1;
+        hi = s_f;
+        if (hi < lo) hi = lo;
     }
-    return tail;
+    const uint32_t k = lo + g.lane;
+    const bool fail = k < hi && !(ring[k & mask].x + add < end);
+    const uint32_t m = gballot(g, fail);
+    return m ? lo + (uint32_t)__ffs((int)m) - 1u : hi;
 }
 
-// ---- serial paths (one lane), only entered when the record at a boundary is a dropped one --
+// ---- serial paths on the dropped ring (one lane) -----------------------------------------
 
-// ring[p] is a dropped record with t2 >= end.  Its drop run continues while the previous record
-// (send order) is dropped; members of the run with t2 < end were still popped by the heap, so
-// move each of them in front of p (others keep their order) and count it.
-__device__ __noinline__ uint32_t fix_pop_run(double2 *ring, uint32_t mask, uint32_t p, uint32_t tail, double dl,
-                                             double end, uint32_t &acked, uint32_t &lost) {
-    uint32_t k = p + 1;
-    bool prev_dropped = true;
-    while (k < tail && prev_dropped) {
+// move ring[k] in front of ring[p] (p <= k), keeping the order of the records in between
+__device__ __forceinline__ void rotate_to_front(double2 *ring, uint32_t mask, uint32_t p, uint32_t k) {
+    const double2 r = ring[k & mask];
+    for (uint32_t m = k; m > p; m--) ring[m & mask] = ring[(m - 1) & mask];
+    ring[p & mask] = r;
+}
+
+// Records around a search transition b that may be out of event order: b-1 and b themselves plus
+// everything chained to them by near-equal times.  [g0, g1) with h <= g0 <= b <= g1 <= tail.
+__device__ __forceinline__ void near_window(const double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t b,
+                                            uint32_t &g0, uint32_t &g1) {
+    g0 = b;
+    g1 = b;
+    if (b > h) {
+        g0 = b - 1;
+        double t = ring[g0 & mask].x;
+        while (g0 > h) {
+            const double tp = ring[(g0 - 1) & mask].x;
+            if (!near_time(tp, t)) break;
+            t = tp;
+            g0--;
+        }
+    }
+    if (b < tail) {
+        g1 = b + 1;
+        double t = ring[b & mask].x;
+        while (g1 < tail) {
+            const double tn = ring[g1 & mask].x;
+            if (!near_time(tn, t)) break;
+            t = tn;
+            g1++;
+        }
+    }
+}
+
+// Exact retire boundary of the dropped ring: on return records [h, p) are exactly those with
+// t1 + dl < end (members of the boundary window that pass are moved in front, the rest keep
+// their order).  Also reports the best hop-2 candidate (smallest (t2, lat2) key) among the
+// window's unretired records that are already past the forward hop (t1 < end).
+__device__ __noinline__ uint32_t fix_drop_boundary(double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t b,
+                                                   double dl, double end, uint32_t &cand_idx, double &cand_t,
+                                                   double &cand_lat) {
+    uint32_t g0, g1;
+    near_window(ring, mask, h, tail, b, g0, g1);
+    uint32_t p = g0;
+    for (uint32_t k = g0; k < g1; k++) {
         const double2 r = ring[k & mask];
-        prev_dropped = rec_dropped(r);
         if (r.x + dl < end) {
-            for (uint32_t m = k; m > p; m--) ring[m & mask] = ring[(m - 1) & mask];
-            ring[p & mask] = r;
-            if (rec_dropped(r)) lost++;
-            else acked++;
+            if (k != p) rotate_to_front(ring, mask, p, k);
             p++;
         }
-        k++;
+    }
+    cand_idx = 0xFFFFFFFFu;
+    cand_t = INFINITY;
+    cand_lat = 0.0;
+    for (uint32_t k = p; k < g1; k++) {
+        const double2 r = ring[k & mask];
+        if (r.x < end) {
+            const double t2 = r.x + dl, l2 = r.y + dl;
+            if (cand_idx == 0xFFFFFFFFu || t2 < cand_t || (t2 == cand_t && l2 < cand_lat)) {
+                cand_idx = k; cand_t = t2; cand_lat = l2;
+            }
+        }
     }
     return p;
 }
 
-// smallest hop-2 key (t1+dl, lat+dl, dropped) among the records of the drop run starting at p
-// that are already past the forward hop (t1 < end).  Returns its index or 0xFFFFFFFF.
-__device__ __noinline__ uint32_t min_hop2_in_run(const double2 *ring, uint32_t mask, uint32_t p, uint32_t tail,
-                                                 double dl, double end, double2 &best) {
-    uint32_t kb = 0xFFFFFFFFu, k = p;
-    bool prev_dropped = true;
-    double bt = 0.0, by = 0.0;
-    while (k < tail && prev_dropped) {
+// Best hop-1 candidate of the dropped ring: smallest (t1, lat) among the records still on the
+// forward hop (t1 >= end); c = search transition for `t1 < end`.
+__device__ __noinline__ void drop_hop1_candidate(const double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t c,
+                                                 double end, double &cand_t, double &cand_lat) {
+    uint32_t g0, g1;
+    near_window(ring, mask, h, tail, c, g0, g1);
+    cand_t = INFINITY;
+    cand_lat = 0.0;
+    for (uint32_t k = g0; k < g1; k++) {
         const double2 r = ring[k & mask];
-        prev_dropped = rec_dropped(r);
-        if (r.x < end) {
-            const double t2 = r.x + dl;
-            const double l2 = fabs(r.y) + dl;
-            const double y2 = rec_dropped(r) ? -l2 : l2;
-            if (kb == 0xFFFFFFFFu || key_less(t2, y2, bt, by)) { kb = k; bt = t2; by = y2; best = r; }
-        }
-        k++;
+        if (!(r.x < end) && (r.x < cand_t || (r.x == cand_t && r.y < cand_lat))) { cand_t = r.x; cand_lat = r.y; }
     }
-    return kb;
-}
-
-// smallest hop-1 key (t1, lat, dropped) among the records of the drop run starting at c that
-// are still on the forward hop (t1 >= end).
-__device__ __noinline__ double min_hop1_in_run(const double2 *ring, uint32_t mask, uint32_t c, uint32_t tail,
-                                               double end) {
-    uint32_t k = c;
-    bool prev_dropped = true, have = false;
-    double bt = INFINITY, by = 1.0;
-    while (k < tail && prev_dropped) {
-        const double2 r = ring[k & mask];
-        prev_dropped = rec_dropped(r);
-        if (!(r.x < end) && (!have || key_less(r.x, r.y, bt, by))) { have = true; bt = r.x; by = r.y; }
-        k++;
-    }
-    return bt;
-}
-
-// move ring[k] in front of ring[p] (p <= k), keeping the order of the records in between
-__device__ __noinline__ void rotate_to_front(double2 *ring, uint32_t mask, uint32_t p, uint32_t k) {
-    const double2 r = ring[k & mask];
-    for (uint32_t m = k; m > p; m--) ring[m & mask] = ring[(m - 1) & mask];
-    ring[p & mask] = r;
 }
 
 // --------------------------------------------------------------------------------------
@@ -522,12 +549,12 @@ __device__ __forceinline__ void walker_drain(Walker &w, const double *stage, uin
     }
 }
 
-// Means over the RTTs (= forward latency + dl) of the acknowledged records of ring[from, to):
-// the whole list (so:119-122) and, when asked, mean(second half) - mean(first half)
-// (so:138-142).  n = number of acknowledged records in the range (> 0).
+// Means over the RTTs (= forward latency + dl) of the n > 0 acknowledged packets
+// ring[from, from + n) of the accepted ring: the whole list (so:119-122) and, when asked,
+// mean(second half) - mean(first half) (so:138-142).
 __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, uint32_t mask, uint32_t from,
-                                          uint32_t to, uint32_t n, double dl, bool need_halves, double *stage,
-                                          double &mean_all, double &lat_inc) {
+                                          uint32_t n, double dl, bool need_halves, double *stage, double &mean_all,
+                                          double &lat_inc) {
     const uint32_t sub = g.lane >> 3, sl = g.lane & 7u;
     const uint32_t half = n / 2;
     Walker w;
@@ -535,23 +562,20 @@ __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, u
     if (sub == 0) walker_begin(w, 0, n);
     else walker_begin(w, 0, (need_halves && half >= 1) ? half : 0);
     double first_mean = 0.0;
-    uint32_t produced = 0;
-    for (uint32_t i = from; i < to; i += kScanDepth * kGroup) {
-        double2 rr[kScanDepth];
+    for (uint32_t i = 0; i < n; i += kScanDepth * kGroup) {
+        double lat[kScanDepth];
 #pragma unroll
         for (int c = 0; c < kScanDepth; c++) {
             const uint32_t k = i + c * kGroup + g.lane;
-            rr[c].x = 0.0; rr[c].y = -1.0;
-            if (k < to) rr[c] = ring[k & mask];
+            lat[c] = 0.0;
+            if (k < n) lat[c] = ring[(from + k) & mask].y;
         }
 #pragma unroll
         for (int c = 0; c < kScanDepth; c++) {
-            if (i + c * kGroup >= to) break;
-            const double2 r = rr[c];
-            const bool ack = (i + c * kGroup + g.lane < to) && !rec_dropped(r);
-            const uint32_t mack = gballot(g, ack);
-            if (ack) stage[(produced + __popc(mack & ((1u << g.lane) - 1u))) & (kStage - 1)] = r.y + dl;
-            produced += __popc(mack);
+            const uint32_t i0 = i + c * kGroup;
+            if (i0 >= n) break;
+            if (i0 + g.lane < n) stage[(i0 + g.lane) & (kStage - 1)] = lat[c] + dl;
+            const uint32_t produced = (i0 + kGroup < n) ? i0 + kGroup : n;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
             walker_drain(w, stage, produced, sl);
@@ -622,7 +646,7 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
     if (warm && !D.resetting[i]) return;
     double *stage = s_stage[tid / kGroup];
     const bool lead = g.lane == 0;
-    const uint32_t mask = D.cap_mask;
+    const uint32_t mask = D.cap_mask, dmask = D.dcap_mask;
 
     const double dl = D.dl[i];
     const double start = D.now[i];
@@ -632,64 +656,65 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
     double now = start;
 
     double nsend[NS];
-    uint32_t h2[NS], c1[NS], tail[NS], sent[NS], acked[NS], lost[NS], from[NS];
-    double2 *ring[NS];
+    uint32_t ha[NS], hd[NS], ta[NS], td[NS], sent[NS], acked[NS], lost[NS], from[NS];
+    double2 *ra[NS], *rd[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
         nsend[s] = D.next_send[k];
-        h2[s] = D.h2[k]; c1[s] = D.c1[k]; tail[s] = D.tail[k];
+        ha[s] = D.ha[k]; hd[s] = D.hd[k]; ta[s] = D.ta[k]; td[s] = D.td[k];
         sent[s] = D.mi_sent[k];
         acked[s] = lost[s] = 0;
-        from[s] = h2[s];
-        ring[s] = D.ring + ((int64_t)i * NS + s) * D.cap;
+        from[s] = ha[s];
+        ra[s] = ring_of<NS>(D, i, s, 0);
+        rd[s] = ring_of<NS>(D, i, s, 1);
     }
     uint32_t flags = 0;
 
     if (start < end) {  // ns:128: otherwise the loop body never runs
-        double t_h1[NS], t_h2[NS];
+        // candidates for the MI-ending event per sender: hop-1, hop-2 (with the ring it sits in)
+        double t_h1[NS], t_h2[NS], l_h2[NS];
         uint32_t k_h2[NS];
+        bool h2_is_drop[NS];
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            // ---- hop-2 events before `end` (ns:140-146): a prefix of the ring
-            double2 stop;
-            uint32_t p = scan_prefix(g, ring[s], mask, h2[s], tail[s], dl, end, acked[s], lost[s], stop);
-            if (p < tail[s] && rec_dropped(stop)) {  // the boundary cuts a drop run: rare serial path
-                uint32_t a = acked[s], l = lost[s];
-                if (lead) p = fix_pop_run(ring[s], mask, p, tail[s], dl, end, a, l);
+            // ---- accepted ring: exact monotone searches
+            const uint32_t pa = search_boundary(g, ra[s], mask, ha[s], ta[s], dl, end);   // hop-2 events < end
+            acked[s] = pa - ha[s];                                                        // ns:144-146
+            const uint32_t ca = search_boundary(g, ra[s], mask, pa, ta[s], 0.0, end);     // hop-1 events < end
+            ha[s] = pa;
+            double a2_t = INFINITY, a2_l = 0.0, a1_t = INFINITY, a1_l = 0.0;
+            if (pa < ca) {  // first unretired accepted packet is past the forward hop
+                const double2 r = ra[s][pa & mask];
+                a2_t = r.x + dl; a2_l = r.y + dl;
+            }
+            if (ca < ta[s]) {
+                const double2 r = ra[s][ca & mask];
+                a1_t = r.x; a1_l = r.y;
+            }
+            // ---- dropped ring: searches, then the exact serial repair around each transition
+            const uint32_t bd = search_boundary(g, rd[s], dmask, hd[s], td[s], dl, end);
+            uint32_t pd = bd, dk = 0xFFFFFFFFu;
+            double d2_t = INFINITY, d2_l = 0.0;
+            if (td[s] != hd[s]) {
+                if (lead) pd = fix_drop_boundary(rd[s], dmask, hd[s], td[s], bd, dl, end, dk, d2_t, d2_l);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                p = gbcast(p, 0); acked[s] = gbcast(a, 0); lost[s] = gbcast(l, 0);
-                stop.x = INFINITY; stop.y = -1.0;
-                if (p < tail[s]) stop = ring[s][p & mask];
+                pd = gbcast(pd, 0); dk = gbcast(dk, 0); d2_t = gbcast(d2_t, 0); d2_l = gbcast(d2_l, 0);
             }
-            h2[s] = p;
-            // ---- hop-2 candidate for the MI-ending event: the first unretired record, if it is
-            // already past the forward hop (otherwise a hop-1 event precedes it)
-            t_h2[s] = INFINITY;
-            k_h2[s] = p;
-            if (p < tail[s]) {
-                if (!rec_dropped(stop)) {
-                    if (stop.x < end) t_h2[s] = stop.x + dl;
-                } else {
-                    uint32_t kb = 0xFFFFFFFFu;
-                    double2 best;
-                    best.x = 0.0; best.y = 1.0;
-                    if (lead) kb = min_hop2_in_run(ring[s], mask, p, tail[s], dl, end, best);
-                    kb = gbcast(kb, 0);
-                    if (kb != 0xFFFFFFFFu) { t_h2[s] = gbcast(best.x, 0) + dl; k_h2[s] = kb; }
-                }
+            lost[s] = pd - hd[s];                                                         // ns:141-143
+            hd[s] = pd;
+            const uint32_t cd = search_boundary(g, rd[s], dmask, pd, td[s], 0.0, end);
+            double d1_t = INFINITY, d1_l = 0.0;
+            if (td[s] != pd) {
+                if (lead) drop_hop1_candidate(rd[s], dmask, pd, td[s], cd, end, d1_t, d1_l);
+                d1_t = gbcast(d1_t, 0); d1_l = gbcast(d1_l, 0);
             }
-            // ---- hop-1 events before `end` (ns:147-154) only move the cursor: the record is reused
-            if (c1[s] < h2[s]) c1[s] = h2[s];
-            uint32_t na = 0, nl = 0;
-            const uint32_t c = scan_prefix(g, ring[s], mask, c1[s], tail[s], 0.0, end, na, nl, stop);
-            c1[s] = c;
-            t_h1[s] = stop.x;  // INFINITY if none
-            if (c < tail[s] && rec_dropped(stop)) {
-                double tb = stop.x;
-                if (lead) tb = min_hop1_in_run(ring[s], mask, c, tail[s], end);
-                t_h1[s] = gbcast(tb, 0);
-            }
+            // ---- best of each kind by the heap key (time, latency, dropped): ns:111,161,178
+            t_h1[s] = (d1_t < a1_t || (d1_t == a1_t && d1_l < a1_l)) ? d1_t : a1_t;
+            h2_is_drop[s] = (d2_t < a2_t || (d2_t == a2_t && d2_l < a2_l));
+            t_h2[s] = h2_is_drop[s] ? d2_t : a2_t;
+            l_h2[s] = h2_is_drop[s] ? d2_l : a2_l;
+            k_h2[s] = h2_is_drop[s] ? dk : pa;
         }
         // ---- the event that ends the MI: smallest (time, sender, 'A' < 'S', hop) among the stream
         // heads, all >= end here; the reference still processes it (ns:128-131)
@@ -705,22 +730,25 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             if (best == 3 * s + 1) {  // hop-2: acknowledge / lose one more packet
-                double2 r = ring[s][k_h2[s] & mask];
-                if (k_h2[s] != h2[s]) {
-                    if (lead) rotate_to_front(ring[s], mask, h2[s], k_h2[s]);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (h2_is_drop[s]) {
+                    if (k_h2[s] != hd[s]) {
+                        if (lead) rotate_to_front(rd[s], dmask, hd[s], k_h2[s]);
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    }
+                    lost[s]++;
+                    hd[s]++;
+                } else {
+                    acked[s]++;
+                    ha[s]++;
                 }
-                if (rec_dropped(r)) lost[s]++;
-                else acked[s]++;
-                h2[s]++;
-                if (c1[s] < h2[s]) c1[s] = h2[s];
             } else if (best == 3 * s + 2) {  // SEND: one more packet leaves (ns:155-178)
                 const double t = nsend[s];
                 double q = D.q[i], tu = D.tu[i];
                 double u;
                 if (D.rng_mode == PCC_RNG_TRACE) {
-                    uint64_t pos = tail[0];
-                    if (NS > 1) pos += tail[NS - 1];
+                    uint64_t pos = 0;
+#pragma unroll
+                    for (int x = 0; x < NS; x++) pos += (uint64_t)ta[x] + td[x];
                     if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
                     else u = D.trace[i * D.trace_stride + pos];
                 } else {
@@ -730,16 +758,20 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
                 const double rate = D.rate[(int64_t)s * D.n + i];
                 sent[s]++;
                 nsend[s] = t + 1.0 / rate;
-                const double2 rec = link_send(t, u < D.lr[i], dl, D.maxq[i], D.ebw[i], q, tu);
-                if (tail[s] - h2[s] >= D.cap) {
-                    flags |= PCC_FLAG_RING_OVERFLOW;
+                bool dropped;
+                const double2 rec = link_send(t, u < D.lr[i], dl, D.maxq[i], D.ebw[i], q, tu, dropped);
+                if (dropped) {
+                    if (lead) rd[s][td[s] & dmask] = rec;
+                    td[s]++;
                 } else {
-                    if (lead) ring[s][tail[s] & mask] = rec;
-                    tail[s]++;
+                    if (lead) ra[s][ta[s] & mask] = rec;
+                    ta[s]++;
                 }
+                if (ta[s] - ha[s] > D.cap || td[s] - hd[s] > D.dcap) flags |= PCC_FLAG_RING_OVERFLOW;
                 if (lead) { D.q[i] = q; D.tu[i] = tu; }
             }
         }
+        (void)l_h2;
     }
 
     // ---- state
@@ -754,7 +786,7 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
         for (int s = 0; s < NS; s++) {
             const int64_t k = (int64_t)s * D.n + i;
             D.next_send[k] = nsend[s];
-            D.h2[k] = h2[s]; D.c1[k] = c1[s]; D.tail[k] = tail[s];
+            D.ha[k] = ha[s]; D.hd[k] = hd[s]; D.ta[k] = ta[s]; D.td[k] = td[s];
         }
     }
     if (warm) {  // reset(): the two warm-up MIs are not recorded (ns:478-479)
@@ -775,8 +807,7 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
         double lat = 0.0, inc = 0.0;
-        if (acked[s] > 0)
-            rtt_means(g, ring[s], mask, from[s], h2[s], acked[s], dl, need_halves, stage, lat, inc);
+        if (acked[s] > 0) rtt_means(g, ra[s], mask, from[s], acked[s], dl, need_halves, stage, lat, inc);
         double min_lat = D.min_lat[k];
         double m[PCC_N_METRICS];
         mi_metrics(sent[s], acked[s], lost[s], dur, lat, inc, min_lat, m);
@@ -877,7 +908,7 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
         D.rate[k] = rate0[s];
         D.rate0[k] = rate0[s];
         D.next_send[k] = 1.0 / rate0[s];  // ns:111
-        D.h2[k] = 0; D.c1[k] = 0; D.tail[k] = 0; D.mi_sent[k] = 0;
+        D.ha[k] = 0; D.hd[k] = 0; D.ta[k] = 0; D.td[k] = 0; D.mi_sent[k] = 0;
         D.min_lat[k] = 0.0;   // fresh sender id => no connection minimum yet (ns:229-233, so:158)
         D.ep_return[k] = 0.0;
         // all-empty history (so:57-62): every metric of an empty MI is 0 except the two ratios
@@ -948,7 +979,7 @@ size_t carve_state(Dev &d, char *base) {
     d.total_sent = c.take<unsigned long long>(n);
     d.rate = c.take<double>(sn); d.rate0 = c.take<double>(sn); d.next_send = c.take<double>(sn);
     d.min_lat = c.take<double>(sn); d.ep_return = c.take<double>(sn); d.last_return = c.take<double>(sn);
-    d.h2 = c.take<uint32_t>(sn); d.c1 = c.take<uint32_t>(sn); d.tail = c.take<uint32_t>(sn);
+    d.ha = c.take<uint32_t>(sn); d.hd = c.take<uint32_t>(sn); d.ta = c.take<uint32_t>(sn); d.td = c.take<uint32_t>(sn);
     d.mi_sent = c.take<uint32_t>(sn);
     d.hist = c.take<float>(sn * d.HF);
     return (c.off + 255) & ~(size_t)255;
@@ -1021,8 +1052,8 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     for (int f = 0; f < n_features; f++)
         if (feature_ids[f] < 0 || feature_ids[f] >= PCC_N_METRICS)
             return fail(PCC_EINVAL, "feature id %d out of range", feature_ids[f]);
-    if (ring_capacity == 0) ring_capacity = 65536;
-    if (ring_capacity < 16 || (ring_capacity & (ring_capacity - 1)))
+    if (ring_capacity == 0) ring_capacity = 32768;
+    if (ring_capacity < 16 || ring_capacity > (1u << 27) || (ring_capacity & (ring_capacity - 1)))
         return fail(PCC_EINVAL, "ring_capacity must be a power of two >= 16");
 
     int count = 0;
@@ -1045,6 +1076,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.n = n_envs; d.ns = n_senders; d.H = history_len; d.F = n_features; d.HF = history_len * n_features;
     for (int f = 0; f < n_features; f++) d.fid[f] = feature_ids[f];
     d.cap = ring_capacity; d.cap_mask = ring_capacity - 1;
+    d.dcap = 2 * ring_capacity; d.dcap_mask = d.dcap - 1;
     d.key0 = (uint32_t)seed; d.key1 = (uint32_t)(seed >> 32); d.gid_base = env_gid_base;
     d.delta_scale = 0.025;  // src/common/config.py:17
     d.max_steps = 400;      // ns:41
@@ -1053,7 +1085,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.rng_mode = PCC_RNG_PHILOX;
     sim->device = device;
     sim->state_bytes = carve_state(d, nullptr);
-    sim->ring_bytes = (size_t)n_envs * n_senders * ring_capacity * sizeof(double2);
+    sim->ring_bytes = (size_t)n_envs * n_senders * 3 * ring_capacity * sizeof(double2);
     if (hipMalloc(&sim->state_blob, sim->state_bytes) != hipSuccess) {
         const size_t want = sim->state_bytes;
         delete sim;
@@ -1063,7 +1095,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         (void)hipFree(sim->state_blob);
         const size_t want = sim->ring_bytes;
         delete sim;
-        return fail(PCC_ENOMEM, "hipMalloc(%zu) for the in-flight rings failed (n_envs*n_senders*ring_capacity*16 B)", want);
+        return fail(PCC_ENOMEM, "hipMalloc(%zu) for the in-flight rings failed (n_envs*n_senders*3*ring_capacity*16 B)", want);
     }
     carve_state(d, static_cast<char *>(sim->state_blob));
     d.ring = static_cast<double2 *>(sim->ring_blob);
@@ -1198,9 +1230,10 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {
         case PCC_F_RATE0: src = d.rate0; bytes = sn * 8; break;
         case PCC_F_NEXT_SEND: src = d.next_send; bytes = sn * 8; break;
         case PCC_F_MIN_LAT: src = d.min_lat; bytes = sn * 8; break;
-        case PCC_F_RING_HEAD: src = d.h2; bytes = sn * 4; break;
-        case PCC_F_RING_MID: src = d.c1; bytes = sn * 4; break;
-        case PCC_F_RING_TAIL: src = d.tail; bytes = sn * 4; break;
+        case PCC_F_ACC_HEAD: src = d.ha; bytes = sn * 4; break;
+        case PCC_F_ACC_TAIL: src = d.ta; bytes = sn * 4; break;
+        case PCC_F_DROP_HEAD: src = d.hd; bytes = sn * 4; break;
+        case PCC_F_DROP_TAIL: src = d.td; bytes = sn * 4; break;
         case PCC_F_EP_RETURN: src = d.ep_return; bytes = sn * 8; break;
         case PCC_F_LAST_RETURN: src = d.last_return; bytes = sn * 8; break;
         case PCC_F_TOTAL_SENT: src = d.total_sent; bytes = n * 8; break;

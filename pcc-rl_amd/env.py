@@ -25,7 +25,7 @@ from .native import PccError, check, lib
 from .spaces import Box
 
 MAX_STEPS = 400          # ns:41
-DEFAULT_RING_CAPACITY = 65536
+DEFAULT_RING_CAPACITY = 32768
 
 _TORCH_DTYPES = {"float64": torch.float64, "int32": torch.int32, "int64": torch.int64}
 

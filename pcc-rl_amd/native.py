@@ -22,8 +22,9 @@ FIELDS = {
     "now": (6, "float64", False), "run_dur": (7, "float64", False), "steps": (8, "int32", False),
     "episode": (9, "int32", False), "flags": (10, "int32", False), "rate": (11, "float64", True),
     "rate0": (12, "float64", True), "next_send": (13, "float64", True), "min_lat": (14, "float64", True),
-    "ring_head": (15, "int32", True), "ring_mid": (16, "int32", True), "ring_tail": (17, "int32", True),
-    "ep_return": (18, "float64", True), "last_return": (19, "float64", True), "total_sent": (20, "int64", False),
+    "acc_head": (15, "int32", True), "acc_tail": (16, "int32", True), "drop_head": (17, "int32", True),
+    "drop_tail": (18, "int32", True), "ep_return": (19, "float64", True), "last_return": (20, "float64", True),
+    "total_sent": (21, "int64", False),
 }
 
 # every symbol include/pcc_sim.h declares

@@ -65,7 +65,7 @@ def test_golden_vectors_bit_exact(name):
     obs0 = env.reset().cpu().numpy()
     assert np.array_equal(obs0, d["obs0"].astype(np.float32))
     assert np.array_equal(env.state("now").cpu().numpy(), d["warm"][:, 0])
-    in_flight = (env.state("ring_tail") - env.state("ring_head"))[0].cpu().numpy()
+    in_flight = (env.state("acc_tail") - env.state("acc_head") + env.state("drop_tail") - env.state("drop_head"))[0].cpu().numpy()
     # heap length after warm-up = packets in flight + the pending SEND
     assert np.array_equal(in_flight + 1, d["warm"][:, 1].astype(np.int64))
     T = d["actions"].shape[1]
@@ -165,8 +165,8 @@ def test_conservation_and_queue_bounds_at_full_size():
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=DEV, seed=0, record_steps=True, auto_reset=False)
     env.reset()
     gen = torch.Generator(device=DEV).manual_seed(0)
-    sent0 = env.state("ring_tail")[0].clone().long()
-    head0 = env.state("ring_head")[0].clone().long()
+    sent0 = (env.state("acc_tail") + env.state("drop_tail"))[0].clone().long()
+    head0 = (env.state("acc_head") + env.state("drop_head"))[0].clone().long()
     acked = torch.zeros(N, dtype=torch.float64, device=DEV)
     sent = torch.zeros_like(acked)
     now_prev = env.state("now").clone()
@@ -182,10 +182,12 @@ def test_conservation_and_queue_bounds_at_full_size():
         assert bool((env.state("queue_delay") <= env.state("maxq")).all())
         assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(r).all())
     env.check_flags()
-    tail, head = env.state("ring_tail")[0].long(), env.state("ring_head")[0].long()
+    tail = (env.state("acc_tail") + env.state("drop_tail"))[0].long()
+    head = (env.state("acc_head") + env.state("drop_head"))[0].long()
     assert bool(((tail - sent0).double() == sent).all())
     assert bool(((head - head0).double() == acked).all())
-    assert bool((tail >= env.state("ring_mid")[0].long()).all()) and bool((env.state("ring_mid")[0].long() >= head).all())
+    assert bool((env.state("acc_tail") >= env.state("acc_head")).all())
+    assert bool((env.state("drop_tail") >= env.state("drop_head")).all())
     env.close()
 
 
