@@ -168,6 +168,17 @@ int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream)
 int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_out, float *reward_out,
              uint8_t *done_out, double *steps_out, int auto_reset, void *stream);
 
+/*
+ * The two halves of pcc_step as separate calls (pcc_step = pcc_step_send + pcc_step_retire with the
+ * same arguments): `send` applies the actions and transmits every packet of the coming monitor
+ * interval (the SEND events of ns:155-178); `retire` processes acknowledgements and losses, closes
+ * the interval and writes the outputs.  Lets a caller overlap its own work with the first half or
+ * time the halves separately (bench.py does).  Each send must be followed by exactly one retire.
+ */
+int pcc_step_send(pcc_sim_t *sim, const void *actions, int actions_f64, void *stream);
+int pcc_step_retire(pcc_sim_t *sim, float *obs_out, float *reward_out, uint8_t *done_out,
+                    double *steps_out, int auto_reset, void *stream);
+
 /* copy one state field into a caller-owned device buffer (see the PCC_F_* table) */
 int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream);
 

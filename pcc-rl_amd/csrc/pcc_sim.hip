@@ -940,6 +940,7 @@ struct pcc_sim {
     bool ever_reset;
     bool lockstep;      // every env was last reset by the same full reset (host knows when `done` fires)
     uint32_t host_steps;
+    bool send_pending;  // pcc_step_send issued, pcc_step_retire not yet
 };
 
 namespace {
@@ -996,23 +997,38 @@ dim3 group_grid(const Dev &d) {
     return dim3((unsigned)((d.n + per_block - 1) / per_block));
 }
 
-// one monitor interval for all envs (warm = 0) or for the envs being reset (warm = 1)
-int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, const void *actions, int actions_f64,
-              float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
+// the SEND half of one monitor interval, for all envs (warm = 0) or the envs being reset (warm = 1)
+int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, const void *actions, int actions_f64, hipStream_t st) {
     const Dev &d = sim->d;
     const bool tr = d.rng_mode == PCC_RNG_TRACE;
     if (d.ns == 1) {
         if (tr) hipLaunchKernelGGL((send_kernel<1, true>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
         else hipLaunchKernelGGL((send_kernel<1, false>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
-        hipLaunchKernelGGL(retire_kernel<1>, group_grid(d), dim3(kRetireBlock), 0, st, d, warm, warm_mi, last_warm,
-                           obs_out, reward_out, done_out, steps_out);
     } else {
         if (tr) hipLaunchKernelGGL((send_kernel<2, true>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
         else hipLaunchKernelGGL((send_kernel<2, false>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+    }
+    return check_hip(hipGetLastError(), "send kernel launch");
+}
+
+// the RETIRE half: acknowledgements, losses, the MI-ending event, metrics and outputs
+int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, float *obs_out, float *reward_out,
+                  uint8_t *done_out, double *steps_out, hipStream_t st) {
+    const Dev &d = sim->d;
+    if (d.ns == 1)
+        hipLaunchKernelGGL(retire_kernel<1>, group_grid(d), dim3(kRetireBlock), 0, st, d, warm, warm_mi, last_warm,
+                           obs_out, reward_out, done_out, steps_out);
+    else
         hipLaunchKernelGGL(retire_kernel<2>, group_grid(d), dim3(kRetireBlock), 0, st, d, warm, warm_mi, last_warm,
                            obs_out, reward_out, done_out, steps_out);
-    }
-    return check_hip(hipGetLastError(), "monitor-interval kernel launch");
+    return check_hip(hipGetLastError(), "retire kernel launch");
+}
+
+int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, const void *actions, int actions_f64,
+              float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
+    const int rc = launch_send(sim, warm, warm_mi, actions, actions_f64, st);
+    if (rc != PCC_OK) return rc;
+    return launch_retire(sim, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out, st);
 }
 
 // reset(): parameters + state, then the two unrecorded warm-up MIs (ns:469-484)
@@ -1173,6 +1189,7 @@ int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream)
     DeviceGuard guard(sim->device);
     const int rc = launch_reset(sim, mask, 0, obs_out, static_cast<hipStream_t>(stream));
     if (rc != PCC_OK) return rc;
+    sim->send_pending = false;
     if (!mask) {
         sim->ever_reset = true;
         sim->lockstep = true;
@@ -1183,15 +1200,26 @@ int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream)
     return PCC_OK;
 }
 
-int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_out, float *reward_out,
-             uint8_t *done_out, double *steps_out, int auto_reset, void *stream) {
+int pcc_step_send(pcc_sim_t *sim, const void *actions, int actions_f64, void *stream) {
     if (!sim || !actions) return fail(PCC_EINVAL, "NULL argument");
     if (!sim->ever_reset) return fail(PCC_ESTATE, "pcc_step before pcc_reset (the reference raises TypeError: run_dur is None)");
+    if (sim->send_pending) return fail(PCC_ESTATE, "pcc_step_send called twice without pcc_step_retire");
+    DeviceGuard guard(sim->device);
+    const int rc = launch_send(sim, 0, 0, actions, actions_f64, static_cast<hipStream_t>(stream));
+    if (rc == PCC_OK) sim->send_pending = true;
+    return rc;
+}
+
+int pcc_step_retire(pcc_sim_t *sim, float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out,
+                    int auto_reset, void *stream) {
+    if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    if (!sim->send_pending) return fail(PCC_ESTATE, "pcc_step_retire without a preceding pcc_step_send");
     DeviceGuard guard(sim->device);
     const Dev &d = sim->d;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = launch_mi(sim, 0, 0, 0, actions, actions_f64, obs_out, reward_out, done_out, steps_out, st);
+    int rc = launch_retire(sim, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
+    sim->send_pending = false;
     sim->host_steps++;
     if (auto_reset) {
         // when every env is in lockstep the host knows which step finishes the episode and
@@ -1206,6 +1234,13 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
         sim->lockstep = false;  // caller resets on its own schedule from here on
     }
     return PCC_OK;
+}
+
+int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_out, float *reward_out,
+             uint8_t *done_out, double *steps_out, int auto_reset, void *stream) {
+    const int rc = pcc_step_send(sim, actions, actions_f64, stream);
+    if (rc != PCC_OK) return rc;
+    return pcc_step_retire(sim, obs_out, reward_out, done_out, steps_out, auto_reset, stream);
 }
 
 int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {

@@ -179,7 +179,7 @@ class BatchedNetworkEnv(object):
         self._was_reset = True
         return self._out(self._obs)
 
-    def step(self, actions):
+    def _actions(self, actions):
         a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions), device=self.device)
         if a.device != self.device:
             a = a.to(self.device)
@@ -188,14 +188,25 @@ class BatchedNetworkEnv(object):
         if a.numel() != self.n_envs * self.n_senders:
             raise ValueError("actions has %d elements, expected n_envs*n_senders = %d"
                              % (a.numel(), self.n_envs * self.n_senders))
-        a = a.reshape(self.n_envs, self.n_senders).contiguous()
-        check(self._L.pcc_step(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, _ptr(self._obs),
-                               _ptr(self._reward), _ptr(self._done), _ptr(self._steps),
-                               1 if self.auto_reset else 0, self._stream()))
+        return a.reshape(self.n_envs, self.n_senders).contiguous()
+
+    def step_send(self, actions):
+        """First half of step(): apply the actions and transmit the coming monitor interval's packets."""
+        a = self._actions(actions)
+        check(self._L.pcc_step_send(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, self._stream()))
+
+    def step_retire(self):
+        """Second half of step(): acknowledgements, losses, metrics; returns what step() returns."""
+        check(self._L.pcc_step_retire(self._h, _ptr(self._obs), _ptr(self._reward), _ptr(self._done),
+                                      _ptr(self._steps), 1 if self.auto_reset else 0, self._stream()))
         info = {}
         if self._steps is not None:
             info["steps"] = self._out(self._steps)
         return self._out(self._obs), self._out(self._reward), self._done.view(torch.bool), info
+
+    def step(self, actions):
+        self.step_send(actions)
+        return self.step_retire()
 
     # ------------------------------------------------------------------ introspection
     def state(self, name):

@@ -29,7 +29,8 @@ FIELDS = {
 
 # every symbol include/pcc_sim.h declares
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
-           "pcc_set_rng", "pcc_set_seed", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step",
+           "pcc_set_rng", "pcc_set_seed", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
+           "pcc_step_retire",
            "pcc_get_state", "pcc_metric_info", "pcc_device_bytes"]
 
 
@@ -69,13 +70,15 @@ def lib():
     L.pcc_set_max_steps.argtypes = [vp, i32]
     L.pcc_reset.argtypes = [vp, vp, vp, vp]
     L.pcc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
+    L.pcc_step_send.argtypes = [vp, vp, i32, vp]
+    L.pcc_step_retire.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     L.pcc_get_state.argtypes = [vp, i32, vp, vp]
     L.pcc_metric_info.argtypes = [i32, ctypes.POINTER(dbl), ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     L.pcc_device_bytes.restype = i64
     L.pcc_device_bytes.argtypes = [vp]
     for fn in ("pcc_create", "pcc_set_link_params", "pcc_set_param_ranges", "pcc_set_rng", "pcc_set_seed",
-               "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_get_state",
-               "pcc_metric_info"):
+               "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
+               "pcc_step_retire", "pcc_get_state", "pcc_metric_info"):
         getattr(L, fn).restype = i32
     _lib = L
     return L
