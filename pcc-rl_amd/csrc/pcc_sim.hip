@@ -188,33 +188,172 @@ __device__ __forceinline__ double2 *ring_of(const Dev &D, int64_t i, int s, int 
 }
 
 // ======================================================================================
-// send_kernel: one lane per env.  apply_rate_delta (ns:235-241, 275-281) + every SEND event
-// with time < end of the coming MI (ns:155-178).
+// send_kernel: apply_rate_delta (ns:235-241, 275-281) + every SEND event with time < end of the
+// coming MI (ns:155-178).  One lane per env for the serial recurrence; envs with many packets in
+// the MI ("heavy": deep queue, overloaded) are then processed one at a time by the whole wave,
+// 64 packets per pass (heavy_mi below).
 // ======================================================================================
+constexpr double kHeavyPackets = 512.0;  // predicted packets in the MI above which the wave path is used
+
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ double rl_f64(double v, uint32_t l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), (int)l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), (int)l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint64_t rl_u64(uint64_t v, uint32_t l) {
+    const uint32_t lo = rl_u32((uint32_t)v, l), hi = rl_u32((uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t exponent_bits(double x) { return ((uint32_t)__double2hiint(x) >> 20) & 0x7FFu; }
+
+struct SendState {  // wave-uniform while an env is processed by the whole wave
+    double q, tu, t;
+    uint32_t a, d, sent, flags;
+};
+
+// One monitor interval of SENDs for ONE env by all 64 lanes (NS = 1).  Exact, not approximate:
+//   * inside one binade, t_{k+1} = fl(t_k + gap) advances by a constant G = t_1 - t_0 (an exact
+//     multiple of ulp(t)), so lane k owns send time t_0 + k*G -- checked each pass (two equal
+//     increments, t_0 >= 128*gap so k*G is exact, no binade crossing within the pass);
+//   * once ulp(t) >= ulp(q) (t, tu >= maxq) the drain q - (t_k - tu) is exact, so between two
+//     accepted packets the queue seen by packet k is max(0, q_m - (t_k - t_m)) whatever the
+//     tail drops / random losses in between (they leave exactly that state behind), and the
+//     tail-drop test is monotone in k.  The only serial dependence left is from one ACCEPTED
+//     packet to the next: under overload that is ~1 in rate/bw packets;
+//   * a pass whose preconditions fail sends one packet with the serial recurrence instead.
+// Records leave as two dense runs (accepted / dropped) -> coalesced stores.
+template <bool TRACE>
+__device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl, double lr, uint32_t thr, bool always,
+                                         double maxq, double ebw, double gap, double end, uint32_t episode,
+                                         uint32_t mi, uint32_t gid, const double *trace, char *base, SendState &st) {
+    const uint32_t mask_b = D.cap_mask << 4, dmask_b = D.dcap_mask << 4, cap_b = D.cap << 4;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    // the accept-to-accept pass pays off when most packets are dropped (rate well above bw)
+    const bool drop_dominated = gap < 0.45 * ebw;
+    while (st.t < end) {
+        const double t0 = st.t;
+        // ---- loss decisions of the next 64 packets, one per lane
+        bool rnd;
+        if (TRACE) {
+            const uint64_t pos = (uint64_t)st.a + st.d + lane;
+            double u = 1.0;
+            if ((int64_t)pos < D.trace_stride) u = trace[pos];
+            rnd = u < lr;
+        } else {
+            const uint32_t j = st.sent + lane;
+            uint32_t w[4];
+            philox4x32_10(j >> 2, mi, episode, gid, D.key0, D.key1, w);
+            const uint32_t x = (j & 3u) == 0 ? w[0] : (j & 3u) == 1 ? w[1] : (j & 3u) == 2 ? w[2] : w[3];
+            rnd = always || x < thr;
+        }
+        const uint64_t rmask = __ballot(rnd);
+
+        const double t1s = t0 + gap;
+        const double G = t1s - t0;
+        const double t2s = t1s + gap;
+        const double tend = t0 + 64.0 * G;
+        const bool ok = drop_dominated && (t2s - t1s == G) && (t0 >= 128.0 * gap) &&
+                        (exponent_bits(t0) == exponent_bits(tend)) && (st.tu >= maxq) && (st.tu + st.tu >= tend) &&
+                        (G > 0.0);
+        double my_t = 0.0, my_lat = 0.0;
+        bool my_drop = true;
+        uint32_t nv;
+        if (!ok) {
+            // ---- serial pass: up to 64 packets with the plain recurrence, wave-uniform (every lane
+            // computes the same values; lane k keeps packet k's record), exact with no precondition
+            double t = t0;
+            uint32_t k = 0;
+            for (; k < 64u && t < end; k++) {
+                bool dropped;
+                const double2 rec = link_send(t, (rmask >> k) & 1ull, dl, maxq, ebw, st.q, st.tu, dropped);
+                if (lane == k) { my_t = rec.x; my_lat = rec.y; my_drop = dropped; }
+                t += gap;  // ns:161
+            }
+            nv = k;
+            st.t = t;
+        } else {
+            // ---- accept-to-accept pass over 64 packets
+            const double tk = t0 + (double)lane * G;
+            const bool valid = tk < end;
+            const uint64_t vmask = __ballot(valid);
+            nv = (uint32_t)__popcll(vmask);  // valid lanes are a prefix (tk increases)
+            double qm = st.q, tm = st.tu;
+            uint32_t done = 0;  // lanes [0, done) are final
+            double my_q_after = 0.0;
+            for (;;) {
+                const double qc = max0(qm - (tk - tm));  // queue seen by packet k if nothing was accepted since m
+                const double s = ebw + qc;
+                const bool full = s > maxq;              // monotone non-increasing in k
+                const bool open = valid && lane >= done;
+                const uint64_t cm = __ballot(open && !rnd && !full);
+                const uint32_t ks = cm ? (uint32_t)__ffsll((unsigned long long)cm) - 1u : 64u;  // next accepted
+                if (open && lane <= ks) {
+                    my_lat = dl + qc;                    // ns:170
+                    my_drop = lane != ks;
+                    my_q_after = my_drop ? qc : s;       // link state this packet leaves unless it is a random loss
+                }
+                if (ks >= 64u) break;
+                qm = rl_f64(s, ks);                      // ns:82
+                tm = rl_f64(tk, ks);                     // ns:76
+                done = ks + 1u;
+            }
+            my_t = tk + my_lat;                          // ns:174
+            // link state after the pass = what the last packet that was not a random loss left (ns:75-82)
+            const uint64_t touch = vmask & ~rmask;
+            if (touch) {
+                const uint32_t kl = 63u - (uint32_t)__clzll((long long)touch);
+                st.q = rl_f64(my_q_after, kl);
+                st.tu = rl_f64(tk, kl);
+            }
+            st.t = t0 + (double)nv * G;                  // exact: the (nv)-th send time
+        }
+        // ---- the pass's records leave as two dense runs: coalesced stores
+        const bool valid = lane < nv;
+        if (TRACE && (int64_t)((uint64_t)st.a + st.d + nv) > D.trace_stride) st.flags |= PCC_FLAG_TRACE_OVERRUN;
+        const uint64_t dm = __ballot(valid && my_drop), am = __ballot(valid && !my_drop);
+        if (valid) {
+            double2 rec;
+            rec.x = my_t;
+            rec.y = my_lat;
+            const uint32_t off = my_drop ? cap_b + (((st.d + (uint32_t)__popcll(dm & lt)) << 4) & dmask_b)
+                                         : (((st.a + (uint32_t)__popcll(am & lt)) << 4) & mask_b);
+            *reinterpret_cast<double2 *>(base + off) = rec;
+        }
+        st.a += (uint32_t)__popcll(am);
+        st.d += (uint32_t)__popcll(dm);
+        st.sent += nv;
+    }
+}
+
 template <int NS, bool TRACE>
 __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t warm_mi, const void *actions,
                                                      int actions_f64) {
     const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
-    if (i >= D.n) return;
-    if (warm && !D.resetting[i]) return;
+    const uint32_t lane = threadIdx.x;
+    // lanes without an env stay in the kernel: the heavy path needs all 64 lanes as workers
+    const bool live = i < D.n && !(warm && !D.resetting[i < D.n ? i : 0]);
+    const int64_t ii = live ? i : 0;
 
-    const double dl = D.dl[i], lr = D.lr[i], maxq = D.maxq[i], ebw = D.ebw[i];
-    double q = D.q[i], tu = D.tu[i];
-    const double now = D.now[i];
-    const double end = now + D.run_dur[i];  // ns:124
-    const uint32_t episode = D.episode[i] - 1;
-    const uint32_t mi = warm ? warm_mi : D.steps[i] + 2;
-    const uint32_t gid = D.gid_base + (uint32_t)i;
+    const double dl = D.dl[ii], lr = D.lr[ii], maxq = D.maxq[ii], ebw = D.ebw[ii];
+    double q = D.q[ii], tu = D.tu[ii];
+    const double now = D.now[ii];
+    const double end = now + D.run_dur[ii];  // ns:124
+    const uint32_t episode = D.episode[ii] - 1;
+    const uint32_t mi = warm ? warm_mi : D.steps[ii] + 2;
+    const uint32_t gid = D.gid_base + (uint32_t)ii;
     uint32_t flags = 0;
 
     double gap[NS], nsend[NS];
     uint32_t ta[NS], td[NS], ha[NS], hd[NS], sent[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + i;
+        const int64_t k = (int64_t)s * D.n + ii;
         double rate = D.rate[k];
-        if (!warm) {
-            const int64_t a = i * NS + s;
+        if (!warm && live) {
+            const int64_t a = ii * NS + s;
             double delta = actions_f64 ? ((const double *)actions)[a] : (double)((const float *)actions)[a];
             delta *= D.delta_scale;
             rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
@@ -228,43 +367,98 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
         ha[s] = D.ha[k]; hd[s] = D.hd[k];
         sent[s] = 0;
     }
-    const double *trace = TRACE ? D.trace + i * D.trace_stride : nullptr;
+    const double *trace = TRACE ? D.trace + ii * D.trace_stride : nullptr;
     const uint32_t mask_b = D.cap_mask << 4, dmask_b = D.dcap_mask << 4, cap_b = D.cap << 4;
+    const bool run = live && now < end;
 
-    if (NS == 1 && !TRACE) {
-        // Hot loop of the whole simulator: one sender, Philox uniforms.  Four packets per Philox
-        // block, no loads, no data-dependent branches besides the loop exits.
-        // u32_to_unit(x) < lr  <=>  x < ceil(lr * 2^32) for integer x (the scaling is exact).
+    if (NS == 1) {
+        // u32_to_unit(x) < lr  <=>  x < ceil(lr * 2^32) for integer x (the scaling is exact)
         const double thr_d = ceil(lr * 4294967296.0);
         const bool always = thr_d >= 4294967296.0;
         const uint32_t thr = always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
+        char *base = reinterpret_cast<char *>(ring_of<NS>(D, ii, 0, 0));
+        // heavy = many packets ahead, most of them drops (rate well above bw), and the wave path's
+        // standing preconditions hold; everything else stays in the lane-serial loop
+        const bool heavy = run && (end - nsend[0]) > kHeavyPackets * gap[0] && gap[0] < 0.45 * ebw && tu >= maxq &&
+                           nsend[0] >= 128.0 * gap[0];
         double t = nsend[0];
         uint32_t a = ta[0], d = td[0];
-        uint32_t blk = 0;
-        char *base = reinterpret_cast<char *>(ring_of<NS>(D, i, 0, 0));
-        if (now < end) {
-            while (t < end) {
-                uint32_t w[4];
-                philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
-                blk++;
+        if (run && !heavy) {
+            if (!TRACE) {
+                // serial hot loop: four packets per Philox block, no loads, no data-dependent branches.
+                // The first `safe` packets are certainly before `end` (t advances by gap up to
+                // rounding; two packets of margin), so whole blocks of four run without the fp64
+                // exit test; the remainder is sent with the test after every packet.
+                uint32_t blk = 0;
+                const double ahead = (end - t) / gap[0] - 2.0;
+                uint32_t safe4 = ahead >= 4.0 ? (uint32_t)fmin(ahead, 1073741824.0) >> 2 : 0u;
+                for (; safe4; safe4--) {
+                    uint32_t w[4];
+                    philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                    blk++;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (k > 0 && !(t < end)) break;
+                    for (int k = 0; k < 4; k++) {
+                        bool dropped;
+                        const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
+                        const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
+                        *reinterpret_cast<double2 *>(base + off) = rec;
+                        a += dropped ? 0u : 1u;
+                        d += dropped ? 1u : 0u;
+                        t += gap[0];  // ns:161
+                    }
+                }
+                while (t < end) {
+                    uint32_t w[4];
+                    philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                    blk++;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (k > 0 && !(t < end)) break;
+                        bool dropped;
+                        const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
+                        const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
+                        *reinterpret_cast<double2 *>(base + off) = rec;
+                        a += dropped ? 0u : 1u;
+                        d += dropped ? 1u : 0u;
+                        t += gap[0];  // ns:161
+                    }
+                }
+            } else {
+                while (t < end) {
+                    const uint64_t pos = (uint64_t)a + d;
+                    double u = 1.0;
+                    if ((int64_t)pos >= D.trace_stride) flags |= PCC_FLAG_TRACE_OVERRUN;
+                    else u = trace[pos];
                     bool dropped;
-                    const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
+                    const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
                     const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
                     *reinterpret_cast<double2 *>(base + off) = rec;
                     a += dropped ? 0u : 1u;
                     d += dropped ? 1u : 0u;
-                    t += gap[0];  // ns:161
+                    t += gap[0];
                 }
             }
+        }
+        // heavy envs of this wave, one after the other, 64 lanes each
+        uint64_t hm = __ballot(heavy);
+        while (hm) {
+            const uint32_t l = (uint32_t)__ffsll((unsigned long long)hm) - 1u;
+            hm &= hm - 1ull;
+            SendState st;
+            st.q = rl_f64(q, l); st.tu = rl_f64(tu, l); st.t = rl_f64(t, l);
+            st.a = rl_u32(a, l); st.d = rl_u32(d, l); st.sent = 0; st.flags = 0;
+            heavy_mi<TRACE>(D, lane, rl_f64(dl, l), rl_f64(lr, l), rl_u32(thr, l), rl_u32(always ? 1u : 0u, l) != 0u,
+                            rl_f64(maxq, l), rl_f64(ebw, l), rl_f64(gap[0], l), rl_f64(end, l), rl_u32(episode, l),
+                            rl_u32(mi, l), rl_u32(gid, l),
+                            reinterpret_cast<const double *>(rl_u64(reinterpret_cast<uint64_t>(trace), l)),
+                            reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(base), l)), st);
+            if (lane == l) { q = st.q; tu = st.tu; t = st.t; a = st.a; d = st.d; flags |= st.flags; }
         }
         nsend[0] = t;
         sent[0] = (a - ta[0]) + (d - td[0]);
         ta[0] = a; td[0] = d;
-    } else if (now < end) {
-        // general loop: two senders merged in (time, sender id) order, or replayed loss uniforms
+    } else if (run) {
+        // two senders merged in (time, sender id) order
         uint32_t w[NS][4];
         for (;;) {
             int s = 0;
@@ -291,7 +485,7 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
                 nsend[ss] = t + gap[ss];          // ns:161
                 bool dropped;
                 const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
-                char *base = reinterpret_cast<char *>(ring_of<NS>(D, i, ss, 0));
+                char *base = reinterpret_cast<char *>(ring_of<NS>(D, ii, ss, 0));
                 const uint32_t off = dropped ? cap_b + ((td[ss] << 4) & dmask_b) : ((ta[ss] << 4) & mask_b);
                 *reinterpret_cast<double2 *>(base + off) = rec;
                 ta[ss] += dropped ? 0u : 1u;
@@ -300,6 +494,7 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
         }
     }
 
+    if (!live) return;
     D.q[i] = q; D.tu[i] = tu;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
