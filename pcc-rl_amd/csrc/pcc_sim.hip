@@ -31,9 +31,9 @@
 //   send_kernel    one lane per env: apply the action, run the SEND recurrence up to the MI end,
 //                  append records (no loads in the loop).
 //   retire_kernel  16 lanes per env: 16-ary searches of the rings for the hop-2 / hop-1
-//                  boundaries, the MI-ending event, RTT sums through an LDS-staged stream with
-//                  numpy's pairwise tree laid over 8-lane groups, metrics, history,
-//                  observation, reward, done.
+//                  boundaries (all four advanced together), the MI-ending event, RTT sums as
+//                  numpy's pairwise tree with each 128-sample leaf loaded in one round trip by
+//                  an 8-lane subgroup, metrics, history, observation, reward, done.
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
@@ -41,6 +41,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -53,8 +54,6 @@ constexpr int kMaxSenders = 2;
 constexpr int kWave = 64;
 constexpr int kGroup = 16;            // lanes per env in retire_kernel
 constexpr int kRetireBlock = 256;     // 16 envs per workgroup
-constexpr int kStage = 64;            // LDS-staged RTT samples per env (doubles)
-constexpr int kScanDepth = 4;         // 16-record chunks requested ahead in the ring scans
 constexpr double kMaxRate = 1000.0;      // ns:36
 constexpr double kMinRate = 40.0;        // ns:37
 constexpr double kRewardScale = 0.001;   // ns:39
@@ -88,6 +87,8 @@ struct Dev {
     uint32_t key0, key1, gid_base;
     double delta_scale;
     uint32_t max_steps;
+    int debug_skip;  // profiling only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs
+    double heavy_packets, heavy_rho;  // tuning: when the send kernel hands an env to the wave path
     double lo[5], hi[5];
     int rng_mode;
     const double *trace;
@@ -193,7 +194,6 @@ __device__ __forceinline__ double2 *ring_of(const Dev &D, int64_t i, int s, int 
 // the MI ("heavy": deep queue, overloaded) are then processed one at a time by the whole wave,
 // 64 packets per pass (heavy_mi below).
 // ======================================================================================
-constexpr double kHeavyPackets = 512.0;  // predicted packets in the MI above which the wave path is used
 
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
@@ -232,7 +232,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
     const uint32_t mask_b = D.cap_mask << 4, dmask_b = D.dcap_mask << 4, cap_b = D.cap << 4;
     const uint64_t lt = (1ull << lane) - 1ull;
     // the accept-to-accept pass pays off when most packets are dropped (rate well above bw)
-    const bool drop_dominated = gap < 0.45 * ebw;
+    const bool drop_dominated = gap < D.heavy_rho * ebw;
     while (st.t < end) {
         const double t0 = st.t;
         // ---- loss decisions of the next 64 packets, one per lane
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
         char *base = reinterpret_cast<char *>(ring_of<NS>(D, ii, 0, 0));
         // heavy = many packets ahead, most of them drops (rate well above bw), and the wave path's
         // standing preconditions hold; everything else stays in the lane-serial loop
-        const bool heavy = run && (end - nsend[0]) > kHeavyPackets * gap[0] && gap[0] < 0.45 * ebw && tu >= maxq &&
+        const bool heavy = run && (end - nsend[0]) > D.heavy_packets * gap[0] && gap[0] < D.heavy_rho * ebw && tu >= maxq &&
                            nsend[0] >= 128.0 * gap[0];
         double t = nsend[0];
         uint32_t a = ta[0], d = td[0];
@@ -549,6 +549,90 @@ __device__ __forceinline__ uint32_t search_boundary(const Group &g, const double
     return m ? lo + (uint32_t)__ffs((int)m) - 1u : hi;
 }
 
+// K boundary searches advanced together, so their dependent loads overlap: per round every search
+// still running samples its 16 sub-range ends; the last step loads the 16 records
+// [lo - 2, lo + 14) around each transition, which also tells whether the records next to the
+// transition are "near" (within rounding distance) -- if not, the transition is exact as found and
+// ring[b] is already in a register.
+struct Bound {
+    uint32_t b;      // first index failing `t1 + add < end` (== hi if none)
+    bool clean;      // no near-equal neighbours around b-1, b: no event-order repair needed
+    double t, lat;   // ring[b] (valid when b < hi0)
+};
+
+template <int K>
+__device__ __forceinline__ void search_many(const Group &g, const double2 *const (&ring)[K], const uint32_t (&mask)[K],
+                                            const uint32_t (&lo0)[K], const uint32_t (&hi0)[K], const double (&add)[K],
+                                            double end, Bound (&out)[K]) {
+    uint32_t lo[K], hi[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { lo[k] = lo0[k]; hi[k] = hi0[k]; }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) any |= (hi[k] - lo[k] > 12u);
+        if (!any) break;
+        double tsamp[K];
+        uint32_t sidx[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t stride = (hi[k] - lo[k] + kGroup - 1) / kGroup;
+            uint32_t x = lo[k] + (g.lane + 1) * stride;
+            if (x > hi[k]) x = hi[k];
+            sidx[k] = x - 1;
+            tsamp[k] = 0.0;
+            if (hi[k] - lo[k] > 12u) tsamp[k] = ring[k][sidx[k] & mask[k]].x;
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (hi[k] - lo[k] > 12u) {
+                const uint32_t mfail = ~gballot(g, tsamp[k] + add[k] < end) & 0xFFFFu;
+                if (!mfail) {
+                    lo[k] = hi[k];  // the last sample is record hi-1: everything passes
+                } else {
+                    const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
+                    const uint32_t s_f = gbcast(sidx[k], f);
+                    if (f) lo[k] = gbcast(sidx[k], f - 1) + 1;
+                    hi[k] = s_f < lo[k] ? lo[k] : s_f;
+                }
+            }
+        }
+    }
+    // final step: lane l looks at record base + l, base = lo - 2 (clamped to the ring's start)
+    double2 r[K];
+    uint32_t base[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        base[k] = lo[k] - lo0[k] >= 2u ? lo[k] - 2u : lo0[k];
+        const uint32_t idx = base[k] + g.lane;
+        r[k].x = 0.0; r[k].y = 0.0;
+        if (idx < hi0[k]) r[k] = ring[k][idx & mask[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t idx = base[k] + g.lane;
+        const bool in = idx < hi0[k];
+        const bool fail = in && idx >= lo[k] && idx < hi[k] && !(r[k].x + add[k] < end);
+        const uint32_t m = gballot(g, fail);
+        const uint32_t b = m ? base[k] + (uint32_t)__ffs((int)m) - 1u : hi[k];
+        // near flag of lane l: records idx and idx+1 both exist and are within rounding distance
+        const double tn = __shfl_down(r[k].x, 1, kGroup);
+        const bool nr = in && (idx + 1 < hi0[k]) && g.lane + 1 < kGroup && near_time(r[k].x, tn);
+        const uint32_t mnear = gballot(g, nr);
+        // pairs that matter: (b-2,b-1), (b-1,b), (b,b+1) -> lanes (b-2-base), (b-1-base), (b-base)
+        uint32_t want = 0;
+        for (int d = 0; d < 3; d++) {
+            const int l = (int)(b - base[k]) - 2 + d;
+            if (l >= 0 && l < kGroup) want |= 1u << l;
+        }
+        out[k].b = b;
+        out[k].clean = (mnear & want) == 0u;
+        const uint32_t lb = b - base[k];
+        out[k].t = gbcast(r[k].x, lb < (uint32_t)kGroup ? lb : 0u);
+        out[k].lat = gbcast(r[k].y, lb < (uint32_t)kGroup ? lb : 0u);
+    }
+}
+
 // ---- serial paths on the dropped ring (one lane) -----------------------------------------
 
 // move ring[k] in front of ring[p] (p <= k), keeping the order of the records in between
@@ -633,162 +717,113 @@ __device__ __noinline__ void drop_hop1_candidate(const double2 *ring, uint32_t m
 }
 
 // --------------------------------------------------------------------------------------
-// numpy-exact np.mean pieces.  np.add.reduce splits the samples into 8192-element chunks
-// summed left to right; each chunk is DOUBLE_pairwise_sum: split n -> (n/2 rounded down to a
-// multiple of 8, rest) until <= 128, a leaf keeps 8 strided accumulators r[j] += a[8b + j],
-// folds them ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds the < 8 leftover samples one by one.
-// Every leaf but the last of a chunk is a multiple of 8 long, so a walker consumes its sequence
-// in aligned blocks of 8: lane j of an 8-lane subgroup owns r[j].
+// numpy-exact np.mean pieces.  np.add.reduce splits the samples into 8192-element chunks summed
+// left to right; each chunk is DOUBLE_pairwise_sum: split n -> (n/2 rounded down to a multiple of
+// 8, rest) until <= 128; a leaf keeps 8 strided accumulators r[j] += a[8b + j], folds them
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds the < 8 leftover samples one by one.
+// The RTT samples of an MI are a contiguous slice of the accepted ring (sample = lat0 + dl), so a
+// leaf is random access: an 8-lane subgroup loads its <= 16 strided samples per lane in one
+// round trip (lane j owns r[j]) and folds with __shfl_xor.
 // --------------------------------------------------------------------------------------
-struct Walker {
-    uint32_t base;       // stream index of this sequence's first sample
-    uint32_t consumed;   // samples consumed so far
-    uint32_t remaining;  // samples not yet assigned to a chunk
-    uint32_t nblk, blk, rem;  // current leaf: full blocks, blocks done, leftover samples
-    uint32_t right_n[6];
-    double left_sum[6];
-    uint32_t have_left;
-    int sp;
-    double r, tot;
-    bool done;
-};
-
-__device__ __forceinline__ void walker_descend(Walker &w, uint32_t cur) {
-    while (cur > 128) {
-        uint32_t n2 = cur / 2;
-        n2 -= n2 % 8;
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-            if (k == w.sp) w.right_n[k] = cur - n2;
-        w.have_left &= ~(1u << w.sp);
-        w.sp++;
-        cur = n2;
+__device__ __forceinline__ double leaf_sum(const double2 *ring, uint32_t mask, uint32_t beg, uint32_t len, double dl,
+                                           uint32_t sl) {
+    if (len < 8) {
+        double res = 0.;
+        for (uint32_t e = 0; e < len; e++) res += ring[(beg + e) & mask].y + dl;
+        return res;
     }
-    w.nblk = cur / 8;
-    w.rem = cur % 8;
-    w.blk = 0;
-}
-
-__device__ __forceinline__ void walker_start_chunk(Walker &w) {
-    const uint32_t m = w.remaining < kNpBufsize ? w.remaining : kNpBufsize;
-    w.remaining -= m;
-    w.sp = 0;
-    w.have_left = 0;
-    walker_descend(w, m);
-}
-
-__device__ __forceinline__ void walker_begin(Walker &w, uint32_t base, uint32_t n) {
-    w.base = base;
-    w.consumed = 0;
-    w.remaining = n;
-    w.tot = 0.0;
-    w.r = 0.0;
-    w.done = (n == 0);
-    w.nblk = w.blk = w.rem = 0;
-    w.sp = 0;
-    w.have_left = 0;
-    if (n) walker_start_chunk(w);
-}
-
-// consume whatever the stage holds for this walker; `produced` = samples staged so far.
-// sl = lane inside the 8-lane subgroup.
-__device__ __forceinline__ void walker_drain(Walker &w, const double *stage, uint32_t produced, uint32_t sl) {
-    while (!w.done) {
-        const uint32_t pos = w.base + w.consumed;
-        const uint32_t avail = produced > pos ? produced - pos : 0u;
-        if (w.blk < w.nblk) {
-            if (avail < 8) return;
-            const double v = stage[(pos + sl) & (kStage - 1)];
-            w.r = (w.blk == 0) ? v : w.r + v;
-            w.blk++;
-            w.consumed += 8;
-            continue;
-        }
-        if (avail < w.rem) return;
-        double val = 0.;
-        if (w.nblk > 0) {
-            double x = w.r;
-            x = x + __shfl_xor(x, 1, 8);
-            x = x + __shfl_xor(x, 2, 8);
-            x = x + __shfl_xor(x, 4, 8);
-            val = x;
-        }
-        for (uint32_t e = 0; e < w.rem; e++) val += stage[(pos + e) & (kStage - 1)];
-        w.consumed += w.rem;
-        // unwind the recursion: the leaf just finished is a left or a right child
-        bool descended = false;
-        while (w.sp > 0) {
-            const int top = w.sp - 1;
-            if (!(w.have_left & (1u << top))) {
-                uint32_t rn = 0;
+    const uint32_t nblk = len / 8;  // <= 16
+    double v[16];
 #pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    if (k == top) { w.left_sum[k] = val; rn = w.right_n[k]; }
-                }
-                w.have_left |= 1u << top;
-                walker_descend(w, rn);
-                descended = true;
+    for (int b = 0; b < 16; b++) {
+        v[b] = 0.0;
+        if ((uint32_t)b < nblk) v[b] = ring[(beg + 8u * b + sl) & mask].y;
+    }
+    double tail[7];
+#pragma unroll
+    for (int e = 0; e < 7; e++) {
+        tail[e] = 0.0;
+        if (8u * nblk + e < len) tail[e] = ring[(beg + 8u * nblk + e) & mask].y;
+    }
+    double r = v[0] + dl;
+#pragma unroll
+    for (int b = 1; b < 16; b++)
+        if ((uint32_t)b < nblk) r += v[b] + dl;
+    double x = r;
+    x = x + __shfl_xor(x, 1, 8);
+    x = x + __shfl_xor(x, 2, 8);
+    x = x + __shfl_xor(x, 4, 8);
+#pragma unroll
+    for (int e = 0; e < 7; e++)
+        if (8u * nblk + e < len) x += tail[e] + dl;
+    return x;
+}
+
+// DOUBLE_pairwise_sum of n <= 8192 samples starting at ring index beg: the recursion walked
+// left to right with an explicit stack (depth <= 6)
+__device__ __forceinline__ double pairwise_sum(const double2 *ring, uint32_t mask, uint32_t beg, uint32_t n, double dl,
+                                               uint32_t sl) {
+    uint32_t right_n[8];
+    double left_sum[8];
+    uint32_t have_left = 0;
+    int sp = 0;
+    uint32_t cur = n, pos = beg;
+    for (;;) {
+        while (cur > 128) {
+            uint32_t n2 = cur / 2;
+            n2 -= n2 % 8;
+            right_n[sp] = cur - n2;
+            have_left &= ~(1u << sp);
+            sp++;
+            cur = n2;
+        }
+        double val = leaf_sum(ring, mask, pos, cur, dl, sl);
+        pos += cur;
+        bool descend = false;
+        while (sp > 0) {
+            const int top = sp - 1;
+            if (!(have_left & (1u << top))) {
+                left_sum[top] = val;
+                have_left |= 1u << top;
+                cur = right_n[top];
+                descend = true;
                 break;
             }
-            double ls = 0.;
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-                if (k == top) ls = w.left_sum[k];
-            val = ls + val;
-            w.sp--;
+            val = left_sum[top] + val;
+            sp--;
         }
-        if (descended) continue;
-        w.tot += val;  // chunk complete
-        if (w.remaining) walker_start_chunk(w);
-        else w.done = true;
+        if (!descend) return val;
     }
+}
+
+__device__ __forceinline__ double np_sum(const double2 *ring, uint32_t mask, uint32_t beg, uint32_t n, double dl,
+                                         uint32_t sl) {
+    if (n <= 128) return leaf_sum(ring, mask, beg, n, dl, sl);  // the common case, no stack
+    double tot = 0.;
+    for (uint32_t i = 0; i < n; i += kNpBufsize) {
+        const uint32_t m = n - i < kNpBufsize ? n - i : kNpBufsize;
+        tot += pairwise_sum(ring, mask, beg + i, m, dl, sl);
+    }
+    return tot;
 }
 
 // Means over the RTTs (= forward latency + dl) of the n > 0 acknowledged packets
-// ring[from, from + n) of the accepted ring: the whole list (so:119-122) and, when asked,
-// mean(second half) - mean(first half) (so:138-142).
+// ring[from, from + n) of the accepted ring: the whole list (so:119-122) by lanes 0-7 and, when
+// asked, mean(second half) - mean(first half) (so:138-142) by lanes 8-15.
 __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, uint32_t mask, uint32_t from,
-                                          uint32_t n, double dl, bool need_halves, double *stage, double &mean_all,
+                                          uint32_t n, double dl, bool need_halves, double &mean_all,
                                           double &lat_inc) {
     const uint32_t sub = g.lane >> 3, sl = g.lane & 7u;
     const uint32_t half = n / 2;
-    Walker w;
-    bool second = false;
-    if (sub == 0) walker_begin(w, 0, n);
-    else walker_begin(w, 0, (need_halves && half >= 1) ? half : 0);
-    double first_mean = 0.0;
-    for (uint32_t i = 0; i < n; i += kScanDepth * kGroup) {
-        double lat[kScanDepth];
-#pragma unroll
-        for (int c = 0; c < kScanDepth; c++) {
-            const uint32_t k = i + c * kGroup + g.lane;
-            lat[c] = 0.0;
-            if (k < n) lat[c] = ring[(from + k) & mask].y;
-        }
-#pragma unroll
-        for (int c = 0; c < kScanDepth; c++) {
-            const uint32_t i0 = i + c * kGroup;
-            if (i0 >= n) break;
-            if (i0 + g.lane < n) stage[(i0 + g.lane) & (kStage - 1)] = lat[c] + dl;
-            const uint32_t produced = (i0 + kGroup < n) ? i0 + kGroup : n;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            walker_drain(w, stage, produced, sl);
-            if (sub == 1 && w.done && !second && need_halves && half >= 1) {
-                first_mean = w.tot / (double)half;
-                second = true;
-                walker_begin(w, half, n - half);
-                walker_drain(w, stage, produced, sl);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+    double tot = 0.0, first = 0.0, second = 0.0;
+    if (sub == 0) {
+        tot = np_sum(ring, mask, from, n, dl, sl);
+    } else if (need_halves && half >= 1) {
+        first = np_sum(ring, mask, from, half, dl, sl);
+        second = np_sum(ring, mask, from + half, n - half, dl, sl);
     }
-    // sub 0 now holds the full sum, sub 1 the second-half sum
-    const double tot = gbcast(w.tot, 0);
-    const double tot2 = gbcast(w.tot, 8);
-    const double fm = gbcast(first_mean, 8);
-    mean_all = tot / (double)n;
-    lat_inc = (need_halves && half >= 1) ? tot2 / (double)(n - half) - fm : 0.0;
+    mean_all = gbcast(tot, 0) / (double)n;
+    lat_inc = (need_halves && half >= 1) ? gbcast(second, 8) / (double)(n - half) - gbcast(first, 8) / (double)half : 0.0;
 }
 
 // the 12 metrics of one MI (so:110-191) from its counts and RTT means
@@ -831,7 +866,6 @@ template <int NS>
 __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, uint32_t warm_mi, int last_warm,
                                                               float *obs_out, float *reward_out, uint8_t *done_out,
                                                               double *steps_out) {
-    __shared__ double s_stage[kRetireBlock / kGroup][kStage];
     const uint32_t tid = threadIdx.x;
     Group g;
     g.lane = tid & (kGroup - 1);
@@ -839,7 +873,6 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
     const int64_t i = (int64_t)blockIdx.x * (kRetireBlock / kGroup) + (tid / kGroup);
     if (i >= D.n) return;
     if (warm && !D.resetting[i]) return;
-    double *stage = s_stage[tid / kGroup];
     const bool lead = g.lane == 0;
     const uint32_t mask = D.cap_mask, dmask = D.dcap_mask;
 
@@ -873,34 +906,41 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
         bool h2_is_drop[NS];
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            // ---- accepted ring: exact monotone searches
-            const uint32_t pa = search_boundary(g, ra[s], mask, ha[s], ta[s], dl, end);   // hop-2 events < end
-            acked[s] = pa - ha[s];                                                        // ns:144-146
-            const uint32_t ca = search_boundary(g, ra[s], mask, pa, ta[s], 0.0, end);     // hop-1 events < end
+            // ---- all four boundaries of this sender in one joint search (3-4 dependent loads)
+            const double2 *const rings[4] = {ra[s], ra[s], rd[s], rd[s]};
+            const uint32_t masks[4] = {mask, mask, dmask, dmask};
+            const uint32_t los[4] = {ha[s], ha[s], hd[s], hd[s]};
+            const uint32_t his[4] = {ta[s], ta[s], td[s], td[s]};
+            const double adds[4] = {dl, 0.0, dl, 0.0};
+            Bound bnd[4];
+            search_many<4>(g, rings, masks, los, his, adds, end, bnd);
+            // ---- accepted ring: send order is event order, the transitions are exact
+            const uint32_t pa = bnd[0].b, ca = bnd[1].b;            // hop-2 / hop-1 events < end
+            acked[s] = pa - ha[s];                                   // ns:144-146
             ha[s] = pa;
             double a2_t = INFINITY, a2_l = 0.0, a1_t = INFINITY, a1_l = 0.0;
-            if (pa < ca) {  // first unretired accepted packet is past the forward hop
-                const double2 r = ra[s][pa & mask];
-                a2_t = r.x + dl; a2_l = r.y + dl;
-            }
-            if (ca < ta[s]) {
-                const double2 r = ra[s][ca & mask];
-                a1_t = r.x; a1_l = r.y;
-            }
-            // ---- dropped ring: searches, then the exact serial repair around each transition
-            const uint32_t bd = search_boundary(g, rd[s], dmask, hd[s], td[s], dl, end);
-            uint32_t pd = bd, dk = 0xFFFFFFFFu;
+            if (pa < ca) { a2_t = bnd[0].t + dl; a2_l = bnd[0].lat + dl; }  // first unretired is past the forward hop
+            if (ca < ta[s]) { a1_t = bnd[1].t; a1_l = bnd[1].lat; }
+            // ---- dropped ring: exact as found unless near-equal times surround the transition
+            uint32_t pd = bnd[2].b, dk = 0xFFFFFFFFu;
             double d2_t = INFINITY, d2_l = 0.0;
-            if (td[s] != hd[s]) {
-                if (lead) pd = fix_drop_boundary(rd[s], dmask, hd[s], td[s], bd, dl, end, dk, d2_t, d2_l);
+            bool rotated = false;
+            if (bnd[2].clean) {
+                if (pd < td[s] && bnd[2].t < end) { dk = pd; d2_t = bnd[2].t + dl; d2_l = bnd[2].lat + dl; }
+            } else {
+                if (lead) pd = fix_drop_boundary(rd[s], dmask, hd[s], td[s], bnd[2].b, dl, end, dk, d2_t, d2_l);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 pd = gbcast(pd, 0); dk = gbcast(dk, 0); d2_t = gbcast(d2_t, 0); d2_l = gbcast(d2_l, 0);
+                rotated = true;  // records may have moved inside the window
             }
-            lost[s] = pd - hd[s];                                                         // ns:141-143
+            lost[s] = pd - hd[s];                                    // ns:141-143
             hd[s] = pd;
-            const uint32_t cd = search_boundary(g, rd[s], dmask, pd, td[s], 0.0, end);
             double d1_t = INFINITY, d1_l = 0.0;
-            if (td[s] != pd) {
+            if (!rotated && bnd[3].clean) {
+                if (bnd[3].b < td[s]) { d1_t = bnd[3].t; d1_l = bnd[3].lat; }
+            } else if (td[s] != pd) {
+                const uint32_t cd = rotated ? search_boundary(g, rd[s], dmask, pd, td[s], 0.0, end)
+                                            : (bnd[3].b < pd ? pd : bnd[3].b);
                 if (lead) drop_hop1_candidate(rd[s], dmask, pd, td[s], cd, end, d1_t, d1_l);
                 d1_t = gbcast(d1_t, 0); d1_l = gbcast(d1_l, 0);
             }
@@ -1002,7 +1042,7 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
         double lat = 0.0, inc = 0.0;
-        if (acked[s] > 0) rtt_means(g, ra[s], mask, from[s], acked[s], dl, need_halves, stage, lat, inc);
+        if (acked[s] > 0 && !(D.debug_skip & 1)) rtt_means(g, ra[s], mask, from[s], acked[s], dl, need_halves, lat, inc);
         double min_lat = D.min_lat[k];
         double m[PCC_N_METRICS];
         mi_metrics(sent[s], acked[s], lost[s], dur, lat, inc, min_lat, m);
@@ -1015,7 +1055,7 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
         float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
         float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
         const int keep = D.HF - D.F;
-        for (int base = 0; base < D.HF; base += kGroup) {
+        for (int base = 0; base < D.HF && !(D.debug_skip & 2); base += kGroup) {
             const int x = base + (int)g.lane;
             float v = 0.f;
             if (x < keep) v = hist[x + D.F];
@@ -1291,6 +1331,9 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.key0 = (uint32_t)seed; d.key1 = (uint32_t)(seed >> 32); d.gid_base = env_gid_base;
     d.delta_scale = 0.025;  // src/common/config.py:17
     d.max_steps = 400;      // ns:41
+    d.heavy_packets = 512.0;
+    d.debug_skip = getenv("PCC_DEBUG_SKIP") ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;
+    d.heavy_rho = 0.45;
     const double lo[5] = {100, 0.05, 0, 0.0, 0.3}, hi[5] = {500, 0.5, 8, 0.05, 1.5};  // ns:355-358,466
     memcpy(d.lo, lo, sizeof lo); memcpy(d.hi, hi, sizeof hi);
     d.rng_mode = PCC_RNG_PHILOX;
@@ -1365,6 +1408,15 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed) {
     sim->d.key0 = (uint32_t)seed;
     sim->d.key1 = (uint32_t)(seed >> 32);
     return PCC_OK;
+}
+
+int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
+    if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    switch (key) {
+        case PCC_TUNE_HEAVY_PACKETS: sim->d.heavy_packets = value; return PCC_OK;
+        case PCC_TUNE_HEAVY_RHO: sim->d.heavy_rho = value; return PCC_OK;
+        default: return fail(PCC_EINVAL, "unknown tuning key %d", key);
+    }
 }
 
 int pcc_set_delta_scale(pcc_sim_t *sim, double delta_scale) {

@@ -155,6 +155,13 @@ class BatchedNetworkEnv(object):
         check(self._L.pcc_set_rng(self._h, native.PCC_RNG_TRACE, _ptr(t), t.shape[1]))
         self._trace = t
 
+    def set_tuning(self, heavy_packets=None, heavy_rho=None):
+        """Performance knobs of the send kernel (results do not depend on them)."""
+        if heavy_packets is not None:
+            check(self._L.pcc_set_tuning(self._h, 0, float(heavy_packets)))
+        if heavy_rho is not None:
+            check(self._L.pcc_set_tuning(self._h, 1, float(heavy_rho)))
+
     def seed(self, seed=None):
         if seed is not None:
             self.seed_value = int(seed)

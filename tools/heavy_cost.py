@@ -13,6 +13,8 @@ for name, params in [("drop-dominated (bw 105, rate 1000, queue 2981)", (105.0, 
                      ("middle (bw 350, rate 600, queue 3000)", (350.0, 0.05, 3000.0, 0.01, 600.0)),
                      ("accept-dominated (bw 500, rate 400, dl 0.5)", (500.0, 0.5, 3000.0, 0.01, 400.0))]:
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, link_params=params, record_steps=True)
+    if os.environ.get("PCC_HEAVY_PACKETS"):
+        env.set_tuning(heavy_packets=float(os.environ["PCC_HEAVY_PACKETS"]), heavy_rho=float(os.environ.get("PCC_HEAVY_RHO", 0.45)))
     env.reset()
     zero = torch.zeros((N,), device=dev)
     for t in range(40):

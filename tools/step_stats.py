@@ -18,6 +18,9 @@ def main():
     out = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/step_stats.json"
     dev = torch.device("cuda:0")
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
+    if os.environ.get("PCC_HEAVY_PACKETS") or os.environ.get("PCC_HEAVY_RHO"):
+        env.set_tuning(heavy_packets=float(os.environ.get("PCC_HEAVY_PACKETS", 512)),
+                       heavy_rho=float(os.environ.get("PCC_HEAVY_RHO", 0.45)))
     env.reset()
     gen = torch.Generator(device=dev).manual_seed(1234)
     acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
