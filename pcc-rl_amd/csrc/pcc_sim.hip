@@ -177,6 +177,7 @@ __device__ __forceinline__ double2 link_send(double t, bool rnd /* random.random
 //                  order: send order is event order only up to "near groups" (neighbours
 //                  within kNearTol relative time), which a serial path orders exactly.
 // ======================================================================================
+constexpr uint32_t kRound = 256;    // packets per env per lane-serial round of the send kernel
 constexpr double kNearTol = 1e-12;  // >> the few-ulp spread of a tie group, << any 1/bw
 
 __device__ __forceinline__ bool near_time(double a, double b) {
@@ -207,6 +208,13 @@ __device__ __forceinline__ uint64_t rl_u64(uint64_t v, uint32_t l) {
     const uint32_t lo = rl_u32((uint32_t)v, l), hi = rl_u32((uint32_t)(v >> 32), l);
     return ((uint64_t)hi << 32) | lo;
 }
+// make a wave-uniform value provably uniform for the compiler (scalar registers, scalar branches)
+__device__ __forceinline__ uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ double uni_f64(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ uint32_t exponent_bits(double x) { return ((uint32_t)__double2hiint(x) >> 20) & 0x7FFu; }
 
 struct SendState {  // wave-uniform while an env is processed by the whole wave
@@ -231,8 +239,6 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                                          uint32_t mi, uint32_t gid, const double *trace, char *base, SendState &st) {
     const uint32_t mask_b = D.cap_mask << 4, dmask_b = D.dcap_mask << 4, cap_b = D.cap << 4;
     const uint64_t lt = (1ull << lane) - 1ull;
-    // the accept-to-accept pass pays off when most packets are dropped (rate well above bw)
-    const bool drop_dominated = gap < D.heavy_rho * ebw;
     while (st.t < end) {
         const double t0 = st.t;
         // ---- loss decisions of the next 64 packets, one per lane
@@ -255,7 +261,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
         const double G = t1s - t0;
         const double t2s = t1s + gap;
         const double tend = t0 + 64.0 * G;
-        const bool ok = drop_dominated && (t2s - t1s == G) && (t0 >= 128.0 * gap) &&
+        const bool ok = (t2s - t1s == G) && (t0 >= 128.0 * gap) &&
                         (exponent_bits(t0) == exponent_bits(tend)) && (st.tu >= maxq) && (st.tu + st.tu >= tend) &&
                         (G > 0.0);
         double my_t = 0.0, my_lat = 0.0;
@@ -265,8 +271,19 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
             // ---- serial pass: up to 64 packets with the plain recurrence, wave-uniform (every lane
             // computes the same values; lane k keeps packet k's record), exact with no precondition
             double t = t0;
+            // packets certainly before `end` (two of margin for the rounding of t += gap) run under a
+            // scalar loop counter; the rest with the exit test, kept scalar through readfirstlane
+            const double ahead = (end - t0) / gap - 2.0;
+            const uint32_t nsafe = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)(ahead >= 64.0 ? 64u : (ahead > 0.0 ? (uint32_t)ahead : 0u)));
             uint32_t k = 0;
-            for (; k < 64u && t < end; k++) {
+            for (; k < nsafe; k++) {
+                bool dropped;
+                const double2 rec = link_send(t, (rmask >> k) & 1ull, dl, maxq, ebw, st.q, st.tu, dropped);
+                if (lane == k) { my_t = rec.x; my_lat = rec.y; my_drop = dropped; }
+                t += gap;  // ns:161
+            }
+            for (; k < 64u && __builtin_amdgcn_readfirstlane((int)(t < end)); k++) {
                 bool dropped;
                 const double2 rec = link_send(t, (rmask >> k) & 1ull, dl, maxq, ebw, st.q, st.tu, dropped);
                 if (lane == k) { my_t = rec.x; my_lat = rec.y; my_drop = dropped; }
@@ -280,26 +297,39 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
             const bool valid = tk < end;
             const uint64_t vmask = __ballot(valid);
             nv = (uint32_t)__popcll(vmask);  // valid lanes are a prefix (tk increases)
+            // Phase 1 -- the chain from one ACCEPTED packet to the next, nothing else: with (qm, tm)
+            // the link state the last accepted packet left, every lane tests "would I be tail-dropped";
+            // the first lane that is neither that nor a random loss is the next accepted packet.  Its
+            // (queue after, time) go to lane #accept of seg_q/seg_t.
             double qm = st.q, tm = st.tu;
-            uint32_t done = 0;  // lanes [0, done) are final
-            double my_q_after = 0.0;
-            for (;;) {
-                const double qc = max0(qm - (tk - tm));  // queue seen by packet k if nothing was accepted since m
-                const double s = ebw + qc;
-                const bool full = s > maxq;              // monotone non-increasing in k
-                const bool open = valid && lane >= done;
-                const uint64_t cm = __ballot(open && !rnd && !full);
-                const uint32_t ks = cm ? (uint32_t)__ffsll((unsigned long long)cm) - 1u : 64u;  // next accepted
-                if (open && lane <= ks) {
-                    my_lat = dl + qc;                    // ns:170
-                    my_drop = lane != ks;
-                    my_q_after = my_drop ? qc : s;       // link state this packet leaves unless it is a random loss
-                }
-                if (ks >= 64u) break;
-                qm = rl_f64(s, ks);                      // ns:82
+            uint64_t open = vmask & ~rmask;          // lanes that can still be the next accepted packet
+            uint64_t amask = 0;                      // accepted lanes
+            uint32_t na = 0;
+            double seg_q = 0.0, seg_t = 0.0;         // lane j: link state after the j-th accepted packet
+            while (open) {
+                const double qc = max0(qm - (tk - tm));  // queue seen by packet k if nothing was accepted since tm
+                const bool full = ebw + qc > maxq;       // monotone non-increasing in k
+                const uint64_t cm = open & ~__ballot(full);
+                if (!cm) break;
+                const uint32_t ks = (uint32_t)__ffsll((unsigned long long)cm) - 1u;
+                qm = rl_f64(ebw + qc, ks);               // ns:82
                 tm = rl_f64(tk, ks);                     // ns:76
-                done = ks + 1u;
+                if (lane == na) { seg_q = qm; seg_t = tm; }
+                na++;
+                amask |= 1ull << ks;
+                open &= ~((2ull << ks) - 1ull);          // lanes after ks
             }
+            // Phase 2 -- every lane finishes its own packet from the state its segment started with:
+            // segment = number of accepted packets before this lane (0 = the state the pass began with)
+            const uint32_t seg = (uint32_t)__popcll(amask & lt);
+            const int src = seg ? (int)seg - 1 : 0;
+            double q_seg = __shfl(seg_q, src);
+            double t_seg = __shfl(seg_t, src);
+            if (!seg) { q_seg = st.q; t_seg = st.tu; }
+            const double qc = max0(q_seg - (tk - t_seg));
+            my_lat = dl + qc;                            // ns:170
+            my_drop = !((amask >> lane) & 1ull);
+            const double my_q_after = my_drop ? qc : ebw + qc;  // link state this packet leaves unless a random loss
             my_t = tk + my_lat;                          // ns:174
             // link state after the pass = what the last packet that was not a random loss left (ns:75-82)
             const uint64_t touch = vmask & ~rmask;
@@ -383,70 +413,85 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
                            nsend[0] >= 128.0 * gap[0];
         double t = nsend[0];
         uint32_t a = ta[0], d = td[0];
-        if (run && !heavy) {
-            if (!TRACE) {
-                // serial hot loop: four packets per Philox block, no loads, no data-dependent branches.
-                // The first `safe` packets are certainly before `end` (t advances by gap up to
-                // rounding; two packets of margin), so whole blocks of four run without the fp64
-                // exit test; the remainder is sent with the test after every packet.
-                uint32_t blk = 0;
-                const double ahead = (end - t) / gap[0] - 2.0;
-                uint32_t safe4 = ahead >= 4.0 ? (uint32_t)fmin(ahead, 1073741824.0) >> 2 : 0u;
-                for (; safe4; safe4--) {
-                    uint32_t w[4];
-                    philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
-                    blk++;
+        bool heavy_now = heavy;
+        bool active = run && !heavy;
+        uint32_t blk = 0;  // Philox block = packets sent in this MI / 4
+        // Lane-serial rounds of at most kRound packets per env.  After a round, if only one or two
+        // lanes of the wave still have packets to send, they are the tail everybody else would wait
+        // for: hand them to the wave path, which sends one env's packets 2-5x faster than one lane.
+        for (;;) {
+            if (active) {
+                if (!TRACE) {
+                    // four packets per Philox block, no loads, no data-dependent branches.  The first
+                    // `safe` packets are certainly before `end` (t advances by gap up to rounding; two
+                    // packets of margin), so whole blocks run without the fp64 exit test.
+                    const double ahead = (end - t) / gap[0] - 2.0;
+                    uint32_t safe4 = ahead >= 4.0 ? (uint32_t)fmin(ahead, (double)kRound) >> 2 : 0u;
+                    uint32_t budget4 = kRound / 4 - safe4;
+                    for (; safe4; safe4--) {
+                        uint32_t w[4];
+                        philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                        blk++;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < 4; k++) {
+                            bool dropped;
+                            const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
+                            const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
+                            *reinterpret_cast<double2 *>(base + off) = rec;
+                            a += dropped ? 0u : 1u;
+                            d += dropped ? 1u : 0u;
+                            t += gap[0];  // ns:161
+                        }
+                    }
+                    for (; budget4 && t < end; budget4--) {
+                        uint32_t w[4];
+                        philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                        blk++;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (k > 0 && !(t < end)) break;
+                            bool dropped;
+                            const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
+                            const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
+                            *reinterpret_cast<double2 *>(base + off) = rec;
+                            a += dropped ? 0u : 1u;
+                            d += dropped ? 1u : 0u;
+                            t += gap[0];  // ns:161
+                        }
+                    }
+                } else {
+                    for (uint32_t budget = kRound; budget && t < end; budget--) {
+                        const uint64_t pos = (uint64_t)a + d;
+                        double u = 1.0;
+                        if ((int64_t)pos >= D.trace_stride) flags |= PCC_FLAG_TRACE_OVERRUN;
+                        else u = trace[pos];
                         bool dropped;
-                        const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
+                        const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
                         const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
                         *reinterpret_cast<double2 *>(base + off) = rec;
                         a += dropped ? 0u : 1u;
                         d += dropped ? 1u : 0u;
-                        t += gap[0];  // ns:161
+                        t += gap[0];
                     }
                 }
-                while (t < end) {
-                    uint32_t w[4];
-                    philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
-                    blk++;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (k > 0 && !(t < end)) break;
-                        bool dropped;
-                        const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
-                        const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                        *reinterpret_cast<double2 *>(base + off) = rec;
-                        a += dropped ? 0u : 1u;
-                        d += dropped ? 1u : 0u;
-                        t += gap[0];  // ns:161
-                    }
-                }
-            } else {
-                while (t < end) {
-                    const uint64_t pos = (uint64_t)a + d;
-                    double u = 1.0;
-                    if ((int64_t)pos >= D.trace_stride) flags |= PCC_FLAG_TRACE_OVERRUN;
-                    else u = trace[pos];
-                    bool dropped;
-                    const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
-                    const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                    *reinterpret_cast<double2 *>(base + off) = rec;
-                    a += dropped ? 0u : 1u;
-                    d += dropped ? 1u : 0u;
-                    t += gap[0];
-                }
+                active = t < end;
+            }
+            const uint64_t am = __ballot(active);
+            if (!am) break;
+            if (__popcll(am) <= 2) {  // the wave path sends one env faster than a lone lane in every regime
+                heavy_now = heavy_now || active;
+                break;
             }
         }
-        // heavy envs of this wave, one after the other, 64 lanes each
-        uint64_t hm = __ballot(heavy);
+        // heavy envs of this wave (standing or tail take-over), one after the other, 64 lanes each
+        uint64_t hm = __ballot(heavy_now);
         while (hm) {
             const uint32_t l = (uint32_t)__ffsll((unsigned long long)hm) - 1u;
             hm &= hm - 1ull;
             SendState st;
             st.q = rl_f64(q, l); st.tu = rl_f64(tu, l); st.t = rl_f64(t, l);
-            st.a = rl_u32(a, l); st.d = rl_u32(d, l); st.sent = 0; st.flags = 0;
+            st.a = rl_u32(a, l); st.d = rl_u32(d, l); st.flags = 0;
+            st.sent = (st.a - rl_u32(ta[0], l)) + (st.d - rl_u32(td[0], l));  // packets of this MI already sent by the lane
             heavy_mi<TRACE>(D, lane, rl_f64(dl, l), rl_f64(lr, l), rl_u32(thr, l), rl_u32(always ? 1u : 0u, l) != 0u,
                             rl_f64(maxq, l), rl_f64(ebw, l), rl_f64(gap[0], l), rl_f64(end, l), rl_u32(episode, l),
                             rl_u32(mi, l), rl_u32(gid, l),
