@@ -138,12 +138,13 @@ int pcc_set_rng(pcc_sim_t *sim, int mode, const double *trace, int64_t trace_str
  * seed(), ns:396-398, creates an RNG nothing reads; here it does what a caller expects.) */
 int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
 
-/* Performance knobs; results never depend on them (both send paths are exact).
- *   PCC_TUNE_HEAVY_PACKETS  an env with more predicted packets in the coming monitor interval
- *                           than this (default 512) and ...
- *   PCC_TUNE_HEAVY_RHO      ... bw/rate below this (default 0.45: most packets are dropped) is
- *                           sent by a whole wavefront 64 packets at a time instead of by one lane. */
-enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1 };
+/* Performance knobs of the send kernel; results never depend on them (every send path is exact).
+ * Each lane sends its env's packets in rounds of ROUND_PACKETS (default 256); when at most
+ * TAKEOVER_LANES (default 2) lanes of a wavefront still have packets left after a round, those
+ * envs are finished by the whole wavefront, 64 packets per pass.  An env predicted to send more
+ * than HEAVY_PACKETS packets with bw/rate below HEAVY_RHO skips the lane rounds entirely
+ * (default: off, HEAVY_PACKETS = 1e18). */
+enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3 };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* DELTA_SCALE (src/common/config.py:17, default 0.025) and MAX_STEPS (ns:41, default 400) */

@@ -89,6 +89,7 @@ struct Dev {
     uint32_t max_steps;
     int debug_skip;  // profiling only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs
     double heavy_packets, heavy_rho;  // tuning: when the send kernel hands an env to the wave path
+    uint32_t round_packets, takeover_lanes;
     double lo[5], hi[5];
     int rng_mode;
     const double *trace;
@@ -177,7 +178,6 @@ __device__ __forceinline__ double2 link_send(double t, bool rnd /* random.random
 //                  order: send order is event order only up to "near groups" (neighbours
 //                  within kNearTol relative time), which a serial path orders exactly.
 // ======================================================================================
-constexpr uint32_t kRound = 256;    // packets per env per lane-serial round of the send kernel
 constexpr double kNearTol = 1e-12;  // >> the few-ulp spread of a tie group, << any 1/bw
 
 __device__ __forceinline__ bool near_time(double a, double b) {
@@ -426,8 +426,8 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
                     // `safe` packets are certainly before `end` (t advances by gap up to rounding; two
                     // packets of margin), so whole blocks run without the fp64 exit test.
                     const double ahead = (end - t) / gap[0] - 2.0;
-                    uint32_t safe4 = ahead >= 4.0 ? (uint32_t)fmin(ahead, (double)kRound) >> 2 : 0u;
-                    uint32_t budget4 = kRound / 4 - safe4;
+                    uint32_t safe4 = ahead >= 4.0 ? (uint32_t)fmin(ahead, (double)D.round_packets) >> 2 : 0u;
+                    uint32_t budget4 = D.round_packets / 4 - safe4;
                     for (; safe4; safe4--) {
                         uint32_t w[4];
                         philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
                         }
                     }
                 } else {
-                    for (uint32_t budget = kRound; budget && t < end; budget--) {
+                    for (uint32_t budget = D.round_packets; budget && t < end; budget--) {
                         const uint64_t pos = (uint64_t)a + d;
                         double u = 1.0;
                         if ((int64_t)pos >= D.trace_stride) flags |= PCC_FLAG_TRACE_OVERRUN;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
             }
             const uint64_t am = __ballot(active);
             if (!am) break;
-            if (__popcll(am) <= 2) {  // the wave path sends one env faster than a lone lane in every regime
+            if ((uint32_t)__popcll(am) <= D.takeover_lanes) {  // the wave path sends one env faster than a lone lane
                 heavy_now = heavy_now || active;
                 break;
             }
@@ -1376,7 +1376,9 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.key0 = (uint32_t)seed; d.key1 = (uint32_t)(seed >> 32); d.gid_base = env_gid_base;
     d.delta_scale = 0.025;  // src/common/config.py:17
     d.max_steps = 400;      // ns:41
-    d.heavy_packets = 512.0;
+    d.heavy_packets = 1e18;  // standing classification off: the tail take-over alone measured best
+    d.round_packets = 256;
+    d.takeover_lanes = 2;
     d.debug_skip = getenv("PCC_DEBUG_SKIP") ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;
     d.heavy_rho = 0.45;
     const double lo[5] = {100, 0.05, 0, 0.0, 0.3}, hi[5] = {500, 0.5, 8, 0.05, 1.5};  // ns:355-358,466
@@ -1460,6 +1462,14 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
     switch (key) {
         case PCC_TUNE_HEAVY_PACKETS: sim->d.heavy_packets = value; return PCC_OK;
         case PCC_TUNE_HEAVY_RHO: sim->d.heavy_rho = value; return PCC_OK;
+        case PCC_TUNE_ROUND_PACKETS:
+            if (value < 4 || value > 1048576) return fail(PCC_EINVAL, "round_packets out of range");
+            sim->d.round_packets = ((uint32_t)value + 3u) & ~3u;
+            return PCC_OK;
+        case PCC_TUNE_TAKEOVER_LANES:
+            if (value < 0 || value > 64) return fail(PCC_EINVAL, "takeover_lanes out of range");
+            sim->d.takeover_lanes = (uint32_t)value;
+            return PCC_OK;
         default: return fail(PCC_EINVAL, "unknown tuning key %d", key);
     }
 }

@@ -155,8 +155,12 @@ class BatchedNetworkEnv(object):
         check(self._L.pcc_set_rng(self._h, native.PCC_RNG_TRACE, _ptr(t), t.shape[1]))
         self._trace = t
 
-    def set_tuning(self, heavy_packets=None, heavy_rho=None):
+    def set_tuning(self, heavy_packets=None, heavy_rho=None, round_packets=None, takeover_lanes=None):
         """Performance knobs of the send kernel (results do not depend on them)."""
+        if round_packets is not None:
+            check(self._L.pcc_set_tuning(self._h, 2, float(round_packets)))
+        if takeover_lanes is not None:
+            check(self._L.pcc_set_tuning(self._h, 3, float(takeover_lanes)))
         if heavy_packets is not None:
             check(self._L.pcc_set_tuning(self._h, 0, float(heavy_packets)))
         if heavy_rho is not None:

@@ -19,8 +19,11 @@ def main():
     dev = torch.device("cuda:0")
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
     if os.environ.get("PCC_HEAVY_PACKETS") or os.environ.get("PCC_HEAVY_RHO"):
-        env.set_tuning(heavy_packets=float(os.environ.get("PCC_HEAVY_PACKETS", 512)),
+        env.set_tuning(heavy_packets=float(os.environ.get("PCC_HEAVY_PACKETS", 1e18)),
                        heavy_rho=float(os.environ.get("PCC_HEAVY_RHO", 0.45)))
+    if os.environ.get("PCC_ROUND") or os.environ.get("PCC_TAKEOVER"):
+        env.set_tuning(round_packets=float(os.environ.get("PCC_ROUND", 256)),
+                       takeover_lanes=float(os.environ.get("PCC_TAKEOVER", 2)))
     env.reset()
     gen = torch.Generator(device=dev).manual_seed(1234)
     acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
