@@ -770,37 +770,46 @@ __device__ __noinline__ void drop_hop1_candidate(const double2 *ring, uint32_t m
 // leaf is random access: an 8-lane subgroup loads its <= 16 strided samples per lane in one
 // round trip (lane j owns r[j]) and folds with __shfl_xor.
 // --------------------------------------------------------------------------------------
-__device__ __forceinline__ double leaf_sum(const double2 *ring, uint32_t mask, uint32_t beg, uint32_t len, double dl,
-                                           uint32_t sl) {
-    if (len < 8) {
-        double res = 0.;
-        for (uint32_t e = 0; e < len; e++) res += ring[(beg + e) & mask].y + dl;
-        return res;
-    }
-    const uint32_t nblk = len / 8;  // <= 16
+__device__ __noinline__ double leaf_sum(const double2 *ring, uint32_t mask, uint32_t beg, uint32_t len, double dl,
+                                        uint32_t sl) {
+    // Kept out of line on purpose: inlined copies let the compiler hoist every copy's loads to the
+    // top and the kernel's register count explodes.  Loads are unconditional -- any ring index is
+    // a valid address -- and only the adds are guarded; byte offsets wrap with one AND.
+    const uint32_t nblk = len >> 3;  // <= 16 full blocks of 8 ...
+    const uint32_t ntail = len & 7u; // ... and < 8 leftover samples, added one by one at the end
+    const char *base = reinterpret_cast<const char *>(ring) + 8;  // .y of record 0
+    const uint32_t bmask = mask << 4;
+    const uint32_t o0 = ((beg + sl) << 4) & bmask;
     double v[16];
 #pragma unroll
-    for (int b = 0; b < 16; b++) {
-        v[b] = 0.0;
-        if ((uint32_t)b < nblk) v[b] = ring[(beg + 8u * b + sl) & mask].y;
+    for (int b = 0; b < 8; b++) v[b] = *reinterpret_cast<const double *>(base + ((o0 + 128u * b) & bmask));
+    // lane e of the subgroup fetches leftover sample e (lane 7's load is unused)
+    const double tv = *reinterpret_cast<const double *>(base + ((((beg + 8u * nblk + sl) << 4)) & bmask));
+    if (nblk > 8) {
+#pragma unroll
+        for (int b = 8; b < 16; b++) v[b] = *reinterpret_cast<const double *>(base + ((o0 + 128u * b) & bmask));
     }
-    double tail[7];
+    double x = 0.;
+    if (nblk) {
+        double r = v[0] + dl;
+#pragma unroll
+        for (int b = 1; b < 8; b++)
+            if ((uint32_t)b < nblk) r += v[b] + dl;
+        if (nblk > 8) {
+#pragma unroll
+            for (int b = 8; b < 16; b++)
+                if ((uint32_t)b < nblk) r += v[b] + dl;
+        }
+        x = r;
+        x = x + __shfl_xor(x, 1, 8);
+        x = x + __shfl_xor(x, 2, 8);
+        x = x + __shfl_xor(x, 4, 8);
+    }
 #pragma unroll
     for (int e = 0; e < 7; e++) {
-        tail[e] = 0.0;
-        if (8u * nblk + e < len) tail[e] = ring[(beg + 8u * nblk + e) & mask].y;
+        const double te = __shfl(tv, e, 8);
+        if ((uint32_t)e < ntail) x += te + dl;
     }
-    double r = v[0] + dl;
-#pragma unroll
-    for (int b = 1; b < 16; b++)
-        if ((uint32_t)b < nblk) r += v[b] + dl;
-    double x = r;
-    x = x + __shfl_xor(x, 1, 8);
-    x = x + __shfl_xor(x, 2, 8);
-    x = x + __shfl_xor(x, 4, 8);
-#pragma unroll
-    for (int e = 0; e < 7; e++)
-        if (8u * nblk + e < len) x += tail[e] + dl;
     return x;
 }
 
@@ -860,15 +869,37 @@ __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, u
                                           double &lat_inc) {
     const uint32_t sub = g.lane >> 3, sl = g.lane & 7u;
     const uint32_t half = n / 2;
+    const bool halves = need_halves && half >= 1;
     double tot = 0.0, first = 0.0, second = 0.0;
-    if (sub == 0) {
+    if (n <= 256) {
+        // The usual case.  The list is at most three leaves (n -> n2 | rest, rest -> r2 | rest - r2)
+        // and each half exactly one, so both subgroups run the SAME leaf code side by side on
+        // different slices instead of one after the other.
+        uint32_t n2 = n, r2 = 0, r3 = 0;
+        if (n > 128) {
+            n2 = n / 2; n2 -= n2 % 8;
+            r2 = n - n2;
+            if (r2 > 128) { uint32_t x = r2 / 2; x -= x % 8; r3 = r2 - x; r2 = x; }
+        }
+        const double a = leaf_sum(ring, mask, from, sub == 0 ? n2 : (halves ? half : 0u), dl, sl);
+        const double b = leaf_sum(ring, mask, sub == 0 ? from + n2 : from + half,
+                                  sub == 0 ? r2 : (halves ? n - half : 0u), dl, sl);
+        tot = a;
+        if (n > 128) {
+            double right = b;
+            if (r3) right = b + leaf_sum(ring, mask, from + n2 + r2, sub == 0 ? r3 : 0u, dl, sl);
+            tot = a + right;
+        }
+        first = a;
+        second = b;
+    } else if (sub == 0) {
         tot = np_sum(ring, mask, from, n, dl, sl);
-    } else if (need_halves && half >= 1) {
+    } else if (halves) {
         first = np_sum(ring, mask, from, half, dl, sl);
         second = np_sum(ring, mask, from + half, n - half, dl, sl);
     }
     mean_all = gbcast(tot, 0) / (double)n;
-    lat_inc = (need_halves && half >= 1) ? gbcast(second, 8) / (double)(n - half) - gbcast(first, 8) / (double)half : 0.0;
+    lat_inc = halves ? gbcast(second, 8) / (double)(n - half) - gbcast(first, 8) / (double)half : 0.0;
 }
 
 // the 12 metrics of one MI (so:110-191) from its counts and RTT means
