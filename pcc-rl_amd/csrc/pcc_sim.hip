@@ -89,7 +89,8 @@ struct Dev {
     uint32_t max_steps;
     int debug_skip;  // profiling only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs
     double heavy_packets, heavy_rho;  // tuning: when the send kernel hands an env to the wave path
-    uint32_t round_packets, takeover_lanes;
+    uint32_t round_packets, takeover_lanes, send_envs_per_wave;
+    double heavy_predict;  // predicted packets per MI above which an env goes to the heavy wave
     double lo[5], hi[5];
     int rng_mode;
     const double *trace;
@@ -99,6 +100,7 @@ struct Dev {
     double *bw, *dl, *lr, *maxq, *ebw, *q, *tu, *now, *run_dur;
     uint32_t *steps, *episode, *flags;
     uint8_t *done, *resetting;
+    uint8_t *heavy_flag;   // [N] env predicted (by the previous retire) to send many packets in its next MI
     unsigned long long *total_sent;
     // per sender, [S][N]
     double *rate, *rate0, *next_send, *min_lat, *ep_return, *last_return;
@@ -359,12 +361,20 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
 }
 
 template <int NS, bool TRACE>
-__global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t warm_mi, const void *actions,
-                                                     int actions_f64) {
-    const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
-    const uint32_t lane = threadIdx.x;
-    // lanes without an env stay in the kernel: the heavy path needs all 64 lanes as workers
-    const bool live = i < D.n && !(warm && !D.resetting[i < D.n ? i : 0]);
+__global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32_t warm_mi, const void *actions,
+                                                         int actions_f64) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    // Two wavefronts per block of envs.  Wave 0 ("light") runs the lane-per-env rounds for the envs
+    // NOT flagged heavy; wave 1 ("heavy") sends the flagged envs one after the other with all 64
+    // lanes (heavy_mi).  The flag is the previous retire's prediction for this MI -- a performance
+    // hint only, every path is exact -- and the two waves touch disjoint envs, so nothing is shared.
+    // Lanes without an env stay in the kernel: the wave path needs all 64 lanes as workers.
+    const bool heavy_wave = threadIdx.x >= kWave;
+    const int64_t i = (int64_t)blockIdx.x * D.send_envs_per_wave + lane;
+    const bool in_range = lane < D.send_envs_per_wave && i < D.n;
+    const bool flagged = NS == 1 && in_range && D.heavy_flag[in_range ? i : 0] != 0;
+    const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]) && (flagged == heavy_wave);
+    if (heavy_wave && !__ballot(live)) return;
     const int64_t ii = live ? i : 0;
 
     const double dl = D.dl[ii], lr = D.lr[ii], maxq = D.maxq[ii], ebw = D.ebw[ii];
@@ -409,8 +419,8 @@ __global__ __launch_bounds__(kWave) void send_kernel(Dev D, int warm, uint32_t w
         char *base = reinterpret_cast<char *>(ring_of<NS>(D, ii, 0, 0));
         // heavy = many packets ahead, most of them drops (rate well above bw), and the wave path's
         // standing preconditions hold; everything else stays in the lane-serial loop
-        const bool heavy = run && (end - nsend[0]) > D.heavy_packets * gap[0] && gap[0] < D.heavy_rho * ebw && tu >= maxq &&
-                           nsend[0] >= 128.0 * gap[0];
+        const bool heavy = run && (heavy_wave || ((end - nsend[0]) > D.heavy_packets * gap[0] && gap[0] < D.heavy_rho * ebw &&
+                                                  tu >= maxq && nsend[0] >= 128.0 * gap[0]));
         double t = nsend[0];
         uint32_t a = ta[0], d = td[0];
         bool heavy_now = heavy;
@@ -1167,6 +1177,9 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
         if (steps_out)
             for (int s = 0; s < NS; s++) steps_out[(i * NS + s) * PCC_STEP_COLS + PCC_COL_RUN_DUR] = new_run_dur;
         D.run_dur[i] = new_run_dur;
+        // prediction for the next MI's send kernel: packets ~ MI length x current rate (the next
+        // action moves the rate by at most a few percent)
+        if (NS == 1) D.heavy_flag[i] = new_run_dur * D.rate[i] > D.heavy_predict ? 1 : 0;
         D.steps[i] = steps + 1;
         const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
         D.done[i] = done;
@@ -1213,6 +1226,7 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
     D.run_dur[i] = 3 * lat;   // ns:467
     D.steps[i] = 0;
     D.done[i] = 0;
+    D.heavy_flag[i] = 0;  // the warm-up MIs and the first step run in the light wave
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
@@ -1287,7 +1301,7 @@ size_t carve_state(Dev &d, char *base) {
     d.maxq = c.take<double>(n); d.ebw = c.take<double>(n); d.q = c.take<double>(n);
     d.tu = c.take<double>(n); d.now = c.take<double>(n); d.run_dur = c.take<double>(n);
     d.steps = c.take<uint32_t>(n); d.episode = c.take<uint32_t>(n); d.flags = c.take<uint32_t>(n);
-    d.done = c.take<uint8_t>(n); d.resetting = c.take<uint8_t>(n);
+    d.done = c.take<uint8_t>(n); d.resetting = c.take<uint8_t>(n); d.heavy_flag = c.take<uint8_t>(n);
     d.total_sent = c.take<unsigned long long>(n);
     d.rate = c.take<double>(sn); d.rate0 = c.take<double>(sn); d.next_send = c.take<double>(sn);
     d.min_lat = c.take<double>(sn); d.ep_return = c.take<double>(sn); d.last_return = c.take<double>(sn);
@@ -1313,11 +1327,13 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, const void *actions,
     const Dev &d = sim->d;
     const bool tr = d.rng_mode == PCC_RNG_TRACE;
     if (d.ns == 1) {
-        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<1, false>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        const dim3 sgrid((unsigned)((d.n + d.send_envs_per_wave - 1) / d.send_envs_per_wave));
+        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), sgrid, dim3(2 * kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<1, false>), sgrid, dim3(2 * kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
     } else {
-        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<2, false>), lane_grid(d), dim3(kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        const dim3 sgrid((unsigned)((d.n + d.send_envs_per_wave - 1) / d.send_envs_per_wave));
+        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), sgrid, dim3(2 * kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<2, false>), sgrid, dim3(2 * kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
     }
     return check_hip(hipGetLastError(), "send kernel launch");
 }
@@ -1410,6 +1426,8 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.heavy_packets = 1e18;  // standing classification off: the tail take-over alone measured best
     d.round_packets = 256;
     d.takeover_lanes = 2;
+    d.send_envs_per_wave = 64;
+    d.heavy_predict = 4096.0;
     d.debug_skip = getenv("PCC_DEBUG_SKIP") ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;
     d.heavy_rho = 0.45;
     const double lo[5] = {100, 0.05, 0, 0.0, 0.3}, hi[5] = {500, 0.5, 8, 0.05, 1.5};  // ns:355-358,466
@@ -1497,6 +1515,11 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             if (value < 4 || value > 1048576) return fail(PCC_EINVAL, "round_packets out of range");
             sim->d.round_packets = ((uint32_t)value + 3u) & ~3u;
             return PCC_OK;
+        case PCC_TUNE_SEND_ENVS_PER_WAVE:
+            if (value < 1 || value > 64) return fail(PCC_EINVAL, "send_envs_per_wave out of range");
+            sim->d.send_envs_per_wave = (uint32_t)value;
+            return PCC_OK;
+        case PCC_TUNE_HEAVY_PREDICT: sim->d.heavy_predict = value; return PCC_OK;
         case PCC_TUNE_TAKEOVER_LANES:
             if (value < 0 || value > 64) return fail(PCC_EINVAL, "takeover_lanes out of range");
             sim->d.takeover_lanes = (uint32_t)value;

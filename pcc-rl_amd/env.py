@@ -155,8 +155,13 @@ class BatchedNetworkEnv(object):
         check(self._L.pcc_set_rng(self._h, native.PCC_RNG_TRACE, _ptr(t), t.shape[1]))
         self._trace = t
 
-    def set_tuning(self, heavy_packets=None, heavy_rho=None, round_packets=None, takeover_lanes=None):
+    def set_tuning(self, heavy_packets=None, heavy_rho=None, round_packets=None, takeover_lanes=None,
+                   send_envs_per_wave=None, heavy_predict=None):
         """Performance knobs of the send kernel (results do not depend on them)."""
+        if heavy_predict is not None:
+            check(self._L.pcc_set_tuning(self._h, 5, float(heavy_predict)))
+        if send_envs_per_wave is not None:
+            check(self._L.pcc_set_tuning(self._h, 4, float(send_envs_per_wave)))
         if round_packets is not None:
             check(self._L.pcc_set_tuning(self._h, 2, float(round_packets)))
         if takeover_lanes is not None:

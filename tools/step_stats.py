@@ -21,6 +21,10 @@ def main():
     if os.environ.get("PCC_HEAVY_PACKETS") or os.environ.get("PCC_HEAVY_RHO"):
         env.set_tuning(heavy_packets=float(os.environ.get("PCC_HEAVY_PACKETS", 1e18)),
                        heavy_rho=float(os.environ.get("PCC_HEAVY_RHO", 0.45)))
+    if os.environ.get("PCC_HEAVY_PREDICT"):
+        env.set_tuning(heavy_predict=float(os.environ["PCC_HEAVY_PREDICT"]))
+    if os.environ.get("PCC_EPW"):
+        env.set_tuning(send_envs_per_wave=float(os.environ["PCC_EPW"]))
     if os.environ.get("PCC_ROUND") or os.environ.get("PCC_TAKEOVER"):
         env.set_tuning(round_packets=float(os.environ.get("PCC_ROUND", 256)),
                        takeover_lanes=float(os.environ.get("PCC_TAKEOVER", 2)))

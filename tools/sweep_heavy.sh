@@ -1,5 +1,5 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-for sk in 0 1 2; do
-  cd /tmp; PCC_DEBUG_SKIP=$sk timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pq_$sk -o q -- python $R/tools/step_stats.py 65536 60 $R/gpurun_out/tmp.json > /dev/null 2>&1
+for hp in 4096 6144 8192 1000000000; do
+  cd /tmp; PCC_HEAVY_PREDICT=$hp timeout 120 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/sw_hp$hp -o st -- python $R/tools/step_stats.py 65536 410 $R/gpurun_out/sw_hp$hp.json > /dev/null 2>&1
   cd $R
 done
