@@ -147,7 +147,7 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
 enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_SEND_ENVS_PER_WAVE = 4 /* envs per 64-lane wavefront in the send kernel, 1..64 */,
        PCC_TUNE_HEAVY_PREDICT = 5 /* predicted packets per interval above which an env is sent by the
-                                    block's second ("heavy") wavefront from the start; default 1536 */ };
+                                    block's second ("heavy") wavefront from the start; default 4096 */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* DELTA_SCALE (src/common/config.py:17, default 0.025) and MAX_STEPS (ns:41, default 400) */
