@@ -37,6 +37,18 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 B_FIXED_SEND, B_FIXED_RETIRE, B_PACKET_HALF = 120, 330, 16
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate passes over this same script; see profiles/README.md).  Counters cannot be read from
+    inside the process, so the figure is the profile's, labelled with its source."""
+    for name in ("r01_v5_pmc_hbm.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f), "profiles/" + name
+    return None, None
+
+
 def cpu_baseline(seconds_budget=20.0, threads=1):
     """The CPU oracle (oracle/pcc_oracle.c, the literal heap-based restatement of the
     reference engine) timed on this host on a bounded sample of the same workload."""
@@ -161,6 +173,11 @@ def main():
                          "whole_step": {"achieved": (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9,
                                         "frac": (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS}},
         }
+        pmc, src = pmc_traffic()
+        if pmc and N == 65536:
+            out["roofline"]["traffic"] = pmc["send_kernel<1, false>"]["hbm_bytes_per_launch_raw"]
+            out["roofline"]["traffic_source"] = src + " (steps 20..120 of an episode; raw FETCH_SIZE+WRITE_SIZE, KB units x 1024)"
+            out["roofline"]["other_kernels"][0]["traffic"] = pmc["retire_kernel<1>"]["hbm_bytes_per_launch_raw"]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         elif world == 1:

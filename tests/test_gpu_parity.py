@@ -214,3 +214,60 @@ def test_old_gym_adapter_drop_in():
     assert t == 400 and total == 625.6196947931776   # SURVEY.md section 8(c) KAT
     assert len(env.event_record["Events"]) == 400
     env.close()
+
+
+@pytest.mark.parametrize("knobs", [
+    dict(takeover_lanes=64, round_packets=8),            # everything through the wave path after 8 packets
+    dict(takeover_lanes=0, heavy_predict=1e18),          # lane-serial only
+    dict(heavy_predict=0.0),                             # every env sent by the heavy wavefront from the start
+    dict(heavy_packets=16, heavy_rho=10.0),              # standing classification on for every regime
+    dict(send_envs_per_wave=7, round_packets=64, takeover_lanes=3),
+])
+def test_send_paths_are_exact_whatever_the_tuning(knobs):
+    """The tuning knobs only choose WHICH exact send path runs (lane-serial rounds, the wave-wide
+    serial pass, the accept-to-accept pass): every setting must reproduce the oracle bit for bit."""
+    n_envs, n_steps, seed = 600, 120, 21
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=False)
+    env.set_tuning(**knobs)
+    env.reset()
+    rs = np.random.RandomState(seed)
+    acts = rs.uniform(-1, 2, (n_envs, n_steps))   # upward drift: overloaded queues, many drops
+    steps, obs, done = run_gpu(env, acts, n_steps)
+    ref = oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=seed)
+    assert np.array_equal(steps[..., :3], ref["steps"][..., :3])
+    assert np.array_equal(steps, ref["steps"])
+    assert np.array_equal(obs, ref["obs"].astype(np.float32))
+    env.close()
+
+
+def test_wave_path_on_golden_traces():
+    """Trace mode through the wave path: the saturating and deep-queue goldens with every env handed
+    to the heavy wavefront."""
+    for name in ("saturating_0_2", "fixed_deepq", "fixed_lossy"):
+        d = load(name)
+        env = golden_env(d, history_len=int(d["history_len"]))
+        env.set_tuning(heavy_predict=0.0)
+        env.reset()
+        env.set_tuning(heavy_predict=0.0, takeover_lanes=64, round_packets=4)
+        steps, obs, done = run_gpu(env, d["actions"], d["actions"].shape[1])
+        assert np.array_equal(steps, d["steps"]), name
+        env.close()
+
+
+def test_step_halves_and_protocol_errors():
+    env = pcc_rl_amd.BatchedNetworkEnv(64, device=DEV, seed=1)
+    with pytest.raises(pcc_rl_amd.PccError):
+        env.step(torch.zeros(64, device=DEV))          # step before reset
+    env.reset()
+    a = torch.zeros(64, device=DEV)
+    env.step_send(a)
+    with pytest.raises(pcc_rl_amd.PccError):
+        env.step_send(a)                               # two sends without a retire
+    o, r, d, _ = env.step_retire()
+    with pytest.raises(pcc_rl_amd.PccError):
+        env.step_retire()                              # retire without a send
+    env2 = pcc_rl_amd.BatchedNetworkEnv(64, device=DEV, seed=1)
+    env2.reset()
+    o2, r2, d2, _ = env2.step(a)
+    assert torch.equal(o, o2) and torch.equal(r, r2)
+    env.close(); env2.close()
