@@ -1,0 +1,129 @@
+"""On-device PPO for the batched env.
+
+The counterpart of the reference's training script (src/gym/stable_solve.py:39-58): the same
+policy shape (separate pi / vf MLPs, hidden sizes --arch = 32,16, tanh), gamma 0.99, a constant
+learning-rate schedule and an optimiser minibatch of 2048, with PPO1's other defaults (clip 0.2,
+entropy coefficient 0.01, 4 epochs, step size 1e-3, lambda 0.95).  The reference collects 8192
+steps from ONE env per iteration; here an iteration is T steps of N envs, everything -- rollout
+buffers, advantage estimation, updates -- lives on the GPU and the env never leaves it.
+
+This is a caller of the hot path, not part of it: stable-baselines is not available in this
+image, so there is nothing to check agent-level parity against.  What is
+checked: the GAE recursion against a plain loop (CPU test) and that a short run on the GPU
+improves the return.
+"""
+import math
+
+import torch
+from torch import nn
+
+
+def mlp(inp, hidden, out):
+    layers, last = [], inp
+    for h in hidden:
+        layers += [nn.Linear(last, h), nn.Tanh()]
+        last = h
+    layers.append(nn.Linear(last, out))
+    return nn.Sequential(*layers)
+
+
+class MlpPolicy(nn.Module):
+    """pi and vf networks of src/gym/stable_solve.py:39-45 (net_arch = [dict(pi=arch, vf=arch)])
+    with a state-independent log-std, as stable-baselines' diagonal Gaussian head."""
+
+    def __init__(self, obs_dim, act_dim=1, arch=(32, 16)):
+        super().__init__()
+        self.pi = mlp(obs_dim, arch, act_dim)
+        self.vf = mlp(obs_dim, arch, 1)
+        self.log_std = nn.Parameter(torch.zeros(act_dim))
+
+    def dist(self, obs):
+        return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
+
+    def value(self, obs):
+        return self.vf(obs).squeeze(-1)
+
+    @torch.no_grad()
+    def act(self, obs, stochastic=True):
+        d = self.dist(obs)
+        a = d.sample() if stochastic else d.mean
+        return a, d.log_prob(a).sum(-1), self.value(obs)
+
+
+def gae(rewards, values, dones, last_value, gamma=0.99, lam=0.95):
+    """Generalised advantage estimation over [T, N] tensors.  dones[t] marks that the env was reset
+    after step t (the next observation belongs to a new episode)."""
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    running = torch.zeros_like(last_value)
+    next_value = last_value
+    for t in range(T - 1, -1, -1):
+        alive = 1.0 - dones[t].to(rewards.dtype)
+        delta = rewards[t] + gamma * next_value * alive - values[t]
+        running = delta + gamma * lam * alive * running
+        adv[t] = running
+        next_value = values[t]
+    return adv, adv + values
+
+
+class PPO(object):
+    def __init__(self, env, arch=(32, 16), gamma=0.99, lam=0.95, clip=0.2, ent_coef=0.01, lr=1e-3,
+                 epochs=4, minibatch=2048, horizon=64, seed=0):
+        self.env, self.gamma, self.lam, self.clip, self.ent_coef = env, gamma, lam, clip, ent_coef
+        self.epochs, self.minibatch, self.horizon = epochs, minibatch, horizon
+        torch.manual_seed(seed)
+        self.policy = MlpPolicy(env.obs_dim, 1, arch).to(env.device)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=lr, eps=1e-5)
+        self.obs = env.reset().clone()
+
+    def collect(self):
+        env, T, N = self.env, self.horizon, self.env.n_envs
+        dev = env.device
+        obs_b = torch.empty((T, N, env.obs_dim), device=dev)
+        act_b = torch.empty((T, N, 1), device=dev)
+        logp_b = torch.empty((T, N), device=dev)
+        val_b = torch.empty((T, N), device=dev)
+        rew_b = torch.empty((T, N), device=dev)
+        done_b = torch.empty((T, N), dtype=torch.bool, device=dev)
+        obs = self.obs
+        for t in range(T):
+            a, logp, v = self.policy.act(obs)
+            obs_b[t], act_b[t], logp_b[t], val_b[t] = obs, a, logp, v
+            nobs, r, d, _ = env.step(a)           # tensors in, tensors out, no host round trip
+            rew_b[t], done_b[t] = r, d
+            obs = nobs.clone()
+        self.obs = obs
+        with torch.no_grad():
+            last_v = self.policy.value(obs)
+        adv, ret = gae(rew_b, val_b, done_b, last_v, self.gamma, self.lam)
+        return obs_b, act_b, logp_b, adv, ret, rew_b
+
+    def update(self, obs_b, act_b, logp_b, adv, ret):
+        n = obs_b.shape[0] * obs_b.shape[1]
+        obs_f, act_f = obs_b.reshape(n, -1), act_b.reshape(n, -1)
+        logp_f, adv_f, ret_f = logp_b.reshape(n), adv.reshape(n), ret.reshape(n)
+        adv_f = (adv_f - adv_f.mean()) / (adv_f.std() + 1e-8)
+        stats = {}
+        for _ in range(self.epochs):
+            perm = torch.randperm(n, device=obs_f.device)
+            for i in range(0, n, self.minibatch):
+                idx = perm[i:i + self.minibatch]
+                d = self.policy.dist(obs_f[idx])
+                logp = d.log_prob(act_f[idx]).sum(-1)
+                ratio = (logp - logp_f[idx]).exp()
+                a = adv_f[idx]
+                pg = -torch.min(ratio * a, ratio.clamp(1 - self.clip, 1 + self.clip) * a).mean()
+                vf = 0.5 * (self.policy.value(obs_f[idx]) - ret_f[idx]).pow(2).mean()
+                ent = d.entropy().sum(-1).mean()
+                loss = pg + vf - self.ent_coef * ent
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                self.opt.step()
+                stats = {"pg": float(pg), "vf": float(vf), "entropy": float(ent)}
+        return stats
+
+    def iterate(self):
+        obs_b, act_b, logp_b, adv, ret, rew = self.collect()
+        stats = self.update(obs_b, act_b, logp_b, adv, ret)
+        stats["mean_step_reward"] = float(rew.mean())
+        return stats
