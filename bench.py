@@ -83,15 +83,20 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="testing only: every rank uses cuda:0 (lets the N > 1 path run on a 1-GPU box with gloo)")
     args = ap.parse_args()
 
     rank, world, local_rank = pdist.rank_info()
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        pdist.init_process_group("nccl", device=dev)   # "nccl" is RCCL on ROCm
+        pdist.init_process_group(args.backend, device=dev)   # "nccl" is RCCL on ROCm
 
     N, K, W = args.envs, args.steps, args.warmup
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, env_gid_base=pdist.env_gid_base(rank, N),

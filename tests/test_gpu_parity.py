@@ -271,3 +271,59 @@ def test_step_halves_and_protocol_errors():
     o2, r2, d2, _ = env2.step(a)
     assert torch.equal(o, o2) and torch.equal(r, r2)
     env.close(); env2.close()
+
+
+def test_ring_overflow_is_flagged_not_silent():
+    """A ring too small for the packets in flight sets the sticky flag (results are then invalid)."""
+    env = pcc_rl_amd.BatchedNetworkEnv(64, device=DEV, seed=0, ring_capacity=16, auto_reset=False,
+                                       link_params=(100.0, 0.4, 2000.0, 0.0, 900.0))
+    env.reset()
+    for _ in range(5):
+        env.step(torch.ones(64, device=DEV))
+    with pytest.raises(pcc_rl_amd.PccError):
+        env.check_flags()
+    env.close()
+
+
+@pytest.mark.parametrize("params,feats,hist", [
+    ((300.0, 0.05, 40.0, 1.0, 250.0), "loss ratio,send rate", 1),        # every packet lost: no acks, no RTTs
+    ((120.0, 0.2, 1.0, 0.0, 500.0), "recv rate,avg latency,conn min latency,latency increase", 4),  # queue of one packet
+    ((450.0, 0.012, 3000.0, 0.02, 44.0), "send dur,recv dur,ack latency inflation", 2),             # starts at MIN_RATE
+])
+def test_edge_links_match_oracle(params, feats, hist):
+    n_envs, n_steps = 64, 80
+    rs = np.random.RandomState(9)
+    acts = rs.uniform(-1, 1, (n_envs, n_steps))
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=4, history_len=hist, features=feats,
+                                       record_steps=True, auto_reset=False, link_params=params)
+    obs0 = env.reset().cpu().numpy()
+    steps, obs, done = run_gpu(env, acts, n_steps)
+    p = np.tile(np.array(params)[None, :], (n_envs, 1))
+    ref = oracle.run_batch(acts, history_len=hist, features=feats, rng_mode=oracle.RNG_PHILOX, seed=4, params=p)
+    assert np.array_equal(obs0, ref["obs0"].astype(np.float32))
+    assert np.array_equal(steps, ref["steps"])
+    assert np.array_equal(obs, ref["obs"].astype(np.float32))
+    env.close()
+
+
+def test_masked_reset_only_touches_selected_envs():
+    n = 128
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=2, record_steps=True, auto_reset=False)
+    env.reset()
+    a = torch.zeros(n, device=DEV)
+    for _ in range(10):
+        env.step(a)
+    before_now = env.state("now").clone()
+    before_steps = env.state("steps").clone()
+    mask = torch.zeros(n, dtype=torch.bool, device=DEV)
+    mask[::3] = True
+    env.reset(mask)
+    now, steps, ep = env.state("now"), env.state("steps"), env.state("episode")
+    assert bool((steps[mask] == 0).all()) and bool((steps[~mask] == before_steps[~mask]).all())
+    assert bool((now[~mask] == before_now[~mask]).all())
+    assert bool((ep[mask] == 2).all()) and bool((ep[~mask] == 1).all())
+    # both groups keep stepping consistently afterwards (second episode of the reset ones = oracle's)
+    o, r, d, info = env.step(a)
+    assert bool(torch.isfinite(o).all())
+    env.check_flags()
+    env.close()
