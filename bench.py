@@ -69,10 +69,17 @@ def cpu_baseline(seconds_budget=20.0, threads=1):
         done_steps += n_envs * n_steps
         done_pk += float(out["steps"][..., 0].sum())
         base += n_envs
-    return {"value": done_steps / t_used, "unit": "env steps/s", "cores": threads, "kind": "port",
-            "sample": "%d env-steps (%d-env x %d-step batches of the bench workload, Philox uniforms, "
-                      "%.1f packets/step) on the C oracle, %d thread(s), %.1f s; host has %d cores"
-                      % (done_steps, n_envs, n_steps, done_pk / done_steps, threads, t_used, os.cpu_count() or 1)}
+    out = {"value": done_steps / t_used, "unit": "env steps/s", "cores": threads, "kind": "port",
+           "sample": "%d env-steps (%d-env x %d-step batches of the bench workload, Philox uniforms, "
+                     "%.1f packets/step) on the C oracle, %d thread(s), %.1f s; host has %d cores"
+                     % (done_steps, n_envs, n_steps, done_pk / done_steps, threads, t_used, os.cpu_count() or 1)}
+    # the same algorithm in the reference's own language (heapq + numpy), for scale: a few episodes
+    from oracle.pcc_oracle_py import time_episodes
+    py_steps, py_pk, py_s = time_episodes(1000, 2, n_steps=200)
+    out["python_port"] = {"value": py_steps / py_s, "unit": "env steps/s", "cores": 1,
+                          "sample": "%d env-steps, %.1f packets/step, %.1f s (oracle/pcc_oracle_py.py)"
+                                    % (py_steps, py_pk / py_steps, py_s)}
+    return out
 
 
 def main():

@@ -150,6 +150,13 @@ enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKET
                                     block's second ("heavy") wavefront from the start; default 4096 */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
+/* Load balancing of the send kernel: order is a device array [N] holding a permutation of the env
+ * ids (slot -> env); lane `slot % 64` of wavefront `slot / 64` sends for env order[slot].  NULL =
+ * identity.  Read at every following pcc_step / pcc_reset, so it must stay valid; results never
+ * depend on it.  A good order deals the envs with the most predicted packets (run_dur * rate)
+ * round-robin over the wavefronts (BatchedNetworkEnv(balance_every=...) does that). */
+int pcc_set_send_order(pcc_sim_t *sim, const uint32_t *order);
+
 /* DELTA_SCALE (src/common/config.py:17, default 0.025) and MAX_STEPS (ns:41, default 400) */
 int pcc_set_delta_scale(pcc_sim_t *sim, double delta_scale);
 int pcc_set_max_steps(pcc_sim_t *sim, int max_steps);

@@ -96,6 +96,7 @@ struct Dev {
     const double *trace;
     int64_t trace_stride;
     const double *p_bw, *p_dl, *p_queue, *p_loss, *p_rate0;
+    const uint32_t *send_order;  // optional [N]: send-kernel slot -> env id (load balancing), else identity
     // link + env state, [N]
     double *bw, *dl, *lr, *maxq, *ebw, *q, *tu, *now, *run_dur;
     uint32_t *steps, *episode, *flags;
@@ -370,8 +371,11 @@ __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32
     // hint only, every path is exact -- and the two waves touch disjoint envs, so nothing is shared.
     // Lanes without an env stay in the kernel: the wave path needs all 64 lanes as workers.
     const bool heavy_wave = threadIdx.x >= kWave;
-    const int64_t i = (int64_t)blockIdx.x * D.send_envs_per_wave + lane;
-    const bool in_range = lane < D.send_envs_per_wave && i < D.n;
+    const int64_t slot = (int64_t)blockIdx.x * D.send_envs_per_wave + lane;
+    const bool in_range = lane < D.send_envs_per_wave && slot < D.n;
+    // which env this lane sends for: a caller-supplied order (e.g. heaviest envs dealt round-robin
+    // over the wavefronts) only changes who waits for whom, never a result
+    const int64_t i = (in_range && D.send_order) ? (int64_t)D.send_order[slot] : slot;
     const bool flagged = NS == 1 && in_range && D.heavy_flag[in_range ? i : 0] != 0;
     const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]) && (flagged == heavy_wave);
     if (heavy_wave && !__ballot(live)) return;
@@ -1497,6 +1501,12 @@ int pcc_set_rng(pcc_sim_t *sim, int mode, const double *trace, int64_t trace_str
         return PCC_OK;
     }
     return fail(PCC_EINVAL, "unknown rng mode %d", mode);
+}
+
+int pcc_set_send_order(pcc_sim_t *sim, const uint32_t *order) {
+    if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    sim->d.send_order = order;
+    return PCC_OK;
 }
 
 int pcc_set_seed(pcc_sim_t *sim, uint64_t seed) {

@@ -54,7 +54,7 @@ class BatchedNetworkEnv(object):
 
     def __init__(self, n_envs, device="cuda", history_len=None, features=None, seed=0, n_senders=1,
                  link_params=None, env_gid_base=0, ring_capacity=0, auto_reset=True, delta_scale=None,
-                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False):
+                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False, balance_every=0):
         if history_len is None:
             history_len = arg_or_default("--history-len", default=10)
         if features is None:
@@ -96,6 +96,13 @@ class BatchedNetworkEnv(object):
         self._params = None
         self._trace = None
         self._was_reset = False
+        # optional send-kernel load balancing: every `balance_every` steps the envs are re-dealt over
+        # the wavefronts by predicted packets (0 = never, the default: on the benchmark workload it
+        # shortens late-episode steps and lengthens early ones, a wash; needs n_envs % 64 == 0)
+        self.balance_every = int(balance_every) if self.n_envs % 64 == 0 and self.n_envs >= 128 else 0
+        self._order = None
+        self._since_balance = 0
+        self._t = 0
         if link_params is not None:
             self.set_link_params(*(link_params.values() if isinstance(link_params, dict) else link_params))
 
@@ -193,6 +200,9 @@ class BatchedNetworkEnv(object):
                 raise ValueError("mask must be [n_envs]")
         check(self._L.pcc_reset(self._h, _ptr(m), _ptr(self._obs), self._stream()))
         self._was_reset = True
+        self._since_balance = self.balance_every  # re-deal at the next step: the links are new
+        if mask is None:
+            self._t = 0
         return self._out(self._obs)
 
     def _actions(self, actions):
@@ -206,8 +216,27 @@ class BatchedNetworkEnv(object):
                              % (a.numel(), self.n_envs * self.n_senders))
         return a.reshape(self.n_envs, self.n_senders).contiguous()
 
+    def rebalance(self):
+        """Deal the envs over the send kernel's wavefronts by predicted packets in the next interval
+        (run_dur * rate, summed over senders): rank r goes to wavefront r % n_waves, so every
+        wavefront gets the same share of heavy envs.  A performance hint only."""
+        pred = self.state("run_dur") * self.state("rate").sum(0)
+        ranks = torch.argsort(pred, descending=True)
+        n_waves = self.n_envs // 64
+        r = torch.arange(self.n_envs, device=self.device)
+        slot = (r % n_waves) * 64 + r // n_waves
+        order = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        order[slot] = ranks.to(torch.int32)
+        check(self._L.pcc_set_send_order(self._h, _ptr(order)))
+        self._order = order     # keep alive: the library reads it at every step
+        self._since_balance = 0
+
     def step_send(self, actions):
         """First half of step(): apply the actions and transmit the coming monitor interval's packets."""
+        if self.balance_every:
+            self._since_balance += 1
+            if self._since_balance >= self.balance_every:
+                self.rebalance()
         a = self._actions(actions)
         check(self._L.pcc_step_send(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, self._stream()))
 
@@ -215,6 +244,9 @@ class BatchedNetworkEnv(object):
         """Second half of step(): acknowledgements, losses, metrics; returns what step() returns."""
         check(self._L.pcc_step_retire(self._h, _ptr(self._obs), _ptr(self._reward), _ptr(self._done),
                                       _ptr(self._steps), 1 if self.auto_reset else 0, self._stream()))
+        self._t += 1
+        if self.auto_reset and self._t % self.max_steps == 0:
+            self._since_balance = self.balance_every  # the envs were just reset: re-deal at the next step
         info = {}
         if self._steps is not None:
             info["steps"] = self._out(self._steps)

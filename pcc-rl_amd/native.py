@@ -29,7 +29,7 @@ FIELDS = {
 
 # every symbol include/pcc_sim.h declares
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
-           "pcc_set_rng", "pcc_set_seed", "pcc_set_tuning", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
+           "pcc_set_rng", "pcc_set_seed", "pcc_set_send_order", "pcc_set_tuning", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
            "pcc_step_retire",
            "pcc_get_state", "pcc_metric_info", "pcc_device_bytes"]
 
@@ -66,6 +66,8 @@ def lib():
     L.pcc_set_param_ranges.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     L.pcc_set_rng.argtypes = [vp, i32, vp, i64]
     L.pcc_set_seed.argtypes = [vp, u64]
+    L.pcc_set_send_order.argtypes = [vp, vp]
+    L.pcc_set_send_order.restype = i32
     L.pcc_set_tuning.argtypes = [vp, i32, dbl]
     L.pcc_set_tuning.restype = i32
     L.pcc_set_delta_scale.argtypes = [vp, dbl]

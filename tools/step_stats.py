@@ -17,7 +17,8 @@ def main():
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 450
     out = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/step_stats.json"
     dev = torch.device("cuda:0")
-    env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, ring_capacity=int(os.environ.get("PCC_RING_CAP", 0)))
+    env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, ring_capacity=int(os.environ.get("PCC_RING_CAP", 0)),
+                                       balance_every=int(os.environ.get("PCC_BALANCE", 0)))
     if os.environ.get("PCC_HEAVY_PACKETS") or os.environ.get("PCC_HEAVY_RHO"):
         env.set_tuning(heavy_packets=float(os.environ.get("PCC_HEAVY_PACKETS", 1e18)),
                        heavy_rho=float(os.environ.get("PCC_HEAVY_RHO", 0.45)))
