@@ -799,7 +799,8 @@ __device__ __noinline__ double leaf_sum(const double2 *ring, uint32_t mask, uint
     for (int b = 0; b < 8; b++) v[b] = *reinterpret_cast<const double *>(base + ((o0 + 128u * b) & bmask));
     // lane e of the subgroup fetches leftover sample e (lane 7's load is unused)
     const double tv = *reinterpret_cast<const double *>(base + ((((beg + 8u * nblk + sl) << 4)) & bmask));
-    if (nblk > 8) {
+    const bool wide = __ballot(nblk > 8) != 0;  // wave-uniform: one control flow for all groups
+    if (wide) {
 #pragma unroll
         for (int b = 8; b < 16; b++) v[b] = *reinterpret_cast<const double *>(base + ((o0 + 128u * b) & bmask));
     }
@@ -809,7 +810,7 @@ __device__ __noinline__ double leaf_sum(const double2 *ring, uint32_t mask, uint
 #pragma unroll
         for (int b = 1; b < 8; b++)
             if ((uint32_t)b < nblk) r += v[b] + dl;
-        if (nblk > 8) {
+        if (wide) {
 #pragma unroll
             for (int b = 8; b < 16; b++)
                 if ((uint32_t)b < nblk) r += v[b] + dl;
@@ -895,15 +896,14 @@ __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, u
             r2 = n - n2;
             if (r2 > 128) { uint32_t x = r2 / 2; x -= x % 8; r3 = r2 - x; r2 = x; }
         }
+        // always the same three calls (a zero length costs nothing but the call), so the four env
+        // groups of a wavefront stay in one control flow whatever their list lengths
         const double a = leaf_sum(ring, mask, from, sub == 0 ? n2 : (halves ? half : 0u), dl, sl);
         const double b = leaf_sum(ring, mask, sub == 0 ? from + n2 : from + half,
                                   sub == 0 ? r2 : (halves ? n - half : 0u), dl, sl);
+        const double c = leaf_sum(ring, mask, from + n2 + r2, sub == 0 ? r3 : 0u, dl, sl);
         tot = a;
-        if (n > 128) {
-            double right = b;
-            if (r3) right = b + leaf_sum(ring, mask, from + n2 + r2, sub == 0 ? r3 : 0u, dl, sl);
-            tot = a + right;
-        }
+        if (n > 128) tot = a + (r3 ? b + c : b);
         first = a;
         second = b;
     } else if (sub == 0) {
