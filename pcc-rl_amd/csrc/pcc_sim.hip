@@ -141,11 +141,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __device__ __forceinline__ double u32_to_unit(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
 
-// loss uniform of the j-th SEND of sender s in monitor interval mi (the draw of ns:73)
+// loss uniform of the j-th SEND on the env's link (any sender) in monitor interval mi (the draw of
+// ns:73; one stream per env consumed in event order, like the reference's random.random())
 __device__ __forceinline__ double philox_packet_uniform(const Dev &D, uint32_t gid, uint32_t episode, uint32_t mi,
-                                                        int s, uint32_t j) {
+                                                        uint32_t j) {
     uint32_t w[4];
-    philox4x32_10(j >> 2, mi + ((uint32_t)s << 24), episode, gid, D.key0, D.key1, w);
+    philox4x32_10(j >> 2, mi, episode, gid, D.key0, D.key1, w);
     const uint32_t i = j & 3u;
     return u32_to_unit(i == 0 ? w[0] : i == 1 ? w[1] : i == 2 ? w[2] : w[3]);
 }
@@ -361,6 +362,149 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
     }
 }
 
+// Two senders on the shared link, one env, all 64 lanes.  Same exactness argument as heavy_mi; the
+// 64 packets of a pass are the first 64 of the (time, sender id) merge of the two senders'
+// arithmetic send sequences, found per lane by a merge-path search.
+struct SendState2 {
+    double q, tu, t[2];
+    uint32_t a[2], d[2], sent[2], flags;
+};
+
+template <bool TRACE>
+__device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl, double lr, uint32_t thr, bool always,
+                                          double maxq, double ebw, double gap0, double gap1, double end,
+                                          uint32_t episode, uint32_t mi, uint32_t gid, const double *trace, char *base0,
+                                          char *base1, SendState2 &st) {
+    const uint32_t mask_b = D.cap_mask << 4, dmask_b = D.dcap_mask << 4, cap_b = D.cap << 4;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const double gap[2] = {gap0, gap1};
+    while ((st.t[0] < st.t[1] ? st.t[0] : st.t[1]) < end) {
+        // ---- loss decisions of the next 64 packets of the merged stream
+        uint64_t rm;
+        if (TRACE) {
+            const uint64_t pos = (uint64_t)st.a[0] + st.d[0] + st.a[1] + st.d[1] + lane;
+            double u = 1.0;
+            if ((int64_t)pos < D.trace_stride) u = trace[pos];
+            rm = __ballot(u < lr);
+        } else {
+            const uint32_t j = st.sent[0] + st.sent[1] + lane;
+            uint32_t w[4];
+            philox4x32_10(j >> 2, mi, episode, gid, D.key0, D.key1, w);
+            const uint32_t x = (j & 3u) == 0 ? w[0] : (j & 3u) == 1 ? w[1] : (j & 3u) == 2 ? w[2] : w[3];
+            rm = __ballot(always || x < thr);
+        }
+        // ---- per-sender send sequences: t0 + k*G, exact while the preconditions hold
+        double G[2];
+        bool ok = (st.tu >= maxq);
+        double tend_max = 0.0;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const double t0 = st.t[s], t1s = t0 + gap[s];
+            G[s] = t1s - t0;
+            const double t2s = t1s + gap[s], tend = t0 + 64.0 * G[s];
+            ok = ok && (t2s - t1s == G[s]) && (t0 >= 128.0 * gap[s]) && (exponent_bits(t0) == exponent_bits(tend)) &&
+                 (G[s] > 0.0);
+            tend_max = tend > tend_max ? tend : tend_max;
+        }
+        ok = ok && (st.tu + st.tu >= tend_max);
+        double my_t = 0.0, my_lat = 0.0;
+        bool my_drop = true;
+        uint32_t my_s = 0, nv;
+        if (!ok) {
+            // ---- serial pass: the plain merged recurrence, wave-uniform, lane k keeps packet k
+            uint32_t k = 0;
+            for (; k < 64u; k++) {
+                const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(st.t[1] < st.t[0] ? 1 : 0));
+                const double t = s ? st.t[1] : st.t[0];
+                if (!__builtin_amdgcn_readfirstlane((int)(t < end))) break;
+                const bool rnd = (rm >> k) & 1ull;
+                bool dropped;
+                const double2 rec = link_send(t, rnd, dl, maxq, ebw, st.q, st.tu, dropped);
+                if (lane == k) { my_t = rec.x; my_lat = rec.y; my_drop = dropped; my_s = s; }
+                if (s) st.t[1] = t + gap[1];
+                else st.t[0] = t + gap[0];
+            }
+            nv = k;
+        } else {
+            // ---- merge path: c = how many of sender 0's packets precede merged position `lane`
+            // (sender 0 first on equal times); smallest c with B[lane-c-1] < A[c]
+            uint32_t lo = 0, hi = lane;
+            while (lo < hi) {
+                const uint32_t c = (lo + hi) >> 1;
+                const double Ac = st.t[0] + (double)c * G[0];
+                const double Bp = st.t[1] + (double)(lane - c - 1) * G[1];
+                if (Bp < Ac) hi = c;
+                else lo = c + 1;
+            }
+            const uint32_t c0 = lo, c1 = lane - lo;
+            const double A = st.t[0] + (double)c0 * G[0], B = st.t[1] + (double)c1 * G[1];
+            my_s = (A <= B) ? 0u : 1u;
+            const double tk = my_s ? B : A;
+            const bool valid = tk < end;
+            const uint64_t vmask = __ballot(valid);
+            nv = (uint32_t)__popcll(vmask);  // merged times increase: valid lanes are a prefix
+            const uint64_t rmask = rm;
+            // phase 1: accepted packet to accepted packet
+            double qm = st.q, tm = st.tu;
+            uint64_t open = vmask & ~rmask, amask = 0;
+            uint32_t na = 0;
+            double seg_q = 0.0, seg_t = 0.0;
+            while (open) {
+                const double qc = max0(qm - (tk - tm));
+                const bool full = ebw + qc > maxq;
+                const uint64_t cm = open & ~__ballot(full);
+                if (!cm) break;
+                const uint32_t ks = (uint32_t)__ffsll((unsigned long long)cm) - 1u;
+                qm = rl_f64(ebw + qc, ks);
+                tm = rl_f64(tk, ks);
+                if (lane == na) { seg_q = qm; seg_t = tm; }
+                na++;
+                amask |= 1ull << ks;
+                open &= ~((2ull << ks) - 1ull);
+            }
+            // phase 2: every lane finishes its own packet
+            const uint32_t seg = (uint32_t)__popcll(amask & lt);
+            const int src = seg ? (int)seg - 1 : 0;
+            double q_seg = __shfl(seg_q, src), t_seg = __shfl(seg_t, src);
+            if (!seg) { q_seg = st.q; t_seg = st.tu; }
+            const double qc = max0(q_seg - (tk - t_seg));
+            my_lat = dl + qc;
+            my_drop = !((amask >> lane) & 1ull);
+            const double my_q_after = my_drop ? qc : ebw + qc;
+            my_t = tk + my_lat;
+            const uint64_t touch = vmask & ~rmask;
+            if (touch) {
+                const uint32_t kl = 63u - (uint32_t)__clzll((long long)touch);
+                st.q = rl_f64(my_q_after, kl);
+                st.tu = rl_f64(tk, kl);
+            }
+            const uint32_t n1 = (uint32_t)__popcll(__ballot(valid && my_s == 1u)), n0 = nv - n1;
+            st.t[0] = st.t[0] + (double)n0 * G[0];   // exact
+            st.t[1] = st.t[1] + (double)n1 * G[1];
+        }
+        // ---- records: four dense runs (sender x accepted/dropped)
+        const bool valid = lane < nv;
+        if (TRACE && (int64_t)((uint64_t)st.a[0] + st.d[0] + st.a[1] + st.d[1] + nv) > D.trace_stride)
+            st.flags |= PCC_FLAG_TRACE_OVERRUN;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const uint64_t dm = __ballot(valid && my_s == (uint32_t)s && my_drop);
+            const uint64_t am = __ballot(valid && my_s == (uint32_t)s && !my_drop);
+            if (valid && my_s == (uint32_t)s) {
+                double2 rec;
+                rec.x = my_t;
+                rec.y = my_lat;
+                const uint32_t off = my_drop ? cap_b + (((st.d[s] + (uint32_t)__popcll(dm & lt)) << 4) & dmask_b)
+                                             : (((st.a[s] + (uint32_t)__popcll(am & lt)) << 4) & mask_b);
+                *reinterpret_cast<double2 *>((s ? base1 : base0) + off) = rec;
+            }
+            st.a[s] += (uint32_t)__popcll(am);
+            st.d[s] += (uint32_t)__popcll(dm);
+            st.sent[s] += (uint32_t)__popcll(am) + (uint32_t)__popcll(dm);
+        }
+    }
+}
+
 template <int NS, bool TRACE>
 __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32_t warm_mi, const void *actions,
                                                          int actions_f64) {
@@ -376,7 +520,7 @@ __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32
     // which env this lane sends for: a caller-supplied order (e.g. heaviest envs dealt round-robin
     // over the wavefronts) only changes who waits for whom, never a result
     const int64_t i = (in_range && D.send_order) ? (int64_t)D.send_order[slot] : slot;
-    const bool flagged = NS == 1 && in_range && D.heavy_flag[in_range ? i : 0] != 0;
+    const bool flagged = in_range && D.heavy_flag[in_range ? i : 0] != 0;
     const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]) && (flagged == heavy_wave);
     if (heavy_wave && !__ballot(live)) return;
     const int64_t ii = live ? i : 0;
@@ -516,39 +660,104 @@ __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32
         nsend[0] = t;
         sent[0] = (a - ta[0]) + (d - td[0]);
         ta[0] = a; td[0] = d;
-    } else if (run) {
-        // two senders merged in (time, sender id) order
-        uint32_t w[NS][4];
+    } else {
+        // two senders merged in (time, sender id) order: lane-serial rounds, then the tail of the
+        // wave goes to the two-sender wave path
+        const double thr_d = ceil(lr * 4294967296.0);
+        const bool always = thr_d >= 4294967296.0;
+        const uint32_t thr = always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
+        char *bases[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) bases[s] = reinterpret_cast<char *>(ring_of<NS>(D, ii, s, 0));
+        bool active = run && !heavy_wave, heavy_now = run && heavy_wave;
+        uint32_t blk = 0;  // Philox block = packets of this MI sent on the link / 4
         for (;;) {
-            int s = 0;
-            if (NS > 1 && nsend[NS - 1] < nsend[0]) s = NS - 1;
-            const double t = (NS > 1 && s) ? nsend[NS - 1] : nsend[0];
-            if (!(t < end)) break;
+            if (active) {
+                if (!TRACE) {
+                    // lockstep blocks of four packets of the merged stream; the sender of a packet
+                    // is a select, not a branch, so lanes with different interleavings stay together
+                    for (uint32_t budget4 = D.round_packets / 4;
+                         budget4 && (nsend[NS - 1] < nsend[0] ? nsend[NS - 1] : nsend[0]) < end; budget4--) {
+                        uint32_t w[4];
+                        philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                        blk++;
 #pragma unroll
-            for (int ss = 0; ss < NS; ss++) {
-                if (ss != s) continue;
-                double u;
-                if (TRACE) {
-                    uint64_t pos = 0;
-#pragma unroll
-                    for (int x = 0; x < NS; x++) pos += (uint64_t)ta[x] + td[x];
-                    if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
-                    else u = trace[pos];
+                        for (int k = 0; k < 4; k++) {
+                            const bool s1 = nsend[NS - 1] < nsend[0];  // equal times: sender 0 first (heap order)
+                            const double t = s1 ? nsend[NS - 1] : nsend[0];
+                            if (k > 0 && !(t < end)) break;
+                            bool dropped;
+                            const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
+                            const uint32_t a_s = s1 ? ta[NS - 1] : ta[0], d_s = s1 ? td[NS - 1] : td[0];
+                            const uint32_t off = dropped ? cap_b + ((d_s << 4) & dmask_b) : ((a_s << 4) & mask_b);
+                            *reinterpret_cast<double2 *>((s1 ? bases[NS - 1] : bases[0]) + off) = rec;
+                            const uint32_t acc = dropped ? 0u : 1u, drp = dropped ? 1u : 0u;
+                            if (s1) {
+                                ta[NS - 1] += acc; td[NS - 1] += drp; sent[NS - 1]++;  // ns:260-262
+                                nsend[NS - 1] = t + gap[NS - 1];                       // ns:161
+                            } else {
+                                ta[0] += acc; td[0] += drp; sent[0]++;
+                                nsend[0] = t + gap[0];
+                            }
+                        }
+                    }
                 } else {
-                    const uint32_t j = sent[ss];
-                    if ((j & 3u) == 0u) philox4x32_10(j >> 2, mi + ((uint32_t)ss << 24), episode, gid, D.key0, D.key1, w[ss]);
-                    const uint32_t x = (j & 3u) == 0 ? w[ss][0] : (j & 3u) == 1 ? w[ss][1] : (j & 3u) == 2 ? w[ss][2] : w[ss][3];
-                    u = u32_to_unit(x);
+                    for (uint32_t budget = D.round_packets; budget; budget--) {
+                        const bool s1 = nsend[NS - 1] < nsend[0];
+                        const double t = s1 ? nsend[NS - 1] : nsend[0];
+                        if (!(t < end)) break;
+                        uint64_t pos = 0;
+#pragma unroll
+                        for (int x = 0; x < NS; x++) pos += (uint64_t)ta[x] + td[x];
+                        double u = 1.0;
+                        if ((int64_t)pos >= D.trace_stride) flags |= PCC_FLAG_TRACE_OVERRUN;
+                        else u = trace[pos];
+                        bool dropped;
+                        const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
+                        const uint32_t a_s = s1 ? ta[NS - 1] : ta[0], d_s = s1 ? td[NS - 1] : td[0];
+                        const uint32_t off = dropped ? cap_b + ((d_s << 4) & dmask_b) : ((a_s << 4) & mask_b);
+                        *reinterpret_cast<double2 *>((s1 ? bases[NS - 1] : bases[0]) + off) = rec;
+                        const uint32_t acc = dropped ? 0u : 1u, drp = dropped ? 1u : 0u;
+                        if (s1) {
+                            ta[NS - 1] += acc; td[NS - 1] += drp; sent[NS - 1]++;
+                            nsend[NS - 1] = t + gap[NS - 1];
+                        } else {
+                            ta[0] += acc; td[0] += drp; sent[0]++;
+                            nsend[0] = t + gap[0];
+                        }
+                    }
                 }
-                sent[ss]++;                       // ns:260-262
-                nsend[ss] = t + gap[ss];          // ns:161
-                bool dropped;
-                const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
-                char *base = reinterpret_cast<char *>(ring_of<NS>(D, ii, ss, 0));
-                const uint32_t off = dropped ? cap_b + ((td[ss] << 4) & dmask_b) : ((ta[ss] << 4) & mask_b);
-                *reinterpret_cast<double2 *>(base + off) = rec;
-                ta[ss] += dropped ? 0u : 1u;
-                td[ss] += dropped ? 1u : 0u;
+                active = (nsend[NS - 1] < nsend[0] ? nsend[NS - 1] : nsend[0]) < end;
+            }
+            const uint64_t am = __ballot(active);
+            if (!am) break;
+            if ((uint32_t)__popcll(am) <= D.takeover_lanes) {
+                heavy_now = heavy_now || active;
+                break;
+            }
+        }
+        uint64_t hm = __ballot(heavy_now);
+        while (hm) {
+            const uint32_t l = (uint32_t)__ffsll((unsigned long long)hm) - 1u;
+            hm &= hm - 1ull;
+            SendState2 st;
+            st.q = rl_f64(q, l); st.tu = rl_f64(tu, l); st.flags = 0;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                st.t[s] = rl_f64(nsend[s < NS ? s : 0], l);
+                st.a[s] = rl_u32(ta[s < NS ? s : 0], l); st.d[s] = rl_u32(td[s < NS ? s : 0], l);
+                st.sent[s] = rl_u32(sent[s < NS ? s : 0], l);
+            }
+            heavy_mi2<TRACE>(D, lane, rl_f64(dl, l), rl_f64(lr, l), rl_u32(thr, l), rl_u32(always ? 1u : 0u, l) != 0u,
+                             rl_f64(maxq, l), rl_f64(ebw, l), rl_f64(gap[0], l), rl_f64(gap[NS - 1], l), rl_f64(end, l),
+                             rl_u32(episode, l), rl_u32(mi, l), rl_u32(gid, l),
+                             reinterpret_cast<const double *>(rl_u64(reinterpret_cast<uint64_t>(trace), l)),
+                             reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(bases[0]), l)),
+                             reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(bases[NS - 1]), l)), st);
+            if (lane == l) {
+                q = st.q; tu = st.tu; flags |= st.flags;
+#pragma unroll
+                for (int s = 0; s < NS; s++) { nsend[s] = st.t[s]; ta[s] = st.a[s]; td[s] = st.d[s]; sent[s] = st.sent[s]; }
             }
         }
     }
@@ -1077,8 +1286,11 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
                     if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
                     else u = D.trace[i * D.trace_stride + pos];
                 } else {
+                    uint32_t j = 0;
+#pragma unroll
+                    for (int x = 0; x < NS; x++) j += sent[x];
                     u = philox_packet_uniform(D, D.gid_base + (uint32_t)i, D.episode[i] - 1,
-                                              warm ? warm_mi : steps + 2, s, sent[s]);
+                                              warm ? warm_mi : steps + 2, j);
                 }
                 const double rate = D.rate[(int64_t)s * D.n + i];
                 sent[s]++;
@@ -1183,7 +1395,9 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
         D.run_dur[i] = new_run_dur;
         // prediction for the next MI's send kernel: packets ~ MI length x current rate (the next
         // action moves the rate by at most a few percent)
-        if (NS == 1) D.heavy_flag[i] = new_run_dur * D.rate[i] > D.heavy_predict ? 1 : 0;
+        double rate_sum = 0.0;
+        for (int s = 0; s < NS; s++) rate_sum += D.rate[(int64_t)s * D.n + i];
+        D.heavy_flag[i] = new_run_dur * rate_sum > D.heavy_predict ? 1 : 0;
         D.steps[i] = steps + 1;
         const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
         D.done[i] = done;

@@ -240,6 +240,44 @@ def test_send_paths_are_exact_whatever_the_tuning(knobs):
     env.close()
 
 
+@pytest.mark.parametrize("knobs", [
+    dict(),                                              # defaults: rounds, then the two-sender wave path
+    dict(takeover_lanes=0),                              # lane-serial only
+    dict(takeover_lanes=64, round_packets=8),            # merge-path wave passes for almost everything
+    dict(takeover_lanes=64, round_packets=4, heavy_predict=200.0),
+])
+def test_two_sender_philox_batches_match_oracle(knobs):
+    """BASELINE.json configs[4] shape (two senders on one link) at a size the oracle finishes in
+    seconds: per-sender Philox streams, merged send order, both senders' rows and observations."""
+    n_envs, n_steps, seed = 500, 100, 33
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, n_senders=2, record_steps=True,
+                                       auto_reset=False)
+    env.set_tuning(**knobs)
+    env.reset()
+    rs = np.random.RandomState(seed)
+    acts = rs.uniform(-1, 1.5, (n_envs, n_steps, 2))
+    steps, obs, done = run_gpu(env, acts, n_steps)
+    ref = oracle.run_batch(acts, n_senders=2, rng_mode=oracle.RNG_PHILOX, seed=seed)
+    bad = np.argwhere((steps[..., :3] != ref["steps"][..., :3]).any(axis=tuple(range(1, steps.ndim))))
+    assert bad.size == 0, "envs with count mismatches: %s" % bad[:10].ravel()
+    assert np.array_equal(steps, ref["steps"])
+    assert np.array_equal(obs, ref["obs"].astype(np.float32))
+    env.close()
+
+
+def test_two_sender_wave_path_on_golden_trace():
+    d = load("two_sender")
+    d["features"] = np.array(pcc_rl_amd.DEFAULT_FEATURES.split(","))
+    env = golden_env(d, n_senders=2)
+    env.set_tuning(takeover_lanes=64, round_packets=4)
+    env.reset()
+    env.set_tuning(takeover_lanes=64, round_packets=4)
+    T = d["actions"].shape[1]
+    steps, obs, _ = run_gpu(env, d["actions"], T)
+    assert np.array_equal(steps, d["steps"])
+    env.close()
+
+
 def test_wave_path_on_golden_traces():
     """Trace mode through the wave path: the saturating and deep-queue goldens with every env handed
     to the heavy wavefront."""
