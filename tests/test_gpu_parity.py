@@ -248,7 +248,7 @@ def test_send_paths_are_exact_whatever_the_tuning(knobs):
 ])
 def test_two_sender_philox_batches_match_oracle(knobs):
     """BASELINE.json configs[4] shape (two senders on one link) at a size the oracle finishes in
-    seconds: per-sender Philox streams, merged send order, both senders' rows and observations."""
+    seconds: one Philox stream per env consumed in merged send order, both senders' rows and observations."""
     n_envs, n_steps, seed = 500, 100, 33
     env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, n_senders=2, record_steps=True,
                                        auto_reset=False)
