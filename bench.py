@@ -29,11 +29,12 @@ from pcc_rl_amd import distributed as pdist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Algorithmic bytes per env-step: 450 B of fixed traffic + 32 B per packet
-# (one 16-B in-flight record written at send, read at completion).  Split over the two kernels of
-# a step: the send kernel reads the action (4), link parameters (32), and
-# reads+writes link state (2x16) and sender rate/next_send/cursors (2x26) = 120 B, and writes the
-# 16-B record; the retire kernel owns the remaining 330 B (state, history, obs/reward/done) and
-# reads the record.
+# (one 16-B in-flight record written at send, read at completion).  A step is ONE launch
+# (step_kernel: a workgroup sends for its 64 envs, then retires them).  With --split the two
+# halves run as separate launches (send_kernel, retire_kernel) and are timed apart: the send half
+# reads the action (4), link parameters (32), and reads+writes link state (2x16) and sender
+# rate/next_send/cursors (2x26) = 120 B, and writes the 16-B record; the retire half owns the
+# remaining 330 B (state, history, obs/reward/done) and reads the record.
 B_FIXED_SEND, B_FIXED_RETIRE, B_PACKET_HALF = 120, 330, 16
 
 
@@ -41,7 +42,7 @@ def pmc_traffic():
     """HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     separate passes over this same script; see profiles/README.md).  Counters cannot be read from
     inside the process, so the figure is the profile's, labelled with its source."""
-    for name in ("r01_v5_pmc_hbm.json",):
+    for name in ("r01_v6_pmc_hbm.json",):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -91,6 +92,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--no-fuse", action="store_true", help="pcc_step as two launches instead of the fused step_kernel")
+    ap.add_argument("--split", action="store_true",
+                    help="run the step as two launches (send_kernel + retire_kernel) and time them apart")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (lets the N > 1 path run on a 1-GPU box with gloo)")
     args = ap.parse_args()
@@ -111,6 +115,8 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = 64
     actions = torch.rand((pool, N), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
+    if args.no_fuse:
+        env.set_tuning(fused_step=0)
     env.reset()
     returns_gathered = 0
     gather_buf = torch.empty((world * N,), dtype=torch.float32, device=dev) if world > 1 else None
@@ -119,10 +125,13 @@ def main():
         nonlocal returns_gathered
         if ev is not None:
             ev[0].record()
-        env.step_send(actions[t % pool])
-        if ev is not None:
-            ev[1].record()
-        env.step_retire()
+        if args.split:
+            env.step_send(actions[t % pool])
+            if ev is not None:
+                ev[1].record()
+            env.step_retire()
+        else:
+            env.step(actions[t % pool])
         if ev is not None:
             ev[2].record()
         if world > 1 and (t + 1) % env.max_steps == 0:
@@ -152,10 +161,13 @@ def main():
 
     packets = float((env.state("total_sent").sum() - sent0).item())
     env.check_flags()
-    # steps that also ran the episode-boundary reset kernels are kept out of the retire average
     plain = [k for k in range(K) if (W + k + 1) % env.max_steps != 0]
-    send_ms = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
-    retire_ms = sum(ev[k][1].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))
+    # steps that also ran the episode-boundary reset kernels are kept out of the kernel averages
+    if args.split:
+        send_ms = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
+        retire_ms = sum(ev[k][1].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))
+    else:
+        step_ms = sum(ev[k][0].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))
 
     elapsed = pdist.max_over_ranks(elapsed, device=dev)     # MAX over ranks (bench contract)
 
@@ -164,8 +176,6 @@ def main():
         pk_per_step = packets / (N * K)
         send_bytes = N * (B_FIXED_SEND + B_PACKET_HALF * pk_per_step)
         retire_bytes = N * (B_FIXED_RETIRE + B_PACKET_HALF * pk_per_step)
-        send_gbps = send_bytes / (send_ms * 1e-3) / 1e9
-        retire_gbps = retire_bytes / (retire_ms * 1e-3) / 1e9
         out = {
             "metric": "env steps/sec (whole node) at 64k parallel envs",
             "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -175,21 +185,31 @@ def main():
                                    "(ICML'19 ranges), U(-1,1) actions, 400-step episodes, auto-reset" % N,
                        "envs_per_gpu": N, "packets_per_env_step": pk_per_step,
                        "episode_return_allgathers": returns_gathered},
-            # dominant kernel of a step; the other kernel of the step is listed beside it
-            "roofline": {"bound": "hbm", "kernel": "send_kernel<1, false>", "achieved": send_gbps,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": send_gbps / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel_ms": send_ms, "algorithmic_bytes_per_launch": send_bytes,
-                         "other_kernels": [{"kernel": "retire_kernel<1>", "achieved": retire_gbps,
-                                            "frac": retire_gbps / HBM_PEAK_GBPS, "kernel_ms": retire_ms,
-                                            "algorithmic_bytes_per_launch": retire_bytes}],
-                         "whole_step": {"achieved": (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9,
-                                        "frac": (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS}},
         }
+        if args.split:
+            send_gbps = send_bytes / (send_ms * 1e-3) / 1e9
+            retire_gbps = retire_bytes / (retire_ms * 1e-3) / 1e9
+            both = (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "send_kernel<1, false>", "achieved": send_gbps,
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": send_gbps / HBM_PEAK_GBPS,
+                               "traffic": None, "kernel_ms": send_ms, "algorithmic_bytes_per_launch": send_bytes,
+                               "other_kernels": [{"kernel": "retire_kernel<1>", "achieved": retire_gbps,
+                                                  "frac": retire_gbps / HBM_PEAK_GBPS, "kernel_ms": retire_ms,
+                                                  "algorithmic_bytes_per_launch": retire_bytes}],
+                               "whole_step": {"achieved": both, "frac": both / HBM_PEAK_GBPS}}
+        else:
+            # the step IS the dominant kernel: one launch per step
+            step_bytes = send_bytes + retire_bytes
+            gbps = step_bytes / (step_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "step_kernel<1, false>", "achieved": gbps,
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                               "traffic": None, "kernel_ms": step_ms, "algorithmic_bytes_per_launch": step_bytes,
+                               "algorithmic_bytes_per_env_step": B_FIXED_SEND + B_FIXED_RETIRE + 2 * B_PACKET_HALF * pk_per_step}
         pmc, src = pmc_traffic()
-        if pmc and N == 65536:
-            out["roofline"]["traffic"] = pmc["send_kernel<1, false>"]["hbm_bytes_per_launch_raw"]
-            out["roofline"]["traffic_source"] = src + " (steps 20..120 of an episode; raw FETCH_SIZE+WRITE_SIZE, KB units x 1024)"
-            out["roofline"]["other_kernels"][0]["traffic"] = pmc["retire_kernel<1>"]["hbm_bytes_per_launch_raw"]
+        kname = out["roofline"]["kernel"]
+        if pmc and N == 65536 and kname in pmc:
+            out["roofline"]["traffic"] = pmc[kname]["hbm_bytes_per_launch_raw"]
+            out["roofline"]["traffic_source"] = src + " (raw FETCH_SIZE+WRITE_SIZE, KB units x 1024)"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         elif world == 1:

@@ -91,6 +91,7 @@ enum {
 
 #define PCC_FLAG_RING_OVERFLOW 1u  /* more accepted or dropped packets in flight than ring_capacity: results invalid */
 #define PCC_FLAG_TRACE_OVERRUN 2u  /* PCC_RNG_TRACE ran past trace_stride */
+#define PCC_FLAG_INTERNAL 4u       /* (env 0 only) the fused step's retire queue timed out: results invalid, a bug */
 
 /* last error text of the calling thread ("" if none) */
 const char *pcc_last_error(void);
@@ -147,7 +148,12 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
 enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_SEND_ENVS_PER_WAVE = 4 /* envs per 64-lane wavefront in the send kernel, 1..64 */,
        PCC_TUNE_HEAVY_PREDICT = 5 /* predicted packets per interval above which an env is sent by the
-                                    block's second ("heavy") wavefront from the start; default 4096 */ };
+                                    block's second ("heavy") wavefront from the start; default 4096 */,
+       PCC_TUNE_FUSED_STEP = 6 /* 1 (default): pcc_step is ONE launch -- every workgroup sends for its 64
+                                  envs, then retires envs of whichever blocks are done sending (its
+                                  own first), so the retire work fills the SIMDs idle during the send
+                                  tail -- whenever the whole grid is resident at once (65 536 envs
+                                  are); 0, or a larger grid: pcc_step_send + pcc_step_retire */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* Load balancing of the send kernel: order is a device array [N] holding a permutation of the env
@@ -207,6 +213,17 @@ int pcc_metric_info(int id, double *min_val, double *max_val, double *scale);
 
 /* bytes of device memory the handle owns */
 int64_t pcc_device_bytes(const pcc_sim_t *sim);
+
+/* Profiling aid, no reference counterpart.  When the handle was created with the environment
+ * variable PCC_DEBUG_TIMELINE=1, every send wavefront of the LAST step leaves 8 words: start, end
+ * of its lane rounds, end (100 MHz device ticks), envs it sent with the wave path, packets it
+ * sent, packets of its largest env, packets sent by the wave path, live lanes.  Wavefront w of
+ * env block b (send_envs_per_wave envs) is at word (2*b + w) * 8; w = 1 is the block's heavy
+ * wavefront.  After those 2 * blocks entries come `blocks` workgroup entries of the fused step:
+ * block published, workgroup exit, retire items it processed.  Synchronizes the device.  Returns
+ * the number of words (3 * blocks * 8) -- copied, or needed when out is NULL; 0 when the timeline is
+ * off, < 0 on error. */
+int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,8 @@ struct Dev {
     uint32_t key0, key1, gid_base;
     double delta_scale;
     uint32_t max_steps;
+    uint32_t *steal;     // step_kernel's retire queue: [0] blocks done sending, [1] next item, [2..] ready list
+    uint64_t *timeline;  // profiling only (PCC_DEBUG_TIMELINE env): 8 words per send wavefront, see pcc_debug_timeline
     int debug_skip;  // profiling only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs
     double heavy_packets, heavy_rho;  // tuning: when the send kernel hands an env to the wave path
     uint32_t round_packets, takeover_lanes, send_envs_per_wave;
@@ -126,12 +128,21 @@ __device__ __forceinline__ bool key_less(double ta, double ya, double tb, double
     return (__double_as_longlong(ya) >= 0) && (__double_as_longlong(yb) < 0);
 }
 
+__device__ __forceinline__ uint64_t mul_wide_u32(uint32_t a, uint32_t b) {
+    uint64_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "vcc");
+    return r;
+}
+
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one v_mad_u64_u32 per 32x32->64 product (integer multiplies are quarter rate: the
+        // compiler's mul_hi + mul_lo pair costs twice as much)
+        const uint64_t p0 = mul_wide_u32(c0, 0xD2511F53u), p1 = mul_wide_u32(c2, 0xCD9E8D57u);
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -506,16 +517,16 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
 }
 
 template <int NS, bool TRACE>
-__global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32_t warm_mi, const void *actions,
-                                                         int actions_f64) {
-    const uint32_t lane = threadIdx.x & (kWave - 1);
+__device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, const uint32_t tid, int warm,
+                                          uint32_t warm_mi, const void *actions, int actions_f64) {
+    const uint32_t lane = tid & (kWave - 1);
     // Two wavefronts per block of envs.  Wave 0 ("light") runs the lane-per-env rounds for the envs
     // NOT flagged heavy; wave 1 ("heavy") sends the flagged envs one after the other with all 64
     // lanes (heavy_mi).  The flag is the previous retire's prediction for this MI -- a performance
     // hint only, every path is exact -- and the two waves touch disjoint envs, so nothing is shared.
     // Lanes without an env stay in the kernel: the wave path needs all 64 lanes as workers.
-    const bool heavy_wave = threadIdx.x >= kWave;
-    const int64_t slot = (int64_t)blockIdx.x * D.send_envs_per_wave + lane;
+    const bool heavy_wave = tid >= kWave;
+    const int64_t slot = (int64_t)block * D.send_envs_per_wave + lane;
     const bool in_range = lane < D.send_envs_per_wave && slot < D.n;
     // which env this lane sends for: a caller-supplied order (e.g. heaviest envs dealt round-robin
     // over the wavefronts) only changes who waits for whom, never a result
@@ -524,6 +535,8 @@ __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32
     const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]) && (flagged == heavy_wave);
     if (heavy_wave && !__ballot(live)) return;
     const int64_t ii = live ? i : 0;
+    const uint64_t tl0 = D.timeline ? wall_clock64() : 0;
+    uint64_t tl1 = 0, tl_heavy = 0, tl_heavy_pk = 0;
 
     const double dl = D.dl[ii], lr = D.lr[ii], maxq = D.maxq[ii], ebw = D.ebw[ii];
     double q = D.q[ii], tu = D.tu[ii];
@@ -643,6 +656,12 @@ __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32
         }
         // heavy envs of this wave (standing or tail take-over), one after the other, 64 lanes each
         uint64_t hm = __ballot(heavy_now);
+        if (D.timeline) {
+            tl1 = wall_clock64();
+            tl_heavy = (uint64_t)__popcll(hm);
+            tl_heavy_pk = (uint64_t)0 - ((a - ta[0]) + (d - td[0]));  // completed below with the final count
+            if (!heavy_now) tl_heavy_pk = 0;
+        }
         while (hm) {
             const uint32_t l = (uint32_t)__ffsll((unsigned long long)hm) - 1u;
             hm &= hm - 1ull;
@@ -660,6 +679,7 @@ __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32
         nsend[0] = t;
         sent[0] = (a - ta[0]) + (d - td[0]);
         ta[0] = a; td[0] = d;
+        if (D.timeline && heavy_now) tl_heavy_pk += sent[0];
     } else {
         // two senders merged in (time, sender id) order: lane-serial rounds, then the tail of the
         // wave goes to the two-sender wave path
@@ -762,6 +782,22 @@ __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32
         }
     }
 
+    if (D.timeline) {
+        // words: start, end of the lane rounds, end (100 MHz ticks), envs sent by the wave path,
+        // packets of the wave, packets of its largest env, packets sent by the wave path, live lanes
+        uint64_t sum = live ? sent[0] : 0, mx = sum, hp = tl_heavy_pk;
+        for (int o = 32; o; o >>= 1) {
+            sum += __shfl_xor(sum, o);
+            hp += __shfl_xor(hp, o);
+            const uint64_t other = __shfl_xor(mx, o);
+            mx = other > mx ? other : mx;
+        }
+        if (lane == 0) {
+            uint64_t *w = D.timeline + ((int64_t)block * 2 + (heavy_wave ? 1 : 0)) * 8;
+            w[0] = tl0; w[1] = tl1; w[2] = wall_clock64(); w[3] = tl_heavy; w[4] = sum; w[5] = mx; w[6] = hp;
+            w[7] = (uint64_t)__popcll(__ballot(live));
+        }
+    }
     if (!live) return;
     D.q[i] = q; D.tu[i] = tu;
 #pragma unroll
@@ -774,6 +810,12 @@ __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, int warm, uint32
         D.mi_sent[k] = sent[s];
     }
     if (flags) D.flags[i] |= flags;
+}
+
+template <int NS, bool TRACE>
+__global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, uint32_t block0, int warm, uint32_t warm_mi,
+                                                         const void *actions, int actions_f64) {
+    send_wave<NS, TRACE>(D, block0 + blockIdx.x, threadIdx.x, warm, warm_mi, actions, actions_f64);
 }
 
 // ======================================================================================
@@ -1162,15 +1204,9 @@ __device__ __forceinline__ double select_metric(const double (&m)[PCC_N_METRICS]
 }
 
 template <int NS>
-__global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, uint32_t warm_mi, int last_warm,
-                                                              float *obs_out, float *reward_out, uint8_t *done_out,
-                                                              double *steps_out) {
-    const uint32_t tid = threadIdx.x;
-    Group g;
-    g.lane = tid & (kGroup - 1);
-    g.shift = (tid & (kWave - 1)) & ~(uint32_t)(kGroup - 1);
-    const int64_t i = (int64_t)blockIdx.x * (kRetireBlock / kGroup) + (tid / kGroup);
-    if (i >= D.n) return;
+__device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const Group g, int warm, uint32_t warm_mi,
+                                           int last_warm, float *obs_out, float *reward_out, uint8_t *done_out,
+                                           double *steps_out) {
     if (warm && !D.resetting[i]) return;
     const bool lead = g.lane == 0;
     const uint32_t mask = D.cap_mask, dmask = D.dcap_mask;
@@ -1405,6 +1441,107 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int warm, u
     }
 }
 
+template <int NS>
+__global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int64_t slot0, int64_t slot_end, int warm,
+                                                              uint32_t warm_mi, int last_warm, float *obs_out,
+                                                              float *reward_out, uint8_t *done_out, double *steps_out) {
+    const uint32_t tid = threadIdx.x;
+    Group g;
+    g.lane = tid & (kGroup - 1);
+    g.shift = (tid & (kWave - 1)) & ~(uint32_t)(kGroup - 1);
+    // slots [slot0, slot_end) of the send order: the envs one chunk's send launch transmitted for
+    const int64_t slot = slot0 + (int64_t)blockIdx.x * (kRetireBlock / kGroup) + (tid / kGroup);
+    if (slot >= slot_end) return;
+    const int64_t i = D.send_order ? (int64_t)D.send_order[slot] : slot;
+    retire_env<NS>(D, i, g, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out);
+}
+
+// ======================================================================================
+// step_kernel: one whole monitor interval per launch.  A workgroup of four wavefronts owns a block
+// of 64 envs: wavefronts 0/1 send for them (send_wave), then all four retire envs, 16 at a time.
+// Send times are tail-bound -- a few wavefronts carry envs with thousands of packets while most
+// finish early -- so a separate retire launch waits for the slowest wavefront of the whole chip
+// with most SIMDs idle.  Here a workgroup that is done sending publishes its block in a ready list
+// and then takes retire items (16 envs of a ready block) off a global queue until none are left:
+// early finishers retire their own envs and then wait for the stragglers' blocks, whose retire work
+// is spread over all the waiting workgroups the moment they finish sending.  Which workgroup
+// retires an env never changes a result.
+//   steal[0]  blocks published so far (monotone over steps; base_ready = its value at launch)
+//   steal[1]  items claimed so far (monotone; every workgroup ends with exactly one failed claim)
+//   steal[2+k] the k-th block to finish this step, tagged with the step number
+// Waiting is only safe when every workgroup of the grid is resident: the host launches this kernel
+// only for grids the device holds at once (pcc_step falls back to send_kernel + retire_kernel).
+// ======================================================================================
+constexpr int kStepWaves = 4;
+constexpr uint32_t kStealSpinLimit = 1u << 20;  // x ~1 us: a bug must not hang the GPU
+
+template <int NS, bool TRACE>
+__global__ __launch_bounds__(kStepWaves * kWave, 4) void step_kernel(Dev D, uint32_t base_ready, uint32_t base_next,
+                                                                  uint32_t tag, const void *actions, int actions_f64,
+                                                                  float *obs_out, float *reward_out, uint8_t *done_out,
+                                                                  double *steps_out) {
+    __shared__ uint32_t sh_item, sh_block;
+    const uint32_t tid = threadIdx.x;
+    if (tid < 2 * kWave) send_wave<NS, TRACE>(D, blockIdx.x, tid, 0, 0u, actions, actions_f64);
+    // the records and cursors the send wavefronts wrote are read by whoever retires the block
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    constexpr uint32_t kPerItem = kStepWaves * kWave / kGroup;  // envs per retire item
+    const uint32_t items_per_block = (D.send_envs_per_wave + kPerItem - 1) / kPerItem;
+    const uint32_t total_items = gridDim.x * items_per_block;
+    uint64_t tl_sent = 0;
+    if (tid == 0) {
+        const uint32_t pos = atomicAdd(&D.steal[0], 1u) - base_ready;
+        __hip_atomic_store(&D.steal[2 + pos], (tag << 16) | blockIdx.x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (D.timeline) tl_sent = wall_clock64();
+    }
+    Group g;
+    g.lane = tid & (kGroup - 1);
+    g.shift = (tid & (kWave - 1)) & ~(uint32_t)(kGroup - 1);
+    uint32_t n_items = 0;
+    for (;;) {
+        if (tid == 0) {
+            const uint32_t t = atomicAdd(&D.steal[1], 1u) - base_next;
+            uint32_t b = 0;
+            if (t < total_items) {
+                const uint32_t k = t / items_per_block;
+                uint32_t v, spins = 0;
+                while (((v = __hip_atomic_load(&D.steal[2 + k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 16) != tag) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (++spins > kStealSpinLimit) break;
+                }
+                b = v & 0xFFFFu;
+                if ((v >> 16) != tag) {  // never expected: flag it instead of hanging
+                    D.flags[0] |= PCC_FLAG_INTERNAL;
+                    sh_item = 0xFFFFFFFFu;
+                } else {
+                    sh_item = t;
+                }
+            } else {
+                sh_item = 0xFFFFFFFFu;
+            }
+            sh_block = b;
+        }
+        __syncthreads();
+        const uint32_t t = sh_item, b = sh_block;
+        if (t == 0xFFFFFFFFu) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t in_block = (t % items_per_block) * kPerItem + tid / kGroup;
+        const int64_t slot = (int64_t)b * D.send_envs_per_wave + in_block;
+        if (in_block < D.send_envs_per_wave && slot < D.n) {
+            const int64_t i = D.send_order ? (int64_t)D.send_order[slot] : slot;
+            retire_env<NS>(D, i, g, 0, 0u, 0, obs_out, reward_out, done_out, steps_out);
+        }
+        n_items++;
+        __syncthreads();
+    }
+    if (D.timeline && tid == 0) {
+        // block-level words after the 2 x n_envs wavefront entries: sent/published, exit, items retired here
+        uint64_t *w = D.timeline + ((int64_t)2 * D.n + blockIdx.x) * 8;
+        w[0] = tl_sent; w[1] = wall_clock64(); w[2] = n_items;
+    }
+}
+
 // ======================================================================================
 // reset_init_kernel: ns:454-477 -- parameters, fresh link/sender/history state.  The two warm-up
 // MIs (ns:478-479) are run by send_kernel / retire_kernel in warm mode on the marked envs.
@@ -1480,10 +1617,17 @@ struct pcc_sim {
     size_t state_bytes;
     void *ring_blob;
     size_t ring_bytes;
+    void *timeline_blob;
+    size_t timeline_bytes;
     bool ever_reset;
     bool lockstep;      // every env was last reset by the same full reset (host knows when `done` fires)
     uint32_t host_steps;
     bool send_pending;  // pcc_step_send issued, pcc_step_retire not yet
+    bool fused_step;    // pcc_step runs step_kernel (send + work-stealing retire in one launch) when the grid fits
+    int fused_capacity; // workgroups of step_kernel the device holds at once
+    int fused_capacity_key;
+    uint32_t steal_ready_base, steal_next_base;  // values the two queue counters start a step with
+    uint32_t steal_tag;                          // step number, tags the ready list entries
 };
 
 namespace {
@@ -1519,6 +1663,7 @@ size_t carve_state(Dev &d, char *base) {
     d.maxq = c.take<double>(n); d.ebw = c.take<double>(n); d.q = c.take<double>(n);
     d.tu = c.take<double>(n); d.now = c.take<double>(n); d.run_dur = c.take<double>(n);
     d.steps = c.take<uint32_t>(n); d.episode = c.take<uint32_t>(n); d.flags = c.take<uint32_t>(n);
+    d.steal = c.take<uint32_t>(n + 2);
     d.done = c.take<uint8_t>(n); d.resetting = c.take<uint8_t>(n); d.heavy_flag = c.take<uint8_t>(n);
     d.total_sent = c.take<unsigned long long>(n);
     d.rate = c.take<double>(sn); d.rate0 = c.take<double>(sn); d.next_send = c.take<double>(sn);
@@ -1535,38 +1680,85 @@ int check_hip(hipError_t err, const char *what) {
 }
 
 dim3 lane_grid(const Dev &d) { return dim3((unsigned)((d.n + kWave - 1) / kWave)); }
-dim3 group_grid(const Dev &d) {
-    const int64_t per_block = kRetireBlock / kGroup;
-    return dim3((unsigned)((d.n + per_block - 1) / per_block));
-}
-
-// the SEND half of one monitor interval, for all envs (warm = 0) or the envs being reset (warm = 1)
-int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, const void *actions, int actions_f64, hipStream_t st) {
+// SEND half of one monitor interval for the env blocks [block0, block0 + n_blocks) of
+// send_envs_per_wave envs each: all envs (warm = 0) or the envs being reset (warm = 1)
+int launch_send_blocks(pcc_sim_t *sim, uint32_t block0, uint32_t n_blocks, int warm, uint32_t warm_mi,
+                       const void *actions, int actions_f64, hipStream_t st) {
     const Dev &d = sim->d;
     const bool tr = d.rng_mode == PCC_RNG_TRACE;
+    const dim3 sgrid(n_blocks), sblock(2 * kWave);
     if (d.ns == 1) {
-        const dim3 sgrid((unsigned)((d.n + d.send_envs_per_wave - 1) / d.send_envs_per_wave));
-        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), sgrid, dim3(2 * kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<1, false>), sgrid, dim3(2 * kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<1, false>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
     } else {
-        const dim3 sgrid((unsigned)((d.n + d.send_envs_per_wave - 1) / d.send_envs_per_wave));
-        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), sgrid, dim3(2 * kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<2, false>), sgrid, dim3(2 * kWave), 0, st, d, warm, warm_mi, actions, actions_f64);
+        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<2, false>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
     }
     return check_hip(hipGetLastError(), "send kernel launch");
 }
 
-// the RETIRE half: acknowledgements, losses, the MI-ending event, metrics and outputs
+// RETIRE half for the send-order slots [slot0, slot_end)
+int launch_retire_slots(pcc_sim_t *sim, int64_t slot0, int64_t slot_end, int warm, uint32_t warm_mi, int last_warm,
+                        float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
+    const Dev &d = sim->d;
+    const int64_t per_block = kRetireBlock / kGroup;
+    const dim3 grid((unsigned)((slot_end - slot0 + per_block - 1) / per_block));
+    if (d.ns == 1)
+        hipLaunchKernelGGL(retire_kernel<1>, grid, dim3(kRetireBlock), 0, st, d, slot0, slot_end, warm, warm_mi,
+                           last_warm, obs_out, reward_out, done_out, steps_out);
+    else
+        hipLaunchKernelGGL(retire_kernel<2>, grid, dim3(kRetireBlock), 0, st, d, slot0, slot_end, warm, warm_mi,
+                           last_warm, obs_out, reward_out, done_out, steps_out);
+    return check_hip(hipGetLastError(), "retire kernel launch");
+}
+
+uint32_t send_blocks(const Dev &d) { return (uint32_t)((d.n + d.send_envs_per_wave - 1) / d.send_envs_per_wave); }
+
+int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, const void *actions, int actions_f64, hipStream_t st) {
+    return launch_send_blocks(sim, 0, send_blocks(sim->d), warm, warm_mi, actions, actions_f64, st);
+}
+
 int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, float *obs_out, float *reward_out,
                   uint8_t *done_out, double *steps_out, hipStream_t st) {
+    return launch_retire_slots(sim, 0, sim->d.n, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out, st);
+}
+
+// one whole MI in one launch (step_kernel); only for grids the device holds at once
+int launch_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_out, float *reward_out,
+                uint8_t *done_out, double *steps_out, hipStream_t st) {
     const Dev &d = sim->d;
-    if (d.ns == 1)
-        hipLaunchKernelGGL(retire_kernel<1>, group_grid(d), dim3(kRetireBlock), 0, st, d, warm, warm_mi, last_warm,
-                           obs_out, reward_out, done_out, steps_out);
-    else
-        hipLaunchKernelGGL(retire_kernel<2>, group_grid(d), dim3(kRetireBlock), 0, st, d, warm, warm_mi, last_warm,
-                           obs_out, reward_out, done_out, steps_out);
-    return check_hip(hipGetLastError(), "retire kernel launch");
+    const bool tr = d.rng_mode == PCC_RNG_TRACE;
+    const uint32_t blocks = send_blocks(d);
+    const dim3 grid(blocks), block(kStepWaves * kWave);
+    const uint32_t br = sim->steal_ready_base, bn = sim->steal_next_base, tag = sim->steal_tag & 0xFFFFu;
+    if (d.ns == 1) {
+        if (tr) hipLaunchKernelGGL((step_kernel<1, true>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
+        else hipLaunchKernelGGL((step_kernel<1, false>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
+    } else {
+        if (tr) hipLaunchKernelGGL((step_kernel<2, true>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
+        else hipLaunchKernelGGL((step_kernel<2, false>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
+    }
+    const uint32_t per_item = kStepWaves * kWave / kGroup;
+    const uint32_t items = blocks * ((d.send_envs_per_wave + per_item - 1) / per_item);
+    sim->steal_ready_base += blocks;
+    sim->steal_next_base += items + blocks;  // every workgroup ends with exactly one failed claim
+    sim->steal_tag++;
+    return check_hip(hipGetLastError(), "step kernel launch");
+}
+
+// workgroups of step_kernel resident at once on this device, for the handle's instantiation
+int step_capacity(pcc_sim_t *sim) {
+    const Dev &d = sim->d;
+    const bool tr = d.rng_mode == PCC_RNG_TRACE;
+    int per_cu = 0;
+    hipError_t e;
+    if (d.ns == 1) e = tr ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<1, true>, kStepWaves * kWave, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<1, false>, kStepWaves * kWave, 0);
+    else e = tr ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<2, true>, kStepWaves * kWave, 0)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<2, false>, kStepWaves * kWave, 0);
+    hipDeviceProp_t prop;
+    if (e != hipSuccess || hipGetDeviceProperties(&prop, sim->device) != hipSuccess) return 0;
+    return per_cu * prop.multiProcessorCount;
 }
 
 int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, const void *actions, int actions_f64,
@@ -1646,6 +1838,9 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.takeover_lanes = 2;
     d.send_envs_per_wave = 64;
     d.heavy_predict = 4096.0;
+    sim->fused_step = !(getenv("PCC_FUSED_STEP") && atoi(getenv("PCC_FUSED_STEP")) == 0);
+    sim->steal_tag = 1;  // the zero-initialised ready list must not look published
+    sim->fused_capacity_key = -1;
     d.debug_skip = getenv("PCC_DEBUG_SKIP") ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;
     d.heavy_rho = 0.45;
     const double lo[5] = {100, 0.05, 0, 0.0, 0.3}, hi[5] = {500, 0.5, 8, 0.05, 1.5};  // ns:355-358,466
@@ -1671,13 +1866,40 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         pcc_destroy(sim);
         return fail(PCC_EHIP, "hipMemset of env state failed");
     }
+    if (getenv("PCC_DEBUG_TIMELINE") && atoi(getenv("PCC_DEBUG_TIMELINE"))) {
+        sim->timeline_bytes = (size_t)n_envs * 3 * 8 * sizeof(uint64_t);
+        if (hipMalloc(&sim->timeline_blob, sim->timeline_bytes) != hipSuccess ||
+            hipMemset(sim->timeline_blob, 0, sim->timeline_bytes) != hipSuccess) {
+            pcc_destroy(sim);
+            return fail(PCC_ENOMEM, "hipMalloc for the debug timeline failed");
+        }
+        d.timeline = static_cast<uint64_t *>(sim->timeline_blob);
+    }
     *out = sim;
     return PCC_OK;
+}
+
+int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words) {
+    if (!sim || !sim->timeline_blob) return 0;
+    DeviceGuard guard(sim->device);
+    const int64_t blocks = send_blocks(sim->d);
+    const int64_t total = blocks * 3 * 8;
+    if (!out || n_words <= 0) return total;
+    if (n_words < total) return fail(PCC_EINVAL, "pcc_debug_timeline needs room for %lld words", (long long)total);
+    const char *src = static_cast<const char *>(sim->timeline_blob);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(out, src, (size_t)blocks * 2 * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(out + blocks * 2 * 8, src + (size_t)sim->d.n * 2 * 8 * sizeof(uint64_t),
+                  (size_t)blocks * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(PCC_EHIP, "reading the debug timeline failed");
+    return total;
 }
 
 void pcc_destroy(pcc_sim_t *sim) {
     if (!sim) return;
     DeviceGuard guard(sim->device);
+    if (sim->timeline_blob) (void)hipFree(sim->timeline_blob);
+
     if (sim->state_blob) (void)hipFree(sim->state_blob);
     if (sim->ring_blob) (void)hipFree(sim->ring_blob);
     delete sim;
@@ -1744,6 +1966,7 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             sim->d.send_envs_per_wave = (uint32_t)value;
             return PCC_OK;
         case PCC_TUNE_HEAVY_PREDICT: sim->d.heavy_predict = value; return PCC_OK;
+        case PCC_TUNE_FUSED_STEP: sim->fused_step = value != 0.0; return PCC_OK;
         case PCC_TUNE_TAKEOVER_LANES:
             if (value < 0 || value > 64) return fail(PCC_EINVAL, "takeover_lanes out of range");
             sim->d.takeover_lanes = (uint32_t)value;
@@ -1780,6 +2003,27 @@ int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream)
     return PCC_OK;
 }
 
+namespace {
+// host bookkeeping after the MI of a step: episode boundary, auto-reset (ns:444, the gym wrapper's reset)
+int after_mi(pcc_sim_t *sim, float *obs_out, int auto_reset, hipStream_t st) {
+    const Dev &d = sim->d;
+    sim->host_steps++;
+    if (auto_reset) {
+        // when every env is in lockstep the host knows which step finishes the episode and
+        // skips the (otherwise no-op) masked reset launches
+        const bool may_be_done = !sim->lockstep || sim->host_steps >= d.max_steps;
+        if (may_be_done) {
+            const int rc = launch_reset(sim, nullptr, 1, obs_out, st);
+            if (rc != PCC_OK) return rc;
+            if (sim->lockstep) sim->host_steps = 0;
+        }
+    } else if (sim->lockstep && sim->host_steps >= d.max_steps) {
+        sim->lockstep = false;  // caller resets on its own schedule from here on
+    }
+    return PCC_OK;
+}
+}  // namespace
+
 int pcc_step_send(pcc_sim_t *sim, const void *actions, int actions_f64, void *stream) {
     if (!sim || !actions) return fail(PCC_EINVAL, "NULL argument");
     if (!sim->ever_reset) return fail(PCC_ESTATE, "pcc_step before pcc_reset (the reference raises TypeError: run_dur is None)");
@@ -1795,32 +2039,39 @@ int pcc_step_retire(pcc_sim_t *sim, float *obs_out, float *reward_out, uint8_t *
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     if (!sim->send_pending) return fail(PCC_ESTATE, "pcc_step_retire without a preceding pcc_step_send");
     DeviceGuard guard(sim->device);
-    const Dev &d = sim->d;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = launch_retire(sim, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
+    const int rc = launch_retire(sim, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
     sim->send_pending = false;
-    sim->host_steps++;
-    if (auto_reset) {
-        // when every env is in lockstep the host knows which step finishes the episode and
-        // skips the (otherwise no-op) masked reset launches
-        const bool may_be_done = !sim->lockstep || sim->host_steps >= d.max_steps;
-        if (may_be_done) {
-            rc = launch_reset(sim, nullptr, 1, obs_out, st);
-            if (rc != PCC_OK) return rc;
-            if (sim->lockstep) sim->host_steps = 0;
-        }
-    } else if (sim->lockstep && sim->host_steps >= d.max_steps) {
-        sim->lockstep = false;  // caller resets on its own schedule from here on
-    }
-    return PCC_OK;
+    return after_mi(sim, obs_out, auto_reset, st);
 }
 
 int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_out, float *reward_out,
              uint8_t *done_out, double *steps_out, int auto_reset, void *stream) {
-    const int rc = pcc_step_send(sim, actions, actions_f64, stream);
+    if (!sim || !actions) return fail(PCC_EINVAL, "NULL argument");
+    if (!sim->ever_reset) return fail(PCC_ESTATE, "pcc_step before pcc_reset (the reference raises TypeError: run_dur is None)");
+    if (sim->send_pending) return fail(PCC_ESTATE, "pcc_step between pcc_step_send and pcc_step_retire");
+    DeviceGuard guard(sim->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    bool fused = sim->fused_step;
+    if (fused) {
+        // the occupancy answer depends on the kernel instantiation (senders, rng mode)
+        const int key = sim->d.ns * 2 + (sim->d.rng_mode == PCC_RNG_TRACE ? 1 : 0);
+        if (sim->fused_capacity_key != key) {
+            sim->fused_capacity = step_capacity(sim);
+            sim->fused_capacity_key = key;
+        }
+        fused = (int64_t)send_blocks(sim->d) <= sim->fused_capacity && send_blocks(sim->d) <= 0xFFFFu;
+    }
+    int rc;
+    if (fused) {
+        rc = launch_step(sim, actions, actions_f64, obs_out, reward_out, done_out, steps_out, st);
+    } else {
+        rc = launch_send(sim, 0, 0, actions, actions_f64, st);
+        if (rc == PCC_OK) rc = launch_retire(sim, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
+    }
     if (rc != PCC_OK) return rc;
-    return pcc_step_retire(sim, obs_out, reward_out, done_out, steps_out, auto_reset, stream);
+    return after_mi(sim, obs_out, auto_reset, st);
 }
 
 int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {

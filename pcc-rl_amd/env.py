@@ -163,8 +163,10 @@ class BatchedNetworkEnv(object):
         self._trace = t
 
     def set_tuning(self, heavy_packets=None, heavy_rho=None, round_packets=None, takeover_lanes=None,
-                   send_envs_per_wave=None, heavy_predict=None):
-        """Performance knobs of the send kernel (results do not depend on them)."""
+                   send_envs_per_wave=None, heavy_predict=None, fused_step=None):
+        """Performance knobs of the step kernels (results do not depend on them)."""
+        if fused_step is not None:
+            check(self._L.pcc_set_tuning(self._h, 6, float(fused_step)))
         if heavy_predict is not None:
             check(self._L.pcc_set_tuning(self._h, 5, float(heavy_predict)))
         if send_envs_per_wave is not None:
@@ -233,10 +235,7 @@ class BatchedNetworkEnv(object):
 
     def step_send(self, actions):
         """First half of step(): apply the actions and transmit the coming monitor interval's packets."""
-        if self.balance_every:
-            self._since_balance += 1
-            if self._since_balance >= self.balance_every:
-                self.rebalance()
+        self._balance_tick()
         a = self._actions(actions)
         check(self._L.pcc_step_send(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, self._stream()))
 
@@ -244,6 +243,15 @@ class BatchedNetworkEnv(object):
         """Second half of step(): acknowledgements, losses, metrics; returns what step() returns."""
         check(self._L.pcc_step_retire(self._h, _ptr(self._obs), _ptr(self._reward), _ptr(self._done),
                                       _ptr(self._steps), 1 if self.auto_reset else 0, self._stream()))
+        return self._step_result()
+
+    def _balance_tick(self):
+        if self.balance_every:
+            self._since_balance += 1
+            if self._since_balance >= self.balance_every:
+                self.rebalance()
+
+    def _step_result(self):
         self._t += 1
         if self.auto_reset and self._t % self.max_steps == 0:
             self._since_balance = self.balance_every  # the envs were just reset: re-deal at the next step
@@ -253,8 +261,14 @@ class BatchedNetworkEnv(object):
         return self._out(self._obs), self._out(self._reward), self._done.view(torch.bool), info
 
     def step(self, actions):
-        self.step_send(actions)
-        return self.step_retire()
+        """One monitor interval for every env (ns:407-446 batched): obs, reward, done, info.  One
+        library call (pcc_step: by default one fused send + retire launch)."""
+        self._balance_tick()
+        a = self._actions(actions)
+        check(self._L.pcc_step(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, _ptr(self._obs),
+                               _ptr(self._reward), _ptr(self._done), _ptr(self._steps),
+                               1 if self.auto_reset else 0, self._stream()))
+        return self._step_result()
 
     # ------------------------------------------------------------------ introspection
     def state(self, name):
@@ -277,11 +291,24 @@ class BatchedNetworkEnv(object):
         if bad:
             over = int(((flags & native.PCC_FLAG_RING_OVERFLOW) != 0).sum().item())
             tr = int(((flags & native.PCC_FLAG_TRACE_OVERRUN) != 0).sum().item())
+            if int(((flags & native.PCC_FLAG_INTERNAL) != 0).sum().item()):
+                raise PccError(-6, "internal error: the fused step's retire queue timed out")
             raise PccError(-6, "%d envs overflowed the in-flight ring, %d ran past the loss trace" % (over, tr))
 
     @property
     def device_bytes(self):
         return int(self._L.pcc_device_bytes(self._h))
+
+    def debug_timeline(self):
+        """[send wavefronts, 8] uint64 of the last send launch (PCC_DEBUG_TIMELINE=1 at creation;
+        see pcc_debug_timeline in include/pcc_sim.h), or None when the timeline is off."""
+        import numpy as np
+        n = int(self._L.pcc_debug_timeline(self._h, None, 0))
+        if n <= 0:
+            return None
+        out = np.zeros(n, dtype=np.uint64)
+        got = int(self._L.pcc_debug_timeline(self._h, out.ctypes.data, n))
+        return out[:got].reshape(-1, 8)
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

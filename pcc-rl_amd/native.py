@@ -8,7 +8,7 @@ import os
 from .build import library_path
 
 PCC_RNG_PHILOX, PCC_RNG_TRACE = 0, 1
-PCC_FLAG_RING_OVERFLOW, PCC_FLAG_TRACE_OVERRUN = 1, 2
+PCC_FLAG_RING_OVERFLOW, PCC_FLAG_TRACE_OVERRUN, PCC_FLAG_INTERNAL = 1, 2, 4
 PCC_STEP_COLS = 19
 STEP_COLUMNS = ["sent", "acked", "lost", "rate", "cur_time", "run_dur", "reward",
                 "send rate", "recv rate", "recv dur", "send dur", "avg latency", "loss ratio",
@@ -31,7 +31,7 @@ FIELDS = {
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
            "pcc_set_rng", "pcc_set_seed", "pcc_set_send_order", "pcc_set_tuning", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
            "pcc_step_retire",
-           "pcc_get_state", "pcc_metric_info", "pcc_device_bytes"]
+           "pcc_get_state", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline"]
 
 
 class PccError(RuntimeError):
@@ -80,6 +80,8 @@ def lib():
     L.pcc_metric_info.argtypes = [i32, ctypes.POINTER(dbl), ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     L.pcc_device_bytes.restype = i64
     L.pcc_device_bytes.argtypes = [vp]
+    L.pcc_debug_timeline.restype = i64
+    L.pcc_debug_timeline.argtypes = [vp, vp, i64]
     for fn in ("pcc_create", "pcc_set_link_params", "pcc_set_param_ranges", "pcc_set_rng", "pcc_set_seed",
                "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
                "pcc_step_retire", "pcc_get_state", "pcc_metric_info"):

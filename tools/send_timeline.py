@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Per-wavefront timeline of the send kernel at chosen steps of an episode (GPU box only).
+
+    PCC_DEBUG_TIMELINE=1 python tools/send_timeline.py [n_envs] > gpurun_out/timeline.json
+
+For each sampled step: kernel span, when the light wavefronts finished their lane rounds, how the
+slowest wavefronts spent their time (rounds vs wave path), packets they carried."""
+import json
+import os
+import sys
+
+os.environ.setdefault("PCC_DEBUG_TIMELINE", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import pcc_rl_amd
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+dev = torch.device("cuda:0")
+env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
+for k, v in os.environ.items():
+    if k.startswith("PCC_TUNE_"):
+        env.set_tuning(**{k[9:].lower(): float(v)})
+gen = torch.Generator(device=dev).manual_seed(1234)
+acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
+env.reset()
+out = []
+sample = {2, 10, 30, 60, 100, 150, 200, 250, 300, 350, 398}
+for t in range(400):
+    env.step_send(acts[t % 64])
+    if t in sample:
+        tl = env.debug_timeline().astype(np.int64)
+        tl = tl[tl[:, 0] > 0]
+        t0 = tl[:, 0].min()
+        start, mid, fin = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0   # us
+        heavy_wave = np.arange(len(tl))  # placeholder, the heavy wavefronts are the ones with 0 round time and w[3] > 0
+        order = np.argsort(-fin)[:8]
+        pct = lambda x: [float(np.percentile(x, p)) for p in (50, 90, 99, 100)]
+        rec = {"step": t, "waves": int(len(tl)), "span_us": float(fin.max()),
+               "start_us_p50_p90_p99_max": pct(start),
+               "rounds_end_us": pct(mid), "finish_us": pct(fin),
+               "packets_total": int(tl[:, 4].sum()), "wave_path_packets": int(tl[:, 6].sum()),
+               "wave_path_envs": int(tl[:, 3].sum()),
+               "busy_wave_us_total": float((fin - start).sum()),
+               "slowest": [{"start": float(start[i]), "rounds_end": float(mid[i]), "finish": float(fin[i]),
+                            "wave_path_envs": int(tl[i, 3]), "packets": int(tl[i, 4]), "largest_env": int(tl[i, 5]),
+                            "wave_path_packets": int(tl[i, 6]), "live": int(tl[i, 7])} for i in order]}
+        out.append(rec)
+    env.step_retire()
+print(json.dumps(out, indent=1))
