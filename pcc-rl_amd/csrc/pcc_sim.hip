@@ -1035,60 +1035,112 @@ __device__ __noinline__ void drop_hop1_candidate(const double2 *ring, uint32_t m
 // leaf is random access: an 8-lane subgroup loads its <= 16 strided samples per lane in one
 // round trip (lane j owns r[j]) and folds with __shfl_xor.
 // --------------------------------------------------------------------------------------
-__device__ __noinline__ double leaf_sum(const double2 *ring, uint32_t mask, uint32_t beg, uint32_t len, double dl,
-                                        uint32_t sl) {
-    // Kept out of line on purpose: inlined copies let the compiler hoist every copy's loads to the
-    // top and the kernel's register count explodes.  Loads are unconditional -- any ring index is
-    // a valid address -- and only the adds are guarded; byte offsets wrap with one AND.
-    const uint32_t nblk = len >> 3;  // <= 16 full blocks of 8 ...
-    const uint32_t ntail = len & 7u; // ... and < 8 leftover samples, added one by one at the end
-    const char *base = reinterpret_cast<const char *>(ring) + 8;  // .y of record 0
-    const uint32_t bmask = mask << 4;
-    const uint32_t o0 = ((beg + sl) << 4) & bmask;
-    double v[16];
-#pragma unroll
-    for (int b = 0; b < 8; b++) v[b] = *reinterpret_cast<const double *>(base + ((o0 + 128u * b) & bmask));
-    // lane e of the subgroup fetches leftover sample e (lane 7's load is unused)
-    const double tv = *reinterpret_cast<const double *>(base + ((((beg + 8u * nblk + sl) << 4)) & bmask));
-    const bool wide = __ballot(nblk > 8) != 0;  // wave-uniform: one control flow for all groups
-    if (wide) {
-#pragma unroll
-        for (int b = 8; b < 16; b++) v[b] = *reinterpret_cast<const double *>(base + ((o0 + 128u * b) & bmask));
-    }
-    double x = 0.;
-    if (nblk) {
-        double r = v[0] + dl;
-#pragma unroll
-        for (int b = 1; b < 8; b++)
-            if ((uint32_t)b < nblk) r += v[b] + dl;
-        if (wide) {
-#pragma unroll
-            for (int b = 8; b < 16; b++)
-                if ((uint32_t)b < nblk) r += v[b] + dl;
-        }
-        x = r;
-        x = x + __shfl_xor(x, 1, 8);
-        x = x + __shfl_xor(x, 2, 8);
-        x = x + __shfl_xor(x, 4, 8);
-    }
-#pragma unroll
-    for (int e = 0; e < 7; e++) {
-        const double te = __shfl(tv, e, 8);
-        if ((uint32_t)e < ntail) x += te + dl;
-    }
+struct LeafPair { double a, b; };
+
+// x + (x of lane ^ 1), x + (x of lane ^ 2), x + (x of the mirrored lane of the 8-lane half row) as
+// DPP moves: one VALU-class operation each instead of a trip through the LDS crossbar.  Adds are
+// commutative, so the mirrored partner (lane 7 - j, which holds the other quad's sum) gives the
+// same ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) in every lane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(phi, plo);
+}
+__device__ __forceinline__ double fold8(double x) {
+    x = x + dpp_f64<0xB1>(x);   // quad_perm:[1,0,3,2]
+    x = x + dpp_f64<0x4E>(x);   // quad_perm:[2,3,0,1]
+    x = x + dpp_f64<0x141>(x);  // row_half_mirror
     return x;
 }
 
-// DOUBLE_pairwise_sum of n <= 8192 samples starting at ring index beg: the recursion walked
-// left to right with an explicit stack (depth <= 6)
-__device__ __forceinline__ double pairwise_sum(const double2 *ring, uint32_t mask, uint32_t beg, uint32_t n, double dl,
-                                               uint32_t sl) {
+// Two leaves per call, one memory round trip: leaf A = [begA, begA + lenA) with lenA <= 128, and,
+// when lenA < 72 (at most 8 full blocks), leaf B = [begB, begB + lenB) with lenB < 72 in the
+// upper eight load slots that a long leaf A would use itself.  (lenB must be 0 when lenA >= 72.)
+// Lane j of the 8-lane subgroup owns accumulator r[j] and loads only the samples it adds (the L1
+// request rate, not the bytes, is what the sums are bound by).  The < 8 leftover samples sit one
+// per lane and are added, in order, in the subgroup's lane 0: ONLY LANE 0 of each subgroup returns
+// the leaf sums, the other lanes return garbage.
+__device__ __noinline__ LeafPair leaf_sum2(const double2 *ring, uint32_t mask, uint32_t begA, uint32_t lenA,
+                                              uint32_t begB, uint32_t lenB, double dl, uint32_t sl) {
+    const uint32_t nblkA = lenA >> 3, nblkB = lenB >> 3;  // full blocks of 8 ...
+    const uint32_t ntA = lenA & 7u, ntB = lenB & 7u;      // ... and < 8 leftover samples, added one by one at the end
+    const char *base = reinterpret_cast<const char *>(ring) + 8;  // .y of record 0
+    const uint32_t bmask = mask << 4;
+    const uint32_t oA = ((begA + sl) << 4) & bmask;
+    const bool wideA = nblkA > 8;
+    const uint32_t o2 = wideA ? oA + 1024u : ((begB + sl) << 4);  // upper bank: blocks 8.. of A, or B
+    const uint32_t n2 = wideA ? nblkA - 8u : nblkB;
+    double v[16], tvA = 0., tvB = 0.;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        v[b] = 0.;
+        if ((uint32_t)b < nblkA) v[b] = *reinterpret_cast<const double *>(base + ((oA + 128u * b) & bmask));
+    }
+    if (sl < ntA) tvA = *reinterpret_cast<const double *>(base + ((((begA + 8u * nblkA + sl) << 4)) & bmask));
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        v[8 + b] = 0.;
+        if ((uint32_t)b < n2) v[8 + b] = *reinterpret_cast<const double *>(base + ((o2 + 128u * b) & bmask));
+    }
+    if (sl < ntB) tvB = *reinterpret_cast<const double *>(base + ((((begB + 8u * nblkB + sl) << 4)) & bmask));
+    double ra = v[0] + dl, rb = v[8] + dl;
+#pragma unroll
+    for (int b = 1; b < 8; b++)
+        if ((uint32_t)b < nblkA) ra += v[b] + dl;
+    if (wideA) {
+#pragma unroll
+        for (int b = 8; b < 16; b++)
+            if ((uint32_t)b < nblkA) ra += v[b] + dl;
+    } else {
+#pragma unroll
+        for (int b = 1; b < 8; b++)
+            if ((uint32_t)b < nblkB) rb += v[8 + b] + dl;
+    }
+    const double fa = fold8(ra), fb = fold8(rb);
+    ra = nblkA ? fa : 0.;
+    rb = nblkB ? fb : 0.;
+    // leftover sample e comes to lane 0 (and 8) of the row by a DPP shift; the moves are independent
+    double ta[7], tb[7];
+    ta[0] = tvA; tb[0] = tvB;
+    ta[1] = dpp_f64<0x101>(tvA); tb[1] = dpp_f64<0x101>(tvB);
+    ta[2] = dpp_f64<0x102>(tvA); tb[2] = dpp_f64<0x102>(tvB);
+    ta[3] = dpp_f64<0x103>(tvA); tb[3] = dpp_f64<0x103>(tvB);
+    ta[4] = dpp_f64<0x104>(tvA); tb[4] = dpp_f64<0x104>(tvB);
+    ta[5] = dpp_f64<0x105>(tvA); tb[5] = dpp_f64<0x105>(tvB);
+    ta[6] = dpp_f64<0x106>(tvA); tb[6] = dpp_f64<0x106>(tvB);
+#pragma unroll
+    for (int e = 0; e < 7; e++) {
+        if ((uint32_t)e < ntA) ra += ta[e] + dl;
+        if ((uint32_t)e < ntB) rb += tb[e] + dl;
+    }
+    LeafPair out;
+    out.a = ra;
+    out.b = rb;
+    return out;
+}
+
+// np.add.reduce over ring[beg, beg + n) as a resumable walk: next() names the next leaf, feed()
+// takes its sum.  8192-sample chunks left to right; inside a chunk DOUBLE_pairwise_sum's
+// recursion (split n -> n/2 rounded down to a multiple of 8 | rest, until <= 128) walked left to
+// right with an explicit stack (depth <= 6).
+struct NpSumWalk {
     uint32_t right_n[8];
     double left_sum[8];
-    uint32_t have_left = 0;
-    int sp = 0;
-    uint32_t cur = n, pos = beg;
-    for (;;) {
+    uint32_t have_left;
+    int sp;
+    uint32_t cur, pos, left_in_job;
+    double tot;
+    bool done;
+
+    __device__ __forceinline__ void start(uint32_t beg, uint32_t n) {
+        pos = beg; left_in_job = n; tot = 0.; sp = 0; have_left = 0; done = n == 0;
+        cur = n < kNpBufsize ? n : kNpBufsize;
+    }
+    __device__ __forceinline__ bool single_leaf() const { return sp == 0 && cur == left_in_job && cur <= 128; }
+    // the next leaf: [leaf_beg, leaf_beg + leaf_len)
+    __device__ __forceinline__ void next(uint32_t &leaf_beg, uint32_t &leaf_len) {
         while (cur > 128) {
             uint32_t n2 = cur / 2;
             n2 -= n2 % 8;
@@ -1097,74 +1149,74 @@ __device__ __forceinline__ double pairwise_sum(const double2 *ring, uint32_t mas
             sp++;
             cur = n2;
         }
-        double val = leaf_sum(ring, mask, pos, cur, dl, sl);
+        leaf_beg = pos;
+        leaf_len = cur;
+    }
+    __device__ __forceinline__ void feed(double val) {
         pos += cur;
-        bool descend = false;
+        left_in_job -= cur;
         while (sp > 0) {
             const int top = sp - 1;
             if (!(have_left & (1u << top))) {
                 left_sum[top] = val;
                 have_left |= 1u << top;
                 cur = right_n[top];
-                descend = true;
-                break;
+                return;  // descend into the right part
             }
             val = left_sum[top] + val;
             sp--;
         }
-        if (!descend) return val;
+        tot += val;  // one chunk finished (0.0 + x == x for the first)
+        cur = left_in_job < kNpBufsize ? left_in_job : kNpBufsize;
+        done = left_in_job == 0;
     }
-}
-
-__device__ __forceinline__ double np_sum(const double2 *ring, uint32_t mask, uint32_t beg, uint32_t n, double dl,
-                                         uint32_t sl) {
-    if (n <= 128) return leaf_sum(ring, mask, beg, n, dl, sl);  // the common case, no stack
-    double tot = 0.;
-    for (uint32_t i = 0; i < n; i += kNpBufsize) {
-        const uint32_t m = n - i < kNpBufsize ? n - i : kNpBufsize;
-        tot += pairwise_sum(ring, mask, beg + i, m, dl, sl);
-    }
-    return tot;
-}
+};
 
 // Means over the RTTs (= forward latency + dl) of the n > 0 acknowledged packets
 // ring[from, from + n) of the accepted ring: the whole list (so:119-122) by lanes 0-7 and, when
-// asked, mean(second half) - mean(first half) (so:138-142) by lanes 8-15.
+// asked, mean(second half) - mean(first half) (so:138-142) by lanes 8-15.  Every 8-lane subgroup
+// of the wavefront walks its own list(s) but all of them call the leaf code together, one memory
+// round trip per call: n <= 128 -- the usual case -- is a single call (whole list | both halves).
 __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, uint32_t mask, uint32_t from,
                                           uint32_t n, double dl, bool need_halves, double &mean_all,
                                           double &lat_inc) {
     const uint32_t sub = g.lane >> 3, sl = g.lane & 7u;
     const uint32_t half = n / 2;
     const bool halves = need_halves && half >= 1;
-    double tot = 0.0, first = 0.0, second = 0.0;
-    if (n <= 256) {
-        // The usual case.  The list is at most three leaves (n -> n2 | rest, rest -> r2 | rest - r2)
-        // and each half exactly one, so both subgroups run the SAME leaf code side by side on
-        // different slices instead of one after the other.
-        uint32_t n2 = n, r2 = 0, r3 = 0;
-        if (n > 128) {
-            n2 = n / 2; n2 -= n2 % 8;
-            r2 = n - n2;
-            if (r2 > 128) { uint32_t x = r2 / 2; x -= x % 8; r3 = r2 - x; r2 = x; }
+    // jobs of this subgroup: lanes 0-7 the whole list; lanes 8-15 first half, then second half
+    const uint32_t jb0 = from, jn0 = sub == 0 ? n : (halves ? half : 0u);
+    const uint32_t jb1 = from + half, jn1 = sub == 0 ? 0u : (halves ? n - half : 0u);
+    double res0 = 0.0, res1 = 0.0;
+    NpSumWalk w;
+    w.start(jb0, jn0);
+    int job = 0;
+    if (w.done) { job = 1; w.start(jb1, jn1); if (w.done) job = 2; }
+    for (;;) {
+        const bool active = job < 2;
+        if (!__ballot(active)) break;
+        uint32_t begA = from, lenA = 0, begB = from, lenB = 0;
+        bool pair = false;
+        if (active) {
+            w.next(begA, lenA);
+            // both halves are single short leaves: one call does both
+            pair = job == 0 && w.single_leaf() && lenA < 72 && jn1 != 0 && jn1 < 72;
+            if (pair) { begB = jb1; lenB = jn1; }
         }
-        // always the same three calls (a zero length costs nothing but the call), so the four env
-        // groups of a wavefront stay in one control flow whatever their list lengths
-        const double a = leaf_sum(ring, mask, from, sub == 0 ? n2 : (halves ? half : 0u), dl, sl);
-        const double b = leaf_sum(ring, mask, sub == 0 ? from + n2 : from + half,
-                                  sub == 0 ? r2 : (halves ? n - half : 0u), dl, sl);
-        const double c = leaf_sum(ring, mask, from + n2 + r2, sub == 0 ? r3 : 0u, dl, sl);
-        tot = a;
-        if (n > 128) tot = a + (r3 ? b + c : b);
-        first = a;
-        second = b;
-    } else if (sub == 0) {
-        tot = np_sum(ring, mask, from, n, dl, sl);
-    } else if (halves) {
-        first = np_sum(ring, mask, from, half, dl, sl);
-        second = np_sum(ring, mask, from + half, n - half, dl, sl);
+        const LeafPair p = leaf_sum2(ring, mask, begA, lenA, begB, lenB, dl, sl);
+        if (active) {
+            if (pair) {
+                res0 = p.a; res1 = p.b; job = 2;
+            } else {
+                w.feed(p.a);
+                if (w.done) {
+                    if (job == 0) { res0 = w.tot; job = 1; w.start(jb1, jn1); if (w.done) job = 2; }
+                    else { res1 = w.tot; job = 2; }
+                }
+            }
+        }
     }
-    mean_all = gbcast(tot, 0) / (double)n;
-    lat_inc = halves ? gbcast(second, 8) / (double)(n - half) - gbcast(first, 8) / (double)half : 0.0;
+    mean_all = gbcast(res0, 0) / (double)n;
+    lat_inc = halves ? gbcast(res1, 8) / (double)(n - half) - gbcast(res0, 8) / (double)half : 0.0;
 }
 
 // the 12 metrics of one MI (so:110-191) from its counts and RTT means
@@ -1210,6 +1262,10 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
     if (warm && !D.resetting[i]) return;
     const bool lead = g.lane == 0;
     const uint32_t mask = D.cap_mask, dmask = D.dcap_mask;
+    // profiling only: where a wavefront's retire time goes (lane 0's view), summed per workgroup
+    const bool tl = D.timeline != nullptr && (threadIdx.x & (kWave - 1)) == 0;
+    uint64_t *tlw = D.timeline ? D.timeline + ((int64_t)2 * D.n + blockIdx.x) * 8 : nullptr;
+    uint64_t tl_t = tl ? wall_clock64() : 0;
 
     const double dl = D.dl[i];
     const double start = D.now[i];
@@ -1347,6 +1403,11 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         (void)l_h2;
     }
 
+    if (tl) {
+        const uint64_t t = wall_clock64();
+        atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[3]), (unsigned long long)(t - tl_t));  // boundaries + ending event
+        tl_t = t;
+    }
     // ---- state
     unsigned long long sent_total = 0;
 #pragma unroll
@@ -1380,7 +1441,17 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
         double lat = 0.0, inc = 0.0;
+        if (tl) {
+            const uint64_t t = wall_clock64();
+            atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[4]), (unsigned long long)(t - tl_t));  // state write-back
+            tl_t = t;
+        }
         if (acked[s] > 0 && !(D.debug_skip & 1)) rtt_means(g, ra[s], mask, from[s], acked[s], dl, need_halves, lat, inc);
+        if (tl) {
+            const uint64_t t = wall_clock64();
+            atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[5]), (unsigned long long)(t - tl_t));  // RTT means
+            tl_t = t;
+        }
         double min_lat = D.min_lat[k];
         double m[PCC_N_METRICS];
         mi_metrics(sent[s], acked[s], lost[s], dur, lat, inc, min_lat, m);
@@ -1439,6 +1510,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         D.done[i] = done;
         if (done_out) done_out[i] = done;
     }
+    if (tl) atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[6]), (unsigned long long)(wall_clock64() - tl_t));  // metrics, history, outputs
 }
 
 template <int NS>
@@ -1458,16 +1530,16 @@ __global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int64_t slo
 
 // ======================================================================================
 // step_kernel: one whole monitor interval per launch.  A workgroup of four wavefronts owns a block
-// of 64 envs: wavefronts 0/1 send for them (send_wave), then all four retire envs, 16 at a time.
+// of 64 envs: wavefronts 0/1 send for them (send_wave), then all four retire envs, each wavefront 4 at a time.
 // Send times are tail-bound -- a few wavefronts carry envs with thousands of packets while most
 // finish early -- so a separate retire launch waits for the slowest wavefront of the whole chip
 // with most SIMDs idle.  Here a workgroup that is done sending publishes its block in a ready list
-// and then takes retire items (16 envs of a ready block) off a global queue until none are left:
+// and then its wavefronts take retire items (4 envs of a ready block) off a global queue until none are left:
 // early finishers retire their own envs and then wait for the stragglers' blocks, whose retire work
 // is spread over all the waiting workgroups the moment they finish sending.  Which workgroup
 // retires an env never changes a result.
 //   steal[0]  blocks published so far (monotone over steps; base_ready = its value at launch)
-//   steal[1]  items claimed so far (monotone; every workgroup ends with exactly one failed claim)
+//   steal[1]  items claimed so far (monotone; every wavefront ends with exactly one failed claim)
 //   steal[2+k] the k-th block to finish this step, tagged with the step number
 // Waiting is only safe when every workgroup of the grid is resident: the host launches this kernel
 // only for grids the device holds at once (pcc_step falls back to send_kernel + retire_kernel).
@@ -1480,13 +1552,16 @@ __global__ __launch_bounds__(kStepWaves * kWave, 4) void step_kernel(Dev D, uint
                                                                   uint32_t tag, const void *actions, int actions_f64,
                                                                   float *obs_out, float *reward_out, uint8_t *done_out,
                                                                   double *steps_out) {
-    __shared__ uint32_t sh_item, sh_block;
     const uint32_t tid = threadIdx.x;
+    if (D.timeline && tid == 2 * kWave) {  // the workgroup's exit stamp and item count are accumulated atomically below
+        uint64_t *w = D.timeline + ((int64_t)2 * D.n + blockIdx.x) * 8;
+        w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 0; w[5] = 0; w[6] = 0;
+    }
     if (tid < 2 * kWave) send_wave<NS, TRACE>(D, blockIdx.x, tid, 0, 0u, actions, actions_f64);
     // the records and cursors the send wavefronts wrote are read by whoever retires the block
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    constexpr uint32_t kPerItem = kStepWaves * kWave / kGroup;  // envs per retire item
+    constexpr uint32_t kPerItem = kWave / kGroup;  // envs per retire item: one per 16-lane group of a wavefront
     const uint32_t items_per_block = (D.send_envs_per_wave + kPerItem - 1) / kPerItem;
     const uint32_t total_items = gridDim.x * items_per_block;
     uint64_t tl_sent = 0;
@@ -1495,50 +1570,48 @@ __global__ __launch_bounds__(kStepWaves * kWave, 4) void step_kernel(Dev D, uint
         __hip_atomic_store(&D.steal[2 + pos], (tag << 16) | blockIdx.x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (D.timeline) tl_sent = wall_clock64();
     }
+    // from here on the wavefronts are on their own: each claims items until none are left
+    const uint32_t lane = tid & (kWave - 1);
     Group g;
     g.lane = tid & (kGroup - 1);
-    g.shift = (tid & (kWave - 1)) & ~(uint32_t)(kGroup - 1);
+    g.shift = lane & ~(uint32_t)(kGroup - 1);
     uint32_t n_items = 0;
     for (;;) {
-        if (tid == 0) {
-            const uint32_t t = atomicAdd(&D.steal[1], 1u) - base_next;
-            uint32_t b = 0;
+        uint32_t t = 0, v = 0;
+        if (lane == 0) {
+            t = atomicAdd(&D.steal[1], 1u) - base_next;
             if (t < total_items) {
                 const uint32_t k = t / items_per_block;
-                uint32_t v, spins = 0;
+                uint32_t spins = 0;
                 while (((v = __hip_atomic_load(&D.steal[2 + k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 16) != tag) {
                     __builtin_amdgcn_s_sleep(32);
                     if (++spins > kStealSpinLimit) break;
                 }
-                b = v & 0xFFFFu;
                 if ((v >> 16) != tag) {  // never expected: flag it instead of hanging
                     D.flags[0] |= PCC_FLAG_INTERNAL;
-                    sh_item = 0xFFFFFFFFu;
-                } else {
-                    sh_item = t;
+                    t = 0xFFFFFFFFu;
                 }
-            } else {
-                sh_item = 0xFFFFFFFFu;
             }
-            sh_block = b;
         }
-        __syncthreads();
-        const uint32_t t = sh_item, b = sh_block;
-        if (t == 0xFFFFFFFFu) break;
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        if (t >= total_items) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const uint32_t in_block = (t % items_per_block) * kPerItem + tid / kGroup;
+        const uint32_t b = v & 0xFFFFu;
+        const uint32_t in_block = (t % items_per_block) * kPerItem + lane / kGroup;
         const int64_t slot = (int64_t)b * D.send_envs_per_wave + in_block;
         if (in_block < D.send_envs_per_wave && slot < D.n) {
             const int64_t i = D.send_order ? (int64_t)D.send_order[slot] : slot;
             retire_env<NS>(D, i, g, 0, 0u, 0, obs_out, reward_out, done_out, steps_out);
         }
         n_items++;
-        __syncthreads();
     }
-    if (D.timeline && tid == 0) {
-        // block-level words after the 2 x n_envs wavefront entries: sent/published, exit, items retired here
+    if (D.timeline && lane == 0) {
+        // block-level words after the 2 x n_envs wavefront entries: sent/published, last exit, items retired here
         uint64_t *w = D.timeline + ((int64_t)2 * D.n + blockIdx.x) * 8;
-        w[0] = tl_sent; w[1] = wall_clock64(); w[2] = n_items;
+        if (tid == 0) w[0] = tl_sent;
+        atomicMax(reinterpret_cast<unsigned long long *>(&w[1]), (unsigned long long)wall_clock64());
+        atomicAdd(reinterpret_cast<unsigned long long *>(&w[2]), (unsigned long long)n_items);
     }
 }
 
@@ -1738,10 +1811,10 @@ int launch_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs
         if (tr) hipLaunchKernelGGL((step_kernel<2, true>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
         else hipLaunchKernelGGL((step_kernel<2, false>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
     }
-    const uint32_t per_item = kStepWaves * kWave / kGroup;
+    const uint32_t per_item = kWave / kGroup;
     const uint32_t items = blocks * ((d.send_envs_per_wave + per_item - 1) / per_item);
     sim->steal_ready_base += blocks;
-    sim->steal_next_base += items + blocks;  // every workgroup ends with exactly one failed claim
+    sim->steal_next_base += items + blocks * kStepWaves;  // every wavefront ends with exactly one failed claim
     sim->steal_tag++;
     return check_hip(hipGetLastError(), "step kernel launch");
 }

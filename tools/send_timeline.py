@@ -27,12 +27,18 @@ acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
 env.reset()
 out = []
 sample = {2, 10, 30, 60, 100, 150, 200, 250, 300, 350, 398}
+FUSED = os.environ.get("PCC_TL_FUSED", "1") != "0"
 for t in range(400):
-    env.step_send(acts[t % 64])
+    if FUSED:
+        env.step(acts[t % 64])
+    else:
+        env.step_send(acts[t % 64])
     if t in sample:
-        tl = env.debug_timeline().astype(np.int64)
+        raw = env.debug_timeline().astype(np.int64)
+        nb = raw.shape[0] // 3
+        tl, bl = raw[:2 * nb], raw[2 * nb:]
         tl = tl[tl[:, 0] > 0]
-        t0 = tl[:, 0].min()
+        t0 = tl[:nb * 2:2, 0].min() if False else tl[tl[:, 0] >= np.median(tl[:, 0]) - 10**7][:, 0].min()
         start, mid, fin = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0   # us
         heavy_wave = np.arange(len(tl))  # placeholder, the heavy wavefronts are the ones with 0 round time and w[3] > 0
         order = np.argsort(-fin)[:8]
@@ -46,6 +52,20 @@ for t in range(400):
                "slowest": [{"start": float(start[i]), "rounds_end": float(mid[i]), "finish": float(fin[i]),
                             "wave_path_envs": int(tl[i, 3]), "packets": int(tl[i, 4]), "largest_env": int(tl[i, 5]),
                             "wave_path_packets": int(tl[i, 6]), "live": int(tl[i, 7])} for i in order]}
+        if FUSED:
+            pub, ext = (bl[:, 0] - t0) / 100.0, (bl[:, 1] - t0) / 100.0
+            rec["block_published_us"] = pct(pub)
+            rec["block_exit_us"] = pct(ext)
+            rec["kernel_span_us"] = float(ext.max())
+            rec["items_per_block_min_p50_max"] = [int(bl[:, 2].min()), int(np.median(bl[:, 2])), int(bl[:, 2].max())]
+            items = max(1, int(bl[:, 2].sum()))
+            rec["retire_us_per_wave_item"] = {"boundaries+event": float(bl[:, 3].sum()) / 100.0 / items,
+                                              "state": float(bl[:, 4].sum()) / 100.0 / items,
+                                              "rtt_means": float(bl[:, 5].sum()) / 100.0 / items,
+                                              "metrics+history": float(bl[:, 6].sum()) / 100.0 / items}
+            last = np.argsort(-pub)[:3]
+            rec["last_published"] = [{"published": float(pub[i]), "exit": float(ext[i]), "items": int(bl[i, 2])} for i in last]
         out.append(rec)
-    env.step_retire()
+    if not FUSED:
+        env.step_retire()
 print(json.dumps(out, indent=1))
