@@ -91,6 +91,8 @@ enum {
 
 #define PCC_FLAG_RING_OVERFLOW 1u  /* more accepted or dropped packets in flight than ring_capacity: results invalid */
 #define PCC_FLAG_TRACE_OVERRUN 2u  /* PCC_RNG_TRACE ran past trace_stride */
+#define PCC_FLAG_POOL_EXHAUSTED 8u /* a sender needed a bigger ring tier and every pool from that tier up was empty (it may
+                                      then also overflow: RING_OVERFLOW); raise the pools with PCC_RING_POOLS */
 #define PCC_FLAG_INTERNAL 4u       /* (env 0 only) the fused step's retire queue timed out: results invalid, a bug */
 
 /* last error text of the calling thread ("" if none) */
@@ -103,12 +105,21 @@ const char *pcc_last_error(void);
  *   n_senders       1 (the reference env, ns:466) or 2 (two senders on the shared bottleneck).
  *   seed            Philox key.  env_gid_base: global id of env 0 (rank * n_envs when the
  *                   batch is sharded over GPUs) so results do not depend on the sharding.
- *   ring_capacity   power of two, per env per sender, in packets (0 = default 32768) of the
- *                   ring of accepted packets; the ring of dropped packets holds twice as many.
- *                   The worst case of the default ranges is rate_max * (RTT_max + one MI) =
- *                   1000 * (30.8 + 15.4) = 46.2k packets in flight between two retire passes
- *                   (nearly all of them drops), of which at most bw_max * that time = 23k are
- *                   accepted.  Device memory = n_envs * n_senders * 3 * ring_capacity * 16 B.
+ *   ring_capacity   power of two: the most accepted packets one sender can have in flight (0 =
+ *                   default 32768); twice as many dropped packets.  The worst case of the
+ *                   default ranges is rate_max * (RTT_max + one MI) = 1000 * (30.8 + 15.4) =
+ *                   46.2k packets in flight between two retire passes (nearly all of them
+ *                   drops), of which at most bw_max * that time = 23k are accepted.
+ *                   Storage is tiered: every sender owns small rings (ring_capacity / 4^k
+ *                   records with k <= 3 chosen so that this is >= 256, i.e. 512 + 1024 by
+ *                   default) and is moved -- at the start of a monitor interval whose packets
+ *                   could overflow them -- into rings 4x, 16x, ... as large taken from shared
+ *                   pools that by default hold 1/2, 1/8, 1/32 of the senders at once
+ *                   (environment variable PCC_RING_POOLS="2,8,32" sets the divisors; 1 =
+ *                   worst case).  An empty pool is flagged (PCC_FLAG_POOL_EXHAUSTED), never
+ *                   silent.  Pool rings are held until the env is reset.  The point of the
+ *                   tiers is address-space locality (TLB reach), not only memory: 65 536 envs
+ *                   take 6.4 GB instead of 103 GB.  pcc_device_bytes reports the total.
  *   device_id       HIP device ordinal (-1 = current device).
  * No env is usable before pcc_reset.
  */

@@ -44,6 +44,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "pcc_sim.h"
 
@@ -77,13 +78,24 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+constexpr int kMaxTiers = 4;
+
 // Everything a kernel needs, passed by value.
 struct Dev {
     int64_t n;
     int ns, H, F, HF;
     int32_t fid[kMaxFeatures];
-    uint32_t cap, cap_mask;      // accepted ring (records)
-    uint32_t dcap, dcap_mask;    // dropped ring = 2 * cap: under overload ~90 % of the packets are drops
+    // In-flight storage in tiers (see "In-flight packet storage" below): tier c rings hold
+    // cap0 * 4^c accepted + twice as many dropped records.  Tier 0 is one slot per (env, sender);
+    // the higher tiers are pools an env is promoted into when an MI could overflow its rings.
+    int n_tiers;
+    uint32_t cap0;
+    char *tier_base[kMaxTiers];
+    uint32_t *tier_free[kMaxTiers];  // [tier_slots[c]] free slot ids (a stack; c >= 1)
+    int32_t *tier_top;               // [kMaxTiers] stack heights
+    char **ring_base;                // [S][N] accepted ring of the sender (dropped ring follows it)
+    uint8_t *ring_tier;              // [S][N]
+    uint32_t *ring_held;             // [S][N][kMaxTiers] pool slot + 1 the sender holds in tier c (0 = none) until reset
     uint32_t key0, key1, gid_base;
     double delta_scale;
     uint32_t max_steps;
@@ -199,9 +211,31 @@ __device__ __forceinline__ bool near_time(double a, double b) {
     return fabs(a - b) <= kNearTol * fmax(1.0, fabs(b));
 }
 
-template <int NS>
-__device__ __forceinline__ double2 *ring_of(const Dev &D, int64_t i, int s, int dropped) {
-    return D.ring + ((int64_t)i * NS + s) * ((int64_t)D.cap + D.dcap) + (dropped ? D.cap : 0u);
+// the rings of one sender: accepted ring of `cap` records at base, dropped ring of 2 * cap after it
+struct RingRef {
+    char *base;
+    uint32_t cap;
+    __device__ __forceinline__ double2 *accepted() const { return reinterpret_cast<double2 *>(base); }
+    __device__ __forceinline__ double2 *dropped() const { return reinterpret_cast<double2 *>(base) + cap; }
+    __device__ __forceinline__ uint32_t mask() const { return cap - 1u; }
+    __device__ __forceinline__ uint32_t dmask() const { return 2u * cap - 1u; }
+};
+
+__device__ __forceinline__ uint32_t tier_cap(const Dev &D, uint32_t tier) { return D.cap0 << (2u * tier); }
+__device__ __forceinline__ size_t tier_slot_bytes(const Dev &D, uint32_t tier) { return (size_t)3 * tier_cap(D, tier) * sizeof(double2); }
+
+__device__ __forceinline__ RingRef ring_ref(const Dev &D, int64_t k /* s * n + i */) {
+    RingRef r;
+    r.base = D.ring_base[k];
+    r.cap = tier_cap(D, D.ring_tier[k]);
+    return r;
+}
+
+// Smallest tier whose rings hold `need_a` accepted and `need_d` dropped records (n_tiers if none).
+__device__ __forceinline__ uint32_t tier_for(const Dev &D, uint32_t need_a, uint32_t need_d) {
+    uint32_t c = 0;
+    while (c < (uint32_t)D.n_tiers && (tier_cap(D, c) < need_a || 2u * tier_cap(D, c) < need_d)) c++;
+    return c;
 }
 
 // ======================================================================================
@@ -230,6 +264,40 @@ __device__ __forceinline__ double uni_f64(double v) {
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+// Move the rings of sender k (lane `l` of the wavefront owns it) to a free slot of tier >= want:
+// all 64 lanes copy the live records [ha, ta) / [hd, td); ring indices stay what they are, only
+// the address of index j changes.  The slot the sender leaves stays reserved for it until its env
+// is reset (pops happen only in send launches, pushes only in reset launches: no stack races).
+// Returns false (and flags the env) when every pool from `want` up is empty.
+__device__ __forceinline__ bool promote_rings(const Dev &D, uint32_t lane, uint32_t l, int64_t k, uint32_t want,
+                                              uint32_t ha, uint32_t ta, uint32_t hd, uint32_t td) {
+    uint32_t got = 0xFFFFFFFFu, slot = 0;
+    if (lane == l) {
+        for (uint32_t c = want; c < (uint32_t)D.n_tiers; c++) {
+            const int32_t old = atomicSub(&D.tier_top[c], 1);
+            if (old > 0) { slot = D.tier_free[c][old - 1]; got = c; break; }
+            atomicAdd(&D.tier_top[c], 1);
+        }
+    }
+    got = rl_u32(got, l);
+    if (got == 0xFFFFFFFFu) return false;
+    slot = rl_u32(slot, l);
+    const int64_t kk = (int64_t)rl_u64((uint64_t)k, l);
+    const RingRef from = ring_ref(D, kk);
+    RingRef to;
+    to.cap = tier_cap(D, got);
+    to.base = D.tier_base[got < kMaxTiers ? got : 0] + (size_t)slot * tier_slot_bytes(D, got);
+    const uint32_t h_a = rl_u32(ha, l), n_a = rl_u32(ta, l) - h_a, h_d = rl_u32(hd, l), n_d = rl_u32(td, l) - h_d;
+    for (uint32_t j = lane; j < n_a; j += kWave) to.accepted()[(h_a + j) & to.mask()] = from.accepted()[(h_a + j) & from.mask()];
+    for (uint32_t j = lane; j < n_d; j += kWave) to.dropped()[(h_d + j) & to.dmask()] = from.dropped()[(h_d + j) & from.dmask()];
+    if (lane == l) {
+        D.ring_base[k] = to.base;
+        D.ring_tier[k] = (uint8_t)got;
+        D.ring_held[k * kMaxTiers + got] = slot + 1u;
+    }
+    return true;
+}
+
 __device__ __forceinline__ uint32_t exponent_bits(double x) { return ((uint32_t)__double2hiint(x) >> 20) & 0x7FFu; }
 
 struct SendState {  // wave-uniform while an env is processed by the whole wave
@@ -251,8 +319,9 @@ struct SendState {  // wave-uniform while an env is processed by the whole wave
 template <bool TRACE>
 __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl, double lr, uint32_t thr, bool always,
                                          double maxq, double ebw, double gap, double end, uint32_t episode,
-                                         uint32_t mi, uint32_t gid, const double *trace, char *base, SendState &st) {
-    const uint32_t mask_b = D.cap_mask << 4, dmask_b = D.dcap_mask << 4, cap_b = D.cap << 4;
+                                         uint32_t mi, uint32_t gid, const double *trace, char *base, uint32_t cap,
+                                         SendState &st) {
+    const uint32_t mask_b = (cap - 1u) << 4, dmask_b = (2u * cap - 1u) << 4, cap_b = cap << 4;
     const uint64_t lt = (1ull << lane) - 1ull;
     while (st.t < end) {
         const double t0 = st.t;
@@ -385,8 +454,8 @@ template <bool TRACE>
 __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl, double lr, uint32_t thr, bool always,
                                           double maxq, double ebw, double gap0, double gap1, double end,
                                           uint32_t episode, uint32_t mi, uint32_t gid, const double *trace, char *base0,
-                                          char *base1, SendState2 &st) {
-    const uint32_t mask_b = D.cap_mask << 4, dmask_b = D.dcap_mask << 4, cap_b = D.cap << 4;
+                                          char *base1, uint32_t cap0, uint32_t cap1, SendState2 &st) {
+    const uint32_t caps[2] = {cap0, cap1};
     const uint64_t lt = (1ull << lane) - 1ull;
     const double gap[2] = {gap0, gap1};
     while ((st.t[0] < st.t[1] ? st.t[0] : st.t[1]) < end) {
@@ -505,6 +574,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                 double2 rec;
                 rec.x = my_t;
                 rec.y = my_lat;
+                const uint32_t cap_b = caps[s] << 4, mask_b = (caps[s] - 1u) << 4, dmask_b = (2u * caps[s] - 1u) << 4;
                 const uint32_t off = my_drop ? cap_b + (((st.d[s] + (uint32_t)__popcll(dm & lt)) << 4) & dmask_b)
                                              : (((st.a[s] + (uint32_t)__popcll(am & lt)) << 4) & mask_b);
                 *reinterpret_cast<double2 *>((s ? base1 : base0) + off) = rec;
@@ -569,15 +639,37 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
         sent[s] = 0;
     }
     const double *trace = TRACE ? D.trace + ii * D.trace_stride : nullptr;
-    const uint32_t mask_b = D.cap_mask << 4, dmask_b = D.dcap_mask << 4, cap_b = D.cap << 4;
     const bool run = live && now < end;
+
+    // ---- ring tier: an upper bound of this MI's packets per sender is known up front (the send
+    // times advance by gap up to rounding; one more SEND can follow in the retire half), so rings
+    // that could overflow are moved to a bigger tier now, by the whole wavefront
+    RingRef rings[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int64_t k = (int64_t)s * D.n + ii;
+        uint32_t want = 0;
+        if (run) {
+            const double ahead = nsend[s] < end ? (end - nsend[s]) / gap[s] + 4.0 : 1.0;
+            const uint32_t n_max = ahead < 1e9 ? (uint32_t)ahead : 1000000000u;
+            want = tier_for(D, ta[s] - ha[s] + n_max, td[s] - hd[s] + n_max);
+        }
+        uint64_t pm = __ballot(run && want > (uint32_t)D.ring_tier[k] && want < (uint32_t)D.n_tiers);
+        while (pm) {
+            const uint32_t l = (uint32_t)__ffsll((unsigned long long)pm) - 1u;
+            pm &= pm - 1ull;
+            if (!promote_rings(D, lane, l, k, want, ha[s], ta[s], hd[s], td[s]) && lane == l) flags |= PCC_FLAG_POOL_EXHAUSTED;
+        }
+        rings[s] = ring_ref(D, k);
+    }
+    const uint32_t mask_b = (rings[0].cap - 1u) << 4, dmask_b = (2u * rings[0].cap - 1u) << 4, cap_b = rings[0].cap << 4;
 
     if (NS == 1) {
         // u32_to_unit(x) < lr  <=>  x < ceil(lr * 2^32) for integer x (the scaling is exact)
         const double thr_d = ceil(lr * 4294967296.0);
         const bool always = thr_d >= 4294967296.0;
         const uint32_t thr = always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
-        char *base = reinterpret_cast<char *>(ring_of<NS>(D, ii, 0, 0));
+        char *base = rings[0].base;
         // heavy = many packets ahead, most of them drops (rate well above bw), and the wave path's
         // standing preconditions hold; everything else stays in the lane-serial loop
         const bool heavy = run && (heavy_wave || ((end - nsend[0]) > D.heavy_packets * gap[0] && gap[0] < D.heavy_rho * ebw &&
@@ -673,7 +765,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                             rl_f64(maxq, l), rl_f64(ebw, l), rl_f64(gap[0], l), rl_f64(end, l), rl_u32(episode, l),
                             rl_u32(mi, l), rl_u32(gid, l),
                             reinterpret_cast<const double *>(rl_u64(reinterpret_cast<uint64_t>(trace), l)),
-                            reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(base), l)), st);
+                            reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(base), l)), rl_u32(rings[0].cap, l), st);
             if (lane == l) { q = st.q; tu = st.tu; t = st.t; a = st.a; d = st.d; flags |= st.flags; }
         }
         nsend[0] = t;
@@ -687,8 +779,12 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
         const bool always = thr_d >= 4294967296.0;
         const uint32_t thr = always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
         char *bases[NS];
+        uint32_t cap_bs[NS], mask_bs[NS], dmask_bs[NS];
 #pragma unroll
-        for (int s = 0; s < NS; s++) bases[s] = reinterpret_cast<char *>(ring_of<NS>(D, ii, s, 0));
+        for (int s = 0; s < NS; s++) {
+            bases[s] = rings[s].base;
+            cap_bs[s] = rings[s].cap << 4; mask_bs[s] = (rings[s].cap - 1u) << 4; dmask_bs[s] = (2u * rings[s].cap - 1u) << 4;
+        }
         bool active = run && !heavy_wave, heavy_now = run && heavy_wave;
         uint32_t blk = 0;  // Philox block = packets of this MI sent on the link / 4
         for (;;) {
@@ -709,7 +805,8 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                             bool dropped;
                             const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
                             const uint32_t a_s = s1 ? ta[NS - 1] : ta[0], d_s = s1 ? td[NS - 1] : td[0];
-                            const uint32_t off = dropped ? cap_b + ((d_s << 4) & dmask_b) : ((a_s << 4) & mask_b);
+                            const uint32_t off = dropped ? (s1 ? cap_bs[NS - 1] : cap_bs[0]) + ((d_s << 4) & (s1 ? dmask_bs[NS - 1] : dmask_bs[0]))
+                                                         : ((a_s << 4) & (s1 ? mask_bs[NS - 1] : mask_bs[0]));
                             *reinterpret_cast<double2 *>((s1 ? bases[NS - 1] : bases[0]) + off) = rec;
                             const uint32_t acc = dropped ? 0u : 1u, drp = dropped ? 1u : 0u;
                             if (s1) {
@@ -735,7 +832,8 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                         bool dropped;
                         const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
                         const uint32_t a_s = s1 ? ta[NS - 1] : ta[0], d_s = s1 ? td[NS - 1] : td[0];
-                        const uint32_t off = dropped ? cap_b + ((d_s << 4) & dmask_b) : ((a_s << 4) & mask_b);
+                        const uint32_t off = dropped ? (s1 ? cap_bs[NS - 1] : cap_bs[0]) + ((d_s << 4) & (s1 ? dmask_bs[NS - 1] : dmask_bs[0]))
+                                                         : ((a_s << 4) & (s1 ? mask_bs[NS - 1] : mask_bs[0]));
                         *reinterpret_cast<double2 *>((s1 ? bases[NS - 1] : bases[0]) + off) = rec;
                         const uint32_t acc = dropped ? 0u : 1u, drp = dropped ? 1u : 0u;
                         if (s1) {
@@ -773,7 +871,8 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                              rl_u32(episode, l), rl_u32(mi, l), rl_u32(gid, l),
                              reinterpret_cast<const double *>(rl_u64(reinterpret_cast<uint64_t>(trace), l)),
                              reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(bases[0]), l)),
-                             reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(bases[NS - 1]), l)), st);
+                             reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(bases[NS - 1]), l)),
+                             rl_u32(rings[0].cap, l), rl_u32(rings[NS - 1].cap, l), st);
             if (lane == l) {
                 q = st.q; tu = st.tu; flags |= st.flags;
 #pragma unroll
@@ -803,7 +902,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         // never silent: more packets in flight than a ring holds means records were overwritten
-        if (ta[s] - ha[s] > D.cap || td[s] - hd[s] > D.dcap) flags |= PCC_FLAG_RING_OVERFLOW;
+        if (ta[s] - ha[s] > rings[s].cap || td[s] - hd[s] > 2u * rings[s].cap) flags |= PCC_FLAG_RING_OVERFLOW;
         const int64_t k = (int64_t)s * D.n + i;
         D.next_send[k] = nsend[s];
         D.ta[k] = ta[s]; D.td[k] = td[s];
@@ -1261,7 +1360,6 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
                                            double *steps_out) {
     if (warm && !D.resetting[i]) return;
     const bool lead = g.lane == 0;
-    const uint32_t mask = D.cap_mask, dmask = D.dcap_mask;
     // profiling only: where a wavefront's retire time goes (lane 0's view), summed per workgroup
     const bool tl = D.timeline != nullptr && (threadIdx.x & (kWave - 1)) == 0;
     uint64_t *tlw = D.timeline ? D.timeline + ((int64_t)2 * D.n + blockIdx.x) * 8 : nullptr;
@@ -1277,6 +1375,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
     double nsend[NS];
     uint32_t ha[NS], hd[NS], ta[NS], td[NS], sent[NS], acked[NS], lost[NS], from[NS];
     double2 *ra[NS], *rd[NS];
+    uint32_t amask[NS], dmasks[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
@@ -1285,8 +1384,9 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         sent[s] = D.mi_sent[k];
         acked[s] = lost[s] = 0;
         from[s] = ha[s];
-        ra[s] = ring_of<NS>(D, i, s, 0);
-        rd[s] = ring_of<NS>(D, i, s, 1);
+        const RingRef rr = ring_ref(D, k);
+        ra[s] = rr.accepted(); rd[s] = rr.dropped();
+        amask[s] = rr.mask(); dmasks[s] = rr.dmask();
     }
     uint32_t flags = 0;
 
@@ -1299,7 +1399,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         for (int s = 0; s < NS; s++) {
             // ---- all four boundaries of this sender in one joint search (3-4 dependent loads)
             const double2 *const rings[4] = {ra[s], ra[s], rd[s], rd[s]};
-            const uint32_t masks[4] = {mask, mask, dmask, dmask};
+            const uint32_t masks[4] = {amask[s], amask[s], dmasks[s], dmasks[s]};
             const uint32_t los[4] = {ha[s], ha[s], hd[s], hd[s]};
             const uint32_t his[4] = {ta[s], ta[s], td[s], td[s]};
             const double adds[4] = {dl, 0.0, dl, 0.0};
@@ -1319,7 +1419,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             if (bnd[2].clean) {
                 if (pd < td[s] && bnd[2].t < end) { dk = pd; d2_t = bnd[2].t + dl; d2_l = bnd[2].lat + dl; }
             } else {
-                if (lead) pd = fix_drop_boundary(rd[s], dmask, hd[s], td[s], bnd[2].b, dl, end, dk, d2_t, d2_l);
+                if (lead) pd = fix_drop_boundary(rd[s], dmasks[s], hd[s], td[s], bnd[2].b, dl, end, dk, d2_t, d2_l);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 pd = gbcast(pd, 0); dk = gbcast(dk, 0); d2_t = gbcast(d2_t, 0); d2_l = gbcast(d2_l, 0);
                 rotated = true;  // records may have moved inside the window
@@ -1330,9 +1430,9 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             if (!rotated && bnd[3].clean) {
                 if (bnd[3].b < td[s]) { d1_t = bnd[3].t; d1_l = bnd[3].lat; }
             } else if (td[s] != pd) {
-                const uint32_t cd = rotated ? search_boundary(g, rd[s], dmask, pd, td[s], 0.0, end)
+                const uint32_t cd = rotated ? search_boundary(g, rd[s], dmasks[s], pd, td[s], 0.0, end)
                                             : (bnd[3].b < pd ? pd : bnd[3].b);
-                if (lead) drop_hop1_candidate(rd[s], dmask, pd, td[s], cd, end, d1_t, d1_l);
+                if (lead) drop_hop1_candidate(rd[s], dmasks[s], pd, td[s], cd, end, d1_t, d1_l);
                 d1_t = gbcast(d1_t, 0); d1_l = gbcast(d1_l, 0);
             }
             // ---- best of each kind by the heap key (time, latency, dropped): ns:111,161,178
@@ -1358,7 +1458,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             if (best == 3 * s + 1) {  // hop-2: acknowledge / lose one more packet
                 if (h2_is_drop[s]) {
                     if (k_h2[s] != hd[s]) {
-                        if (lead) rotate_to_front(rd[s], dmask, hd[s], k_h2[s]);
+                        if (lead) rotate_to_front(rd[s], dmasks[s], hd[s], k_h2[s]);
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     }
                     lost[s]++;
@@ -1390,13 +1490,13 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
                 bool dropped;
                 const double2 rec = link_send(t, u < D.lr[i], dl, D.maxq[i], D.ebw[i], q, tu, dropped);
                 if (dropped) {
-                    if (lead) rd[s][td[s] & dmask] = rec;
+                    if (lead) rd[s][td[s] & dmasks[s]] = rec;
                     td[s]++;
                 } else {
-                    if (lead) ra[s][ta[s] & mask] = rec;
+                    if (lead) ra[s][ta[s] & amask[s]] = rec;
                     ta[s]++;
                 }
-                if (ta[s] - ha[s] > D.cap || td[s] - hd[s] > D.dcap) flags |= PCC_FLAG_RING_OVERFLOW;
+                if (ta[s] - ha[s] > amask[s] + 1u || td[s] - hd[s] > dmasks[s] + 1u) flags |= PCC_FLAG_RING_OVERFLOW;
                 if (lead) { D.q[i] = q; D.tu[i] = tu; }
             }
         }
@@ -1446,7 +1546,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[4]), (unsigned long long)(t - tl_t));  // state write-back
             tl_t = t;
         }
-        if (acked[s] > 0 && !(D.debug_skip & 1)) rtt_means(g, ra[s], mask, from[s], acked[s], dl, need_halves, lat, inc);
+        if (acked[s] > 0 && !(D.debug_skip & 1)) rtt_means(g, ra[s], amask[s], from[s], acked[s], dl, need_halves, lat, inc);
         if (tl) {
             const uint64_t t = wall_clock64();
             atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[5]), (unsigned long long)(t - tl_t));  // RTT means
@@ -1514,7 +1614,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
 }
 
 template <int NS>
-__global__ __launch_bounds__(kRetireBlock) void retire_kernel(Dev D, int64_t slot0, int64_t slot_end, int warm,
+__global__ __launch_bounds__(kRetireBlock, 5) void retire_kernel(Dev D, int64_t slot0, int64_t slot_end, int warm,
                                                               uint32_t warm_mi, int last_warm, float *obs_out,
                                                               float *reward_out, uint8_t *done_out, double *steps_out) {
     const uint32_t tid = threadIdx.x;
@@ -1662,6 +1762,17 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
         D.rate0[k] = rate0[s];
         D.next_send[k] = 1.0 / rate0[s];  // ns:111
         D.ha[k] = 0; D.hd[k] = 0; D.ta[k] = 0; D.td[k] = 0; D.mi_sent[k] = 0;
+        // nothing is in flight any more: the pool slots go back (pushes only here, pops only in
+        // send launches), the sender starts over in its own tier-0 rings
+        for (int c = 1; c < D.n_tiers; c++) {
+            const uint32_t held = D.ring_held[k * kMaxTiers + c];
+            if (held) {
+                D.tier_free[c][atomicAdd(&D.tier_top[c], 1)] = held - 1u;
+                D.ring_held[k * kMaxTiers + c] = 0;
+            }
+        }
+        D.ring_tier[k] = 0;
+        D.ring_base[k] = D.tier_base[0] + (size_t)((int64_t)i * NS + s) * tier_slot_bytes(D, 0);
         D.min_lat[k] = 0.0;   // fresh sender id => no connection minimum yet (ns:229-233, so:158)
         D.ep_return[k] = 0.0;
         // all-empty history (so:57-62): every metric of an empty MI is 0 except the two ratios
@@ -1688,7 +1799,9 @@ struct pcc_sim {
     int device;
     void *state_blob;
     size_t state_bytes;
-    void *ring_blob;
+    void *tier_blob[kMaxTiers];   // tier 0: one slot per (env, sender); tiers >= 1: pools
+    void *tier_free_blob[kMaxTiers];
+    uint32_t tier_slots[kMaxTiers];
     size_t ring_bytes;
     void *timeline_blob;
     size_t timeline_bytes;
@@ -1743,6 +1856,10 @@ size_t carve_state(Dev &d, char *base) {
     d.min_lat = c.take<double>(sn); d.ep_return = c.take<double>(sn); d.last_return = c.take<double>(sn);
     d.ha = c.take<uint32_t>(sn); d.hd = c.take<uint32_t>(sn); d.ta = c.take<uint32_t>(sn); d.td = c.take<uint32_t>(sn);
     d.mi_sent = c.take<uint32_t>(sn);
+    d.ring_base = c.take<char *>(sn);
+    d.ring_held = c.take<uint32_t>(sn * kMaxTiers);
+    d.ring_tier = c.take<uint8_t>(sn);
+    d.tier_top = c.take<int32_t>(kMaxTiers);
     d.hist = c.take<float>(sn * d.HF);
     return (c.off + 255) & ~(size_t)255;
 }
@@ -1901,8 +2018,9 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     Dev &d = sim->d;
     d.n = n_envs; d.ns = n_senders; d.H = history_len; d.F = n_features; d.HF = history_len * n_features;
     for (int f = 0; f < n_features; f++) d.fid[f] = feature_ids[f];
-    d.cap = ring_capacity; d.cap_mask = ring_capacity - 1;
-    d.dcap = 2 * ring_capacity; d.dcap_mask = d.dcap - 1;
+    // tiers: cap0 * 4^c records, the top tier = ring_capacity; as many tiers (<= 4) as keep cap0 >= 256
+    d.n_tiers = 1; d.cap0 = ring_capacity;
+    while (d.n_tiers < kMaxTiers && d.cap0 >= 4u * 256u) { d.cap0 >>= 2; d.n_tiers++; }
     d.key0 = (uint32_t)seed; d.key1 = (uint32_t)(seed >> 32); d.gid_base = env_gid_base;
     d.delta_scale = 0.025;  // src/common/config.py:17
     d.max_steps = 400;      // ns:41
@@ -1921,23 +2039,56 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.rng_mode = PCC_RNG_PHILOX;
     sim->device = device;
     sim->state_bytes = carve_state(d, nullptr);
-    sim->ring_bytes = (size_t)n_envs * n_senders * 3 * ring_capacity * sizeof(double2);
     if (hipMalloc(&sim->state_blob, sim->state_bytes) != hipSuccess) {
         const size_t want = sim->state_bytes;
         delete sim;
         return fail(PCC_ENOMEM, "hipMalloc(%zu) for env state failed", want);
     }
-    if (hipMalloc(&sim->ring_blob, sim->ring_bytes) != hipSuccess) {
-        (void)hipFree(sim->state_blob);
-        const size_t want = sim->ring_bytes;
-        delete sim;
-        return fail(PCC_ENOMEM, "hipMalloc(%zu) for the in-flight rings failed (n_envs*n_senders*3*ring_capacity*16 B)", want);
-    }
     carve_state(d, static_cast<char *>(sim->state_blob));
-    d.ring = static_cast<double2 *>(sim->ring_blob);
-    if (hipMemset(sim->state_blob, 0, sim->state_bytes) != hipSuccess) {
+    // pool sizes: by default 1/2, 1/8, 1/32 of the senders can sit in tiers 1, 2, 3 at the same
+    // time (measured need at the ICML'19 ranges: ~25 %, ~2 %, ~0.02 %); PCC_RING_POOLS="a,b,c"
+    // overrides the divisors (1 = every sender could, the worst case)
+    unsigned div[kMaxTiers] = {1, 2, 8, 32};
+    if (const char *e = getenv("PCC_RING_POOLS")) {
+        unsigned a = 0, b = 0, c = 0;
+        const int got = sscanf(e, "%u,%u,%u", &a, &b, &c);
+        if (got >= 1 && a) div[1] = a;
+        if (got >= 2 && b) div[2] = b;
+        if (got >= 3 && c) div[3] = c;
+    }
+    const size_t senders = (size_t)n_envs * n_senders;
+    sim->ring_bytes = 0;
+    for (int c = 0; c < d.n_tiers; c++) {
+        size_t slots = senders / div[c];
+        if (slots < 256) slots = senders < 256 ? senders : 256;
+        if (c == 0) slots = senders;
+        sim->tier_slots[c] = (uint32_t)slots;
+        const size_t bytes = slots * 3 * ((size_t)d.cap0 << (2 * c)) * sizeof(double2);
+        if (hipMalloc(&sim->tier_blob[c], bytes) != hipSuccess) {
+            pcc_destroy(sim);
+            return fail(PCC_ENOMEM, "hipMalloc(%zu) for the tier-%d in-flight rings failed (%zu slots of 3*%u records)",
+                        bytes, c, slots, d.cap0 << (2 * c));
+        }
+        sim->ring_bytes += bytes;
+        d.tier_base[c] = static_cast<char *>(sim->tier_blob[c]);
+        if (c >= 1) {
+            std::vector<uint32_t> ids(slots);
+            for (size_t j = 0; j < slots; j++) ids[j] = (uint32_t)(slots - 1 - j);  // slot 0 is popped first
+            if (hipMalloc(&sim->tier_free_blob[c], slots * sizeof(uint32_t)) != hipSuccess ||
+                hipMemcpy(sim->tier_free_blob[c], ids.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+                pcc_destroy(sim);
+                return fail(PCC_ENOMEM, "allocating the tier-%d free list failed", c);
+            }
+            sim->ring_bytes += slots * sizeof(uint32_t);
+            d.tier_free[c] = static_cast<uint32_t *>(sim->tier_free_blob[c]);
+        }
+    }
+    int32_t tops[kMaxTiers] = {0, 0, 0, 0};
+    for (int c = 1; c < d.n_tiers; c++) tops[c] = (int32_t)sim->tier_slots[c];
+    if (hipMemset(sim->state_blob, 0, sim->state_bytes) != hipSuccess ||
+        hipMemcpy(d.tier_top, tops, sizeof tops, hipMemcpyHostToDevice) != hipSuccess) {
         pcc_destroy(sim);
-        return fail(PCC_EHIP, "hipMemset of env state failed");
+        return fail(PCC_EHIP, "initialising the env state failed");
     }
     if (getenv("PCC_DEBUG_TIMELINE") && atoi(getenv("PCC_DEBUG_TIMELINE"))) {
         sim->timeline_bytes = (size_t)n_envs * 3 * 8 * sizeof(uint64_t);
@@ -1974,7 +2125,10 @@ void pcc_destroy(pcc_sim_t *sim) {
     if (sim->timeline_blob) (void)hipFree(sim->timeline_blob);
 
     if (sim->state_blob) (void)hipFree(sim->state_blob);
-    if (sim->ring_blob) (void)hipFree(sim->ring_blob);
+    for (int c = 0; c < kMaxTiers; c++) {
+        if (sim->tier_blob[c]) (void)hipFree(sim->tier_blob[c]);
+        if (sim->tier_free_blob[c]) (void)hipFree(sim->tier_free_blob[c]);
+    }
     delete sim;
 }
 

@@ -293,7 +293,9 @@ class BatchedNetworkEnv(object):
             tr = int(((flags & native.PCC_FLAG_TRACE_OVERRUN) != 0).sum().item())
             if int(((flags & native.PCC_FLAG_INTERNAL) != 0).sum().item()):
                 raise PccError(-6, "internal error: the fused step's retire queue timed out")
-            raise PccError(-6, "%d envs overflowed the in-flight ring, %d ran past the loss trace" % (over, tr))
+            pool = int(((flags & native.PCC_FLAG_POOL_EXHAUSTED) != 0).sum().item())
+            raise PccError(-6, "%d envs overflowed the in-flight ring, %d ran past the loss trace, %d found the "
+                               "ring pools empty (PCC_RING_POOLS)" % (over, tr, pool))
 
     @property
     def device_bytes(self):
