@@ -86,6 +86,7 @@ enum {
     PCC_F_EP_RETURN,     /* f64 [S][N]  reward summed over the running episode (ns:442) */
     PCC_F_LAST_RETURN,   /* f64 [S][N]  return of the last finished episode            */
     PCC_F_TOTAL_SENT,    /* u64 [N]     packets sent since create (all episodes, all senders) */
+    PCC_F_RING_TIER,     /* u8  [S][N]  tier of the sender's in-flight rings (0 = its own small rings) */
     PCC_N_FIELDS
 };
 
@@ -164,7 +165,11 @@ enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKET
                                   envs, then retires envs of whichever blocks are done sending (its
                                   own first), so the retire work fills the SIMDs idle during the send
                                   tail -- whenever the whole grid is resident at once (65 536 envs
-                                  are); 0, or a larger grid: pcc_step_send + pcc_step_retire */ };
+                                  are); 0, or a larger grid: pcc_step_send + pcc_step_retire */,
+       PCC_TUNE_HELP_LANES = 7 /* when at most this many lanes (default 16, 0..64) of a wavefront still
+                                  have packets to send, the idle lanes compute their Philox blocks:
+                                  the loss decisions of a lane's next 256 packets come from one block
+                                  per idle lane instead of 64 blocks of its own */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* Load balancing of the send kernel: order is a device array [N] holding a permutation of the env

@@ -103,7 +103,7 @@ struct Dev {
     uint64_t *timeline;  // profiling only (PCC_DEBUG_TIMELINE env): 8 words per send wavefront, see pcc_debug_timeline
     int debug_skip;  // profiling only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs
     double heavy_packets, heavy_rho;  // tuning: when the send kernel hands an env to the wave path
-    uint32_t round_packets, takeover_lanes, send_envs_per_wave;
+    uint32_t round_packets, takeover_lanes, send_envs_per_wave, help_lanes;
     double heavy_predict;  // predicted packets per MI above which an env goes to the heavy wave
     double lo[5], hi[5];
     int rng_mode;
@@ -682,8 +682,26 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
         // Lane-serial rounds of at most kRound packets per env.  After a round, if only one or two
         // lanes of the wave still have packets to send, they are the tail everybody else would wait
         // for: hand them to the wave path, which sends one env's packets 2-5x faster than one lane.
+        bool helped = false;
+        uint64_t loss_bits[4] = {0, 0, 0, 0};  // helped round: bit j of [k] = loss decision of packet 4j + k of the round
         for (;;) {
-            if (active) {
+            if (active && helped) {
+                for (uint32_t j = 0; j < 64u && t < end; j++) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (k > 0 && !(t < end)) break;
+                        bool dropped;
+                        const double2 rec = link_send(t, (loss_bits[k] >> j) & 1ull, dl, maxq, ebw, q, tu, dropped);
+                        const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
+                        *reinterpret_cast<double2 *>(base + off) = rec;
+                        a += dropped ? 0u : 1u;
+                        d += dropped ? 1u : 0u;
+                        t += gap[0];  // ns:161
+                    }
+                    blk++;
+                }
+                active = t < end;
+            } else if (active) {
                 if (!TRACE) {
                     // four packets per Philox block, no loads, no data-dependent branches.  The first
                     // `safe` packets are certainly before `end` (t advances by gap up to rounding; two
@@ -744,6 +762,27 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
             if ((uint32_t)__popcll(am) <= D.takeover_lanes) {  // the wave path sends one env faster than a lone lane
                 heavy_now = heavy_now || active;
                 break;
+            }
+            helped = !TRACE && (uint32_t)__popcll(am) <= D.help_lanes;
+            if (helped) {
+                // Few lanes left: the idle lanes draw for them.  For each active lane all 64 lanes
+                // compute one Philox block each (blocks blk .. blk+63 of that env = its next 256
+                // packets) and the loss decisions come back as four ballots, so the lane's round
+                // below runs without a single Philox round of its own.
+                uint64_t m = am;
+                while (m) {
+                    const uint32_t l = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+                    m &= m - 1ull;
+                    uint32_t w[4];
+                    philox4x32_10(rl_u32(blk, l) + lane, rl_u32(mi, l), rl_u32(episode, l), rl_u32(gid, l), D.key0, D.key1, w);
+                    const uint32_t thr_l = rl_u32(thr, l);
+                    const bool always_l = rl_u32(always ? 1u : 0u, l) != 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint64_t bm = __ballot(always_l || w[k] < thr_l);
+                        if (lane == l) loss_bits[k] = bm;
+                    }
+                }
             }
         }
         // heavy envs of this wave (standing or tail take-over), one after the other, 64 lanes each
@@ -1362,8 +1401,14 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
     const bool lead = g.lane == 0;
     // profiling only: where a wavefront's retire time goes (lane 0's view), summed per workgroup
     const bool tl = D.timeline != nullptr && (threadIdx.x & (kWave - 1)) == 0;
-    uint64_t *tlw = D.timeline ? D.timeline + ((int64_t)2 * D.n + blockIdx.x) * 8 : nullptr;
+    uint64_t *tlw = D.timeline ? D.timeline + (int64_t)2 * D.n * 8 + (int64_t)blockIdx.x * 16 : nullptr;
     uint64_t tl_t = tl ? wall_clock64() : 0;
+#define PCC_TL_STAMP(slot)                                                                               \
+    if (tl) {                                                                                            \
+        const uint64_t t_now = wall_clock64();                                                           \
+        atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[slot]), (unsigned long long)(t_now - tl_t)); \
+        tl_t = t_now;                                                                                    \
+    }
 
     const double dl = D.dl[i];
     const double start = D.now[i];
@@ -1404,7 +1449,9 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             const uint32_t his[4] = {ta[s], ta[s], td[s], td[s]};
             const double adds[4] = {dl, 0.0, dl, 0.0};
             Bound bnd[4];
+            PCC_TL_STAMP(3)  // state loads
             search_many<4>(g, rings, masks, los, his, adds, end, bnd);
+            PCC_TL_STAMP(4)  // the joint boundary search
             // ---- accepted ring: send order is event order, the transitions are exact
             const uint32_t pa = bnd[0].b, ca = bnd[1].b;            // hop-2 / hop-1 events < end
             acked[s] = pa - ha[s];                                   // ns:144-146
@@ -1442,6 +1489,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             l_h2[s] = h2_is_drop[s] ? d2_l : a2_l;
             k_h2[s] = h2_is_drop[s] ? dk : pa;
         }
+        PCC_TL_STAMP(5)  // candidates, near-group repairs
         // ---- the event that ends the MI: smallest (time, sender, 'A' < 'S', hop) among the stream
         // heads, all >= end here; the reference still processes it (ns:128-131)
         int best = 0;
@@ -1503,11 +1551,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         (void)l_h2;
     }
 
-    if (tl) {
-        const uint64_t t = wall_clock64();
-        atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[3]), (unsigned long long)(t - tl_t));  // boundaries + ending event
-        tl_t = t;
-    }
+    PCC_TL_STAMP(6)  // the MI-ending event
     // ---- state
     unsigned long long sent_total = 0;
 #pragma unroll
@@ -1541,20 +1585,13 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
         double lat = 0.0, inc = 0.0;
-        if (tl) {
-            const uint64_t t = wall_clock64();
-            atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[4]), (unsigned long long)(t - tl_t));  // state write-back
-            tl_t = t;
-        }
+        PCC_TL_STAMP(7)  // state write-back
         if (acked[s] > 0 && !(D.debug_skip & 1)) rtt_means(g, ra[s], amask[s], from[s], acked[s], dl, need_halves, lat, inc);
-        if (tl) {
-            const uint64_t t = wall_clock64();
-            atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[5]), (unsigned long long)(t - tl_t));  // RTT means
-            tl_t = t;
-        }
+        PCC_TL_STAMP(8)  // RTT means
         double min_lat = D.min_lat[k];
         double m[PCC_N_METRICS];
         mi_metrics(sent[s], acked[s], lost[s], dur, lat, inc, min_lat, m);
+        PCC_TL_STAMP(9)  // metrics
         const double reward =  // ns:194,205
             (10.0 * m[PCC_M_RECV_RATE] / (double)(8 * kBytesPerPacket) - 1e3 * m[PCC_M_AVG_LATENCY] -
              2e3 * m[PCC_M_LOSS_RATIO]) * kRewardScale;
@@ -1577,6 +1614,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
                 if (obs) obs[x] = v;
             }
         }
+        PCC_TL_STAMP(10)  // history + observation
         if (lead) {
             D.min_lat[k] = min_lat;
             if (reward_out) reward_out[i * NS + s] = (float)reward;
@@ -1610,7 +1648,8 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         D.done[i] = done;
         if (done_out) done_out[i] = done;
     }
-    if (tl) atomicAdd(reinterpret_cast<unsigned long long *>(&tlw[6]), (unsigned long long)(wall_clock64() - tl_t));  // metrics, history, outputs
+    PCC_TL_STAMP(11)  // outputs
+#undef PCC_TL_STAMP
 }
 
 template <int NS>
@@ -1654,8 +1693,8 @@ __global__ __launch_bounds__(kStepWaves * kWave, 4) void step_kernel(Dev D, uint
                                                                   double *steps_out) {
     const uint32_t tid = threadIdx.x;
     if (D.timeline && tid == 2 * kWave) {  // the workgroup's exit stamp and item count are accumulated atomically below
-        uint64_t *w = D.timeline + ((int64_t)2 * D.n + blockIdx.x) * 8;
-        w[1] = 0; w[2] = 0; w[3] = 0; w[4] = 0; w[5] = 0; w[6] = 0;
+        uint64_t *w = D.timeline + (int64_t)2 * D.n * 8 + (int64_t)blockIdx.x * 16;
+        for (int x = 1; x < 16; x++) w[x] = 0;
     }
     if (tid < 2 * kWave) send_wave<NS, TRACE>(D, blockIdx.x, tid, 0, 0u, actions, actions_f64);
     // the records and cursors the send wavefronts wrote are read by whoever retires the block
@@ -1708,7 +1747,7 @@ __global__ __launch_bounds__(kStepWaves * kWave, 4) void step_kernel(Dev D, uint
     }
     if (D.timeline && lane == 0) {
         // block-level words after the 2 x n_envs wavefront entries: sent/published, last exit, items retired here
-        uint64_t *w = D.timeline + ((int64_t)2 * D.n + blockIdx.x) * 8;
+        uint64_t *w = D.timeline + (int64_t)2 * D.n * 8 + (int64_t)blockIdx.x * 16;
         if (tid == 0) w[0] = tl_sent;
         atomicMax(reinterpret_cast<unsigned long long *>(&w[1]), (unsigned long long)wall_clock64());
         atomicAdd(reinterpret_cast<unsigned long long *>(&w[2]), (unsigned long long)n_items);
@@ -2027,6 +2066,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.heavy_packets = 1e18;  // standing classification off: the tail take-over alone measured best
     d.round_packets = 256;
     d.takeover_lanes = 2;
+    d.help_lanes = 16;
     d.send_envs_per_wave = 64;
     d.heavy_predict = 4096.0;
     sim->fused_step = !(getenv("PCC_FUSED_STEP") && atoi(getenv("PCC_FUSED_STEP")) == 0);
@@ -2091,7 +2131,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         return fail(PCC_EHIP, "initialising the env state failed");
     }
     if (getenv("PCC_DEBUG_TIMELINE") && atoi(getenv("PCC_DEBUG_TIMELINE"))) {
-        sim->timeline_bytes = (size_t)n_envs * 3 * 8 * sizeof(uint64_t);
+        sim->timeline_bytes = (size_t)n_envs * 4 * 8 * sizeof(uint64_t);
         if (hipMalloc(&sim->timeline_blob, sim->timeline_bytes) != hipSuccess ||
             hipMemset(sim->timeline_blob, 0, sim->timeline_bytes) != hipSuccess) {
             pcc_destroy(sim);
@@ -2107,14 +2147,14 @@ int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words) {
     if (!sim || !sim->timeline_blob) return 0;
     DeviceGuard guard(sim->device);
     const int64_t blocks = send_blocks(sim->d);
-    const int64_t total = blocks * 3 * 8;
+    const int64_t total = blocks * 2 * 8 + blocks * 16;
     if (!out || n_words <= 0) return total;
     if (n_words < total) return fail(PCC_EINVAL, "pcc_debug_timeline needs room for %lld words", (long long)total);
     const char *src = static_cast<const char *>(sim->timeline_blob);
     if (hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(out, src, (size_t)blocks * 2 * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(out + blocks * 2 * 8, src + (size_t)sim->d.n * 2 * 8 * sizeof(uint64_t),
-                  (size_t)blocks * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+                  (size_t)blocks * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(PCC_EHIP, "reading the debug timeline failed");
     return total;
 }
@@ -2194,6 +2234,10 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             return PCC_OK;
         case PCC_TUNE_HEAVY_PREDICT: sim->d.heavy_predict = value; return PCC_OK;
         case PCC_TUNE_FUSED_STEP: sim->fused_step = value != 0.0; return PCC_OK;
+        case PCC_TUNE_HELP_LANES:
+            if (!(value >= 0.0 && value <= 64.0)) return fail(PCC_EINVAL, "help_lanes out of range");
+            sim->d.help_lanes = (uint32_t)value;
+            return PCC_OK;
         case PCC_TUNE_TAKEOVER_LANES:
             if (value < 0 || value > 64) return fail(PCC_EINVAL, "takeover_lanes out of range");
             sim->d.takeover_lanes = (uint32_t)value;
@@ -2330,6 +2374,7 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {
         case PCC_F_EP_RETURN: src = d.ep_return; bytes = sn * 8; break;
         case PCC_F_LAST_RETURN: src = d.last_return; bytes = sn * 8; break;
         case PCC_F_TOTAL_SENT: src = d.total_sent; bytes = n * 8; break;
+        case PCC_F_RING_TIER: src = d.ring_tier; bytes = sn; break;
         default: return fail(PCC_EINVAL, "unknown field %d", field);
     }
     DeviceGuard guard(sim->device);

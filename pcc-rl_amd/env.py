@@ -27,7 +27,7 @@ from .spaces import Box
 MAX_STEPS = 400          # ns:41
 DEFAULT_RING_CAPACITY = 32768
 
-_TORCH_DTYPES = {"float64": torch.float64, "int32": torch.int32, "int64": torch.int64}
+_TORCH_DTYPES = {"float64": torch.float64, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8}
 
 
 def _ptr(t):
@@ -163,10 +163,12 @@ class BatchedNetworkEnv(object):
         self._trace = t
 
     def set_tuning(self, heavy_packets=None, heavy_rho=None, round_packets=None, takeover_lanes=None,
-                   send_envs_per_wave=None, heavy_predict=None, fused_step=None):
+                   send_envs_per_wave=None, heavy_predict=None, fused_step=None, help_lanes=None):
         """Performance knobs of the step kernels (results do not depend on them)."""
         if fused_step is not None:
             check(self._L.pcc_set_tuning(self._h, 6, float(fused_step)))
+        if help_lanes is not None:
+            check(self._L.pcc_set_tuning(self._h, 7, float(help_lanes)))
         if heavy_predict is not None:
             check(self._L.pcc_set_tuning(self._h, 5, float(heavy_predict)))
         if send_envs_per_wave is not None:
@@ -310,7 +312,7 @@ class BatchedNetworkEnv(object):
             return None
         out = np.zeros(n, dtype=np.uint64)
         got = int(self._L.pcc_debug_timeline(self._h, out.ctypes.data, n))
-        return out[:got].reshape(-1, 8)
+        return out[:got].reshape(-1, 8)   # 2 rows per env block (wavefronts), then 2 rows (16 words) per workgroup
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

@@ -222,6 +222,9 @@ def test_old_gym_adapter_drop_in():
     dict(heavy_predict=0.0),                             # every env sent by the heavy wavefront from the start
     dict(heavy_packets=16, heavy_rho=10.0),              # standing classification on for every regime
     dict(send_envs_per_wave=7, round_packets=64, takeover_lanes=3),
+    dict(help_lanes=64, takeover_lanes=0, heavy_predict=1e18),   # every round after the first with helper-drawn loss bits
+    dict(help_lanes=0),                                          # never
+    dict(fused_step=0),                                          # pcc_step as two launches
 ])
 def test_send_paths_are_exact_whatever_the_tuning(knobs):
     """The tuning knobs only choose WHICH exact send path runs (lane-serial rounds, the wave-wide
@@ -364,4 +367,47 @@ def test_masked_reset_only_touches_selected_envs():
     o, r, d, info = env.step(a)
     assert bool(torch.isfinite(o).all())
     env.check_flags()
+    env.close()
+
+
+def test_ring_tiers_promote_and_come_back_at_reset(monkeypatch):
+    """Rings start in the small tier, envs with many packets in flight are moved up (without
+    changing a result: the goldens above cover that, fixed_deepq needs the top tier), reset gives the
+    pool rings back, and nothing is ever flagged."""
+    n = 2048
+    monkeypatch.setenv("PCC_RING_POOLS", "1,1,1")   # every env overloads below: worst-case pools
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=3, auto_reset=False)
+    monkeypatch.delenv("PCC_RING_POOLS")
+    env.reset()
+    assert int(env.state("ring_tier").max().item()) <= 1      # two warm-up MIs rarely need more than the small rings
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    for t in range(150):
+        env.step(torch.rand(n, generator=gen, device=DEV) * 2 - 0.5)   # upward drift: queues fill, drops pile up
+    env.check_flags()
+    tiers = env.state("ring_tier")[0].cpu().numpy()
+    in_flight = (env.state("drop_tail") - env.state("drop_head"))[0].cpu().numpy()
+    assert tiers.max() >= 2 and (tiers == 0).any()
+    assert (in_flight <= 2 * 512 * 4.0 ** tiers).all()
+    env.reset()
+    assert int(env.state("ring_tier").max().item()) <= 1
+    for t in range(20):
+        env.step(torch.rand(n, generator=gen, device=DEV) * 2 - 1)
+    env.check_flags()
+    env.close()
+
+
+def test_ring_pool_exhaustion_is_flagged(monkeypatch):
+    """Too few pool rings for the load: flagged (and the overflow that follows), never silent."""
+    monkeypatch.setenv("PCC_RING_POOLS", "1000000,1000000,1000000")   # the minimum: 256 rings per pool
+    n = 4096
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=3, auto_reset=False)
+    monkeypatch.delenv("PCC_RING_POOLS")
+    env.reset()
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    for t in range(200):
+        env.step(torch.rand(n, generator=gen, device=DEV) * 2 - 0.5)
+    flags = env.state("flags").cpu().numpy()
+    assert (flags & pcc_rl_amd.native.PCC_FLAG_POOL_EXHAUSTED).any()
+    with pytest.raises(pcc_rl_amd.PccError):
+        env.check_flags()
     env.close()

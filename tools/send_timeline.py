@@ -35,8 +35,8 @@ for t in range(400):
         env.step_send(acts[t % 64])
     if t in sample:
         raw = env.debug_timeline().astype(np.int64)
-        nb = raw.shape[0] // 3
-        tl, bl = raw[:2 * nb], raw[2 * nb:]
+        nb = raw.shape[0] // 4
+        tl, bl = raw[:2 * nb], raw[2 * nb:].reshape(-1, 16)
         tl = tl[tl[:, 0] > 0]
         t0 = tl[:nb * 2:2, 0].min() if False else tl[tl[:, 0] >= np.median(tl[:, 0]) - 10**7][:, 0].min()
         start, mid, fin = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0   # us
@@ -59,10 +59,9 @@ for t in range(400):
             rec["kernel_span_us"] = float(ext.max())
             rec["items_per_block_min_p50_max"] = [int(bl[:, 2].min()), int(np.median(bl[:, 2])), int(bl[:, 2].max())]
             items = max(1, int(bl[:, 2].sum()))
-            rec["retire_us_per_wave_item"] = {"boundaries+event": float(bl[:, 3].sum()) / 100.0 / items,
-                                              "state": float(bl[:, 4].sum()) / 100.0 / items,
-                                              "rtt_means": float(bl[:, 5].sum()) / 100.0 / items,
-                                              "metrics+history": float(bl[:, 6].sum()) / 100.0 / items}
+            names = {3: "state loads", 4: "boundary search", 5: "candidates+repairs", 6: "ending event", 7: "write-back",
+                     8: "rtt_means", 9: "metrics", 10: "history+obs", 11: "outputs"}
+            rec["retire_us_per_wave_item"] = {v: float(bl[:, k].sum()) / 100.0 / items for k, v in names.items()}
             last = np.argsort(-pub)[:3]
             rec["last_published"] = [{"published": float(pub[i]), "exit": float(ext[i]), "items": int(bl[i, 2])} for i in last]
         out.append(rec)
