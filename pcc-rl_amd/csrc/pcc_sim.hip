@@ -587,8 +587,9 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
 }
 
 template <int NS, bool TRACE>
-__device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, const uint32_t tid, int warm,
-                                          uint32_t warm_mi, const void *actions, int actions_f64) {
+__device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, const uint32_t tid,
+                                          const uint32_t n_heavy_waves, int warm, uint32_t warm_mi, const void *actions,
+                                          int actions_f64) {
     const uint32_t lane = tid & (kWave - 1);
     // Two wavefronts per block of envs.  Wave 0 ("light") runs the lane-per-env rounds for the envs
     // NOT flagged heavy; wave 1 ("heavy") sends the flagged envs one after the other with all 64
@@ -602,7 +603,10 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
     // over the wavefronts) only changes who waits for whom, never a result
     const int64_t i = (in_range && D.send_order) ? (int64_t)D.send_order[slot] : slot;
     const bool flagged = in_range && D.heavy_flag[in_range ? i : 0] != 0;
-    const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]) && (flagged == heavy_wave);
+    // several heavy wavefronts (the fused step has three) deal the flagged envs of the block round-robin
+    const uint32_t flag_rank = (uint32_t)__popcll(__ballot(flagged) & ((1ull << lane) - 1ull));
+    const bool mine = heavy_wave ? (flagged && flag_rank % n_heavy_waves == tid / kWave - 1u) : !flagged;
+    const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]) && mine;
     if (heavy_wave && !__ballot(live)) return;
     const int64_t ii = live ? i : 0;
     const uint64_t tl0 = D.timeline ? wall_clock64() : 0;
@@ -930,7 +934,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
             const uint64_t other = __shfl_xor(mx, o);
             mx = other > mx ? other : mx;
         }
-        if (lane == 0) {
+        if (lane == 0 && tid < 2 * kWave) {
             uint64_t *w = D.timeline + ((int64_t)block * 2 + (heavy_wave ? 1 : 0)) * 8;
             w[0] = tl0; w[1] = tl1; w[2] = wall_clock64(); w[3] = tl_heavy; w[4] = sum; w[5] = mx; w[6] = hp;
             w[7] = (uint64_t)__popcll(__ballot(live));
@@ -953,7 +957,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
 template <int NS, bool TRACE>
 __global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, uint32_t block0, int warm, uint32_t warm_mi,
                                                          const void *actions, int actions_f64) {
-    send_wave<NS, TRACE>(D, block0 + blockIdx.x, threadIdx.x, warm, warm_mi, actions, actions_f64);
+    send_wave<NS, TRACE>(D, block0 + blockIdx.x, threadIdx.x, 1u, warm, warm_mi, actions, actions_f64);
 }
 
 // ======================================================================================
@@ -1669,7 +1673,8 @@ __global__ __launch_bounds__(kRetireBlock, 5) void retire_kernel(Dev D, int64_t 
 
 // ======================================================================================
 // step_kernel: one whole monitor interval per launch.  A workgroup of four wavefronts owns a block
-// of 64 envs: wavefronts 0/1 send for them (send_wave), then all four retire envs, each wavefront 4 at a time.
+// of 64 envs: wavefront 0 sends for the light envs lane-per-env, wavefronts 1-3 share the envs predicted
+// heavy (send_wave), then all four retire envs, each wavefront 4 at a time.
 // Send times are tail-bound -- a few wavefronts carry envs with thousands of packets while most
 // finish early -- so a separate retire launch waits for the slowest wavefront of the whole chip
 // with most SIMDs idle.  Here a workgroup that is done sending publishes its block in a ready list
@@ -1692,11 +1697,12 @@ __global__ __launch_bounds__(kStepWaves * kWave, 4) void step_kernel(Dev D, uint
                                                                   float *obs_out, float *reward_out, uint8_t *done_out,
                                                                   double *steps_out) {
     const uint32_t tid = threadIdx.x;
+
     if (D.timeline && tid == 2 * kWave) {  // the workgroup's exit stamp and item count are accumulated atomically below
         uint64_t *w = D.timeline + (int64_t)2 * D.n * 8 + (int64_t)blockIdx.x * 16;
         for (int x = 1; x < 16; x++) w[x] = 0;
     }
-    if (tid < 2 * kWave) send_wave<NS, TRACE>(D, blockIdx.x, tid, 0, 0u, actions, actions_f64);
+    send_wave<NS, TRACE>(D, blockIdx.x, tid, kStepWaves - 1u, 0, 0u, actions, actions_f64);  // wavefront 0 light, 1-3 heavy
     // the records and cursors the send wavefronts wrote are read by whoever retires the block
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
@@ -2332,7 +2338,10 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
             sim->fused_capacity = step_capacity(sim);
             sim->fused_capacity_key = key;
         }
-        fused = (int64_t)send_blocks(sim->d) <= sim->fused_capacity && send_blocks(sim->d) <= 0xFFFFu;
+        // small grids leave most of the chip empty: two launches spread the retire work over all
+        // CUs, the fused step would retire a block's 64 envs with only its own four wavefronts
+        const int64_t blocks = send_blocks(sim->d);
+        fused = blocks <= sim->fused_capacity && blocks <= 0xFFFF && 2 * blocks >= sim->fused_capacity;
     }
     int rc;
     if (fused) {
