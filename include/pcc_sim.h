@@ -165,7 +165,8 @@ enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKET
                                   envs, then retires envs of whichever blocks are done sending (its
                                   own first), so the retire work fills the SIMDs idle during the send
                                   tail -- whenever the whole grid is resident at once (65 536 envs
-                                  are); 0, or a larger grid: pcc_step_send + pcc_step_retire */,
+                                  are) and fills at least half of the device; 0, or another grid size:
+                                  pcc_step_send + pcc_step_retire; 2: fused for small grids too */,
        PCC_TUNE_HELP_LANES = 7 /* when at most this many lanes (default 16, 0..64) of a wavefront still
                                   have packets to send, the idle lanes compute their Philox blocks:
                                   the loss decisions of a lane's next 256 packets come from one block

@@ -1854,6 +1854,7 @@ struct pcc_sim {
     bool lockstep;      // every env was last reset by the same full reset (host knows when `done` fires)
     uint32_t host_steps;
     bool send_pending;  // pcc_step_send issued, pcc_step_retire not yet
+    bool fused_always;  // ... even for grids that fill less than half of the device (tests)
     bool fused_step;    // pcc_step runs step_kernel (send + work-stealing retire in one launch) when the grid fits
     int fused_capacity; // workgroups of step_kernel the device holds at once
     int fused_capacity_key;
@@ -2239,7 +2240,7 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             sim->d.send_envs_per_wave = (uint32_t)value;
             return PCC_OK;
         case PCC_TUNE_HEAVY_PREDICT: sim->d.heavy_predict = value; return PCC_OK;
-        case PCC_TUNE_FUSED_STEP: sim->fused_step = value != 0.0; return PCC_OK;
+        case PCC_TUNE_FUSED_STEP: sim->fused_step = value != 0.0; sim->fused_always = value == 2.0; return PCC_OK;
         case PCC_TUNE_HELP_LANES:
             if (!(value >= 0.0 && value <= 64.0)) return fail(PCC_EINVAL, "help_lanes out of range");
             sim->d.help_lanes = (uint32_t)value;
@@ -2341,7 +2342,7 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
         // small grids leave most of the chip empty: two launches spread the retire work over all
         // CUs, the fused step would retire a block's 64 envs with only its own four wavefronts
         const int64_t blocks = send_blocks(sim->d);
-        fused = blocks <= sim->fused_capacity && blocks <= 0xFFFF && 2 * blocks >= sim->fused_capacity;
+        fused = blocks <= sim->fused_capacity && blocks <= 0xFFFF && (sim->fused_always || 2 * blocks >= sim->fused_capacity);
     }
     int rc;
     if (fused) {

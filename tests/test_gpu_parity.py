@@ -225,6 +225,8 @@ def test_old_gym_adapter_drop_in():
     dict(help_lanes=64, takeover_lanes=0, heavy_predict=1e18),   # every round after the first with helper-drawn loss bits
     dict(help_lanes=0),                                          # never
     dict(fused_step=0),                                          # pcc_step as two launches
+    dict(fused_step=2),                                          # one launch: send + work-stealing retire
+    dict(fused_step=2, heavy_predict=64.0, takeover_lanes=1),    # ... with all three heavy wavefronts busy
 ])
 def test_send_paths_are_exact_whatever_the_tuning(knobs):
     """The tuning knobs only choose WHICH exact send path runs (lane-serial rounds, the wave-wide
@@ -248,6 +250,8 @@ def test_send_paths_are_exact_whatever_the_tuning(knobs):
     dict(takeover_lanes=0),                              # lane-serial only
     dict(takeover_lanes=64, round_packets=8),            # merge-path wave passes for almost everything
     dict(takeover_lanes=64, round_packets=4, heavy_predict=200.0),
+    dict(fused_step=2),
+    dict(fused_step=2, heavy_predict=100.0),
 ])
 def test_two_sender_philox_batches_match_oracle(knobs):
     """BASELINE.json configs[4] shape (two senders on one link) at a size the oracle finishes in
@@ -279,6 +283,18 @@ def test_two_sender_wave_path_on_golden_trace():
     steps, obs, _ = run_gpu(env, d["actions"], T)
     assert np.array_equal(steps, d["steps"])
     env.close()
+
+
+def test_fused_step_on_golden_traces():
+    """The one-launch step (send, then work-stealing retire) on reference traces."""
+    for name in ("default_pm1", "saturating_0_2", "fixed_deepq"):
+        d = load(name)
+        env = golden_env(d, history_len=int(d["history_len"]))
+        env.set_tuning(fused_step=2)
+        env.reset()
+        steps, obs, done = run_gpu(env, d["actions"], d["actions"].shape[1])
+        assert np.array_equal(steps, d["steps"]), name
+        env.close()
 
 
 def test_wave_path_on_golden_traces():
