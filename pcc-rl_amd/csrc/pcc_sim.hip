@@ -1126,9 +1126,14 @@ __device__ __forceinline__ void near_window(const double2 *ring, uint32_t mask, 
 // t1 + dl < end (members of the boundary window that pass are moved in front, the rest keep
 // their order).  Also reports the best hop-2 candidate (smallest (t2, lat2) key) among the
 // window's unretired records that are already past the forward hop (t1 < end).
-__device__ __noinline__ uint32_t fix_drop_boundary(double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t b,
-                                                   double dl, double end, uint32_t &cand_idx, double &cand_t,
-                                                   double &cand_lat) {
+// (results by value: reference out-parameters of an out-of-line function live in scratch memory)
+struct DropFix { uint32_t p, cand_idx; double cand_t, cand_lat; };
+struct Cand { double t, lat; };
+
+__device__ __noinline__ DropFix fix_drop_boundary(double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t b,
+                                                  double dl, double end) {
+    uint32_t cand_idx;
+    double cand_t, cand_lat;
     uint32_t g0, g1;
     near_window(ring, mask, h, tail, b, g0, g1);
     uint32_t p = g0;
@@ -1151,21 +1156,25 @@ __device__ __noinline__ uint32_t fix_drop_boundary(double2 *ring, uint32_t mask,
             }
         }
     }
-    return p;
+    DropFix out;
+    out.p = p; out.cand_idx = cand_idx; out.cand_t = cand_t; out.cand_lat = cand_lat;
+    return out;
 }
 
 // Best hop-1 candidate of the dropped ring: smallest (t1, lat) among the records still on the
 // forward hop (t1 >= end); c = search transition for `t1 < end`.
-__device__ __noinline__ void drop_hop1_candidate(const double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t c,
-                                                 double end, double &cand_t, double &cand_lat) {
+__device__ __noinline__ Cand drop_hop1_candidate(const double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t c,
+                                                 double end) {
     uint32_t g0, g1;
     near_window(ring, mask, h, tail, c, g0, g1);
-    cand_t = INFINITY;
-    cand_lat = 0.0;
+    double cand_t = INFINITY, cand_lat = 0.0;
     for (uint32_t k = g0; k < g1; k++) {
         const double2 r = ring[k & mask];
         if (!(r.x < end) && (r.x < cand_t || (r.x == cand_t && r.y < cand_lat))) { cand_t = r.x; cand_lat = r.y; }
     }
+    Cand out;
+    out.t = cand_t; out.lat = cand_lat;
+    return out;
 }
 
 // --------------------------------------------------------------------------------------
@@ -1268,8 +1277,11 @@ __device__ __noinline__ LeafPair leaf_sum2(const double2 *ring, uint32_t mask, u
 // recursion (split n -> n/2 rounded down to a multiple of 8 | rest, until <= 128) walked left to
 // right with an explicit stack (depth <= 6).
 struct NpSumWalk {
-    uint32_t right_n[8];
-    double left_sum[8];
+    // the stack lives in registers: every access is a select over the (at most 7) levels, a
+    // dynamically indexed array would go to scratch memory
+    static constexpr int kDepth = 7;  // 8192 -> 4096 -> ... -> 128
+    uint32_t right_n[kDepth];
+    double left_sum[kDepth];
     uint32_t have_left;
     int sp;
     uint32_t cur, pos, left_in_job;
@@ -1279,6 +1291,8 @@ struct NpSumWalk {
     __device__ __forceinline__ void start(uint32_t beg, uint32_t n) {
         pos = beg; left_in_job = n; tot = 0.; sp = 0; have_left = 0; done = n == 0;
         cur = n < kNpBufsize ? n : kNpBufsize;
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) { right_n[k] = 0; left_sum[k] = 0.; }
     }
     __device__ __forceinline__ bool single_leaf() const { return sp == 0 && cur == left_in_job && cur <= 128; }
     // the next leaf: [leaf_beg, leaf_beg + leaf_len)
@@ -1286,7 +1300,9 @@ struct NpSumWalk {
         while (cur > 128) {
             uint32_t n2 = cur / 2;
             n2 -= n2 % 8;
-            right_n[sp] = cur - n2;
+#pragma unroll
+            for (int k = 0; k < kDepth; k++)
+                if (k == sp) right_n[k] = cur - n2;
             have_left &= ~(1u << sp);
             sp++;
             cur = n2;
@@ -1300,12 +1316,17 @@ struct NpSumWalk {
         while (sp > 0) {
             const int top = sp - 1;
             if (!(have_left & (1u << top))) {
-                left_sum[top] = val;
+#pragma unroll
+                for (int k = 0; k < kDepth; k++)
+                    if (k == top) { left_sum[k] = val; cur = right_n[k]; }
                 have_left |= 1u << top;
-                cur = right_n[top];
                 return;  // descend into the right part
             }
-            val = left_sum[top] + val;
+            double l = 0.;
+#pragma unroll
+            for (int k = 0; k < kDepth; k++)
+                if (k == top) l = left_sum[k];
+            val = l + val;
             sp--;
         }
         tot += val;  // one chunk finished (0.0 + x == x for the first)
@@ -1390,11 +1411,12 @@ __device__ __forceinline__ void mi_metrics(uint32_t sent, uint32_t acked, uint32
     m[PCC_M_LATENCY_RATIO] = cm > 0.0 ? lat / cm : 1.0;
 }
 
+// m[id] for a per-lane id without an indexed (= scratch memory) array: OR of masked bit patterns
 __device__ __forceinline__ double select_metric(const double (&m)[PCC_N_METRICS], int id) {
-    double v = m[0];
+    unsigned long long bits = 0ull;
 #pragma unroll
-    for (int k = 1; k < PCC_N_METRICS; k++) v = (id == k) ? m[k] : v;
-    return v;
+    for (int k = 0; k < PCC_N_METRICS; k++) bits |= (id == k) ? (unsigned long long)__double_as_longlong(m[k]) : 0ull;
+    return __longlong_as_double((long long)bits);
 }
 
 template <int NS>
@@ -1470,7 +1492,10 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             if (bnd[2].clean) {
                 if (pd < td[s] && bnd[2].t < end) { dk = pd; d2_t = bnd[2].t + dl; d2_l = bnd[2].lat + dl; }
             } else {
-                if (lead) pd = fix_drop_boundary(rd[s], dmasks[s], hd[s], td[s], bnd[2].b, dl, end, dk, d2_t, d2_l);
+                if (lead) {
+                    const DropFix fx = fix_drop_boundary(rd[s], dmasks[s], hd[s], td[s], bnd[2].b, dl, end);
+                    pd = fx.p; dk = fx.cand_idx; d2_t = fx.cand_t; d2_l = fx.cand_lat;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 pd = gbcast(pd, 0); dk = gbcast(dk, 0); d2_t = gbcast(d2_t, 0); d2_l = gbcast(d2_l, 0);
                 rotated = true;  // records may have moved inside the window
@@ -1483,7 +1508,10 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             } else if (td[s] != pd) {
                 const uint32_t cd = rotated ? search_boundary(g, rd[s], dmasks[s], pd, td[s], 0.0, end)
                                             : (bnd[3].b < pd ? pd : bnd[3].b);
-                if (lead) drop_hop1_candidate(rd[s], dmasks[s], pd, td[s], cd, end, d1_t, d1_l);
+                if (lead) {
+                    const Cand c1 = drop_hop1_candidate(rd[s], dmasks[s], pd, td[s], cd, end);
+                    d1_t = c1.t; d1_l = c1.lat;
+                }
                 d1_t = gbcast(d1_t, 0); d1_l = gbcast(d1_l, 0);
             }
             // ---- best of each kind by the heap key (time, latency, dropped): ns:111,161,178
