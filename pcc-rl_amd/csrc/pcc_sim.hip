@@ -1411,6 +1411,11 @@ __device__ __forceinline__ void mi_metrics(uint32_t sent, uint32_t acked, uint32
     m[PCC_M_LATENCY_RATIO] = cm > 0.0 ? lat / cm : 1.0;
 }
 
+// scale of metric id (so:193-206: 1e7 for the two rate metrics, 1 otherwise) without a table load
+__device__ __forceinline__ double metric_scale(int id) {
+    return (id == PCC_M_SEND_RATE || id == PCC_M_RECV_RATE) ? 1e7 : 1.0;
+}
+
 // m[id] for a per-lane id without an indexed (= scratch memory) array: OR of masked bit patterns
 __device__ __forceinline__ double select_metric(const double (&m)[PCC_N_METRICS], int id) {
     unsigned long long bits = 0ull;
@@ -1591,7 +1596,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
     if (lead) {
         D.now[i] = now;
         if (flags) D.flags[i] |= flags;
-        D.total_sent[i] += sent_total;
+        atomicAdd(&D.total_sent[i], sent_total);  // no return value: nothing waits for the old count
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const int64_t k = (int64_t)s * D.n + i;
@@ -1612,7 +1617,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
                         id == PCC_M_SENT_LATENCY_INFLATION);
     }
     const double dur = now - start;  // ns:311-314
-    double new_run_dur = run_dur;
+    double new_run_dur = run_dur, rate_sum = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
@@ -1620,7 +1625,22 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         PCC_TL_STAMP(7)  // state write-back
         if (acked[s] > 0 && !(D.debug_skip & 1)) rtt_means(g, ra[s], amask[s], from[s], acked[s], dl, need_halves, lat, inc);
         PCC_TL_STAMP(8)  // RTT means
+        // everything the rest of the MI reads, in one batch of loads (one round trip, not five)
+        float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
+        const int keep = D.HF - D.F;
+        const bool small_hist = D.HF <= 2 * kGroup;  // the usual 10 x 3: two passes of 16 lanes
+        float old_row[2] = {0.f, 0.f};                // the history entries this lane rolls down
+        if (small_hist) {
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int x = b * kGroup + (int)g.lane;
+                if (x < keep) old_row[b] = hist[x + D.F];
+            }
+        }
         double min_lat = D.min_lat[k];
+        const double ep_before = D.ep_return[k];
+        const double rate_now = D.rate[k];
+        rate_sum += rate_now;
         double m[PCC_N_METRICS];
         mi_metrics(sent[s], acked[s], lost[s], dur, lat, inc, min_lat, m);
         PCC_TL_STAMP(9)  // metrics
@@ -1630,16 +1650,14 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         if (s == 0 && m[PCC_M_AVG_LATENCY] > 0.0) new_run_dur = 0.5 * m[PCC_M_AVG_LATENCY];  // ns:437-438
 
         // history roll (so:64-66) + observation (ns:400-404, so:68-73), 16 lanes wide
-        float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
         float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
-        const int keep = D.HF - D.F;
         for (int base = 0; base < D.HF && !(D.debug_skip & 2); base += kGroup) {
             const int x = base + (int)g.lane;
             float v = 0.f;
-            if (x < keep) v = hist[x + D.F];
+            if (x < keep) v = small_hist ? (base ? old_row[1] : old_row[0]) : hist[x + D.F];
             else if (x < D.HF) {
                 const int id = D.fid[x - keep];
-                v = (float)(select_metric(m, id) / c_metric_scale[id]);
+                v = (float)(select_metric(m, id) / metric_scale(id));
             }
             if (x < D.HF) {
                 hist[x] = v;
@@ -1650,7 +1668,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         if (lead) {
             D.min_lat[k] = min_lat;
             if (reward_out) reward_out[i * NS + s] = (float)reward;
-            const double ret = D.ep_return[k] + reward;
+            const double ret = ep_before + reward;
             D.ep_return[k] = ret;
             if (steps + 1 >= D.max_steps) D.last_return[k] = ret;
         }
@@ -1661,7 +1679,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             row[PCC_COL_SENT] = (double)sent[s];
             row[PCC_COL_ACKED] = (double)acked[s];
             row[PCC_COL_LOST] = (double)lost[s];
-            row[PCC_COL_RATE] = D.rate[k];
+            row[PCC_COL_RATE] = rate_now;
             row[PCC_COL_CUR_TIME] = now;
             row[PCC_COL_REWARD] = reward;
         }
@@ -1672,8 +1690,6 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         D.run_dur[i] = new_run_dur;
         // prediction for the next MI's send kernel: packets ~ MI length x current rate (the next
         // action moves the rate by at most a few percent)
-        double rate_sum = 0.0;
-        for (int s = 0; s < NS; s++) rate_sum += D.rate[(int64_t)s * D.n + i];
         D.heavy_flag[i] = new_run_dur * rate_sum > D.heavy_predict ? 1 : 0;
         D.steps[i] = steps + 1;
         const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
