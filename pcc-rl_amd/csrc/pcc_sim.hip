@@ -1656,7 +1656,11 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
             float v = 0.f;
             if (x < keep) v = small_hist ? (base ? old_row[1] : old_row[0]) : hist[x + D.F];
             else if (x < D.HF) {
-                const int id = D.fid[x - keep];
+                // fid[] sits in the kernel arguments: a per-lane index would be a memory load (a round
+                // trip per pass), a select over the statically indexed entries is not
+                int id = 0;
+#pragma unroll
+                for (int f = 0; f < kMaxFeatures; f++) id = (x - keep == f) ? D.fid[f] : id;
                 v = (float)(select_metric(m, id) / metric_scale(id));
             }
             if (x < D.HF) {
