@@ -116,7 +116,9 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = 64
     actions = torch.rand((pool, N), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
-    if args.no_fuse:
+    if args.no_fuse or args.share_device:
+        # two processes on one GPU cannot both have their whole grid resident: the one-launch step's
+        # retire queue would wait for workgroups that are not running
         env.set_tuning(fused_step=0)
     env.reset()
     returns_gathered = 0
