@@ -27,13 +27,21 @@
 //     (compile with -ffp-contract=off).  The per-MI RTT means replicate numpy's pairwise
 //     summation bit for bit, because run_dur = 0.5 * mean feeds back into event boundaries.
 //
+// In-flight rings are tiered: small per-sender rings plus pools of 4x/16x/64x larger ones a sender
+// is promoted into (by its whole wavefront, at the start of an MI that could overflow them).
+//
 // Kernels per step:
-//   send_kernel    one lane per env: apply the action, run the SEND recurrence up to the MI end,
+//   step_kernel    (pcc_step when the grid fills the device) one launch: a workgroup sends for
+//                  its 64 envs -- send_wave: a light wavefront with one lane per env, up to three
+//                  heavy wavefronts that send one env at a time with all 64 lanes -- publishes
+//                  the block, and its wavefronts then retire envs of whichever blocks are
+//                  published (retire_env, work stealing off a global queue).
+//   send_kernel    send_wave alone: apply the action, run the SEND recurrence up to the MI end,
 //                  append records (no loads in the loop).
-//   retire_kernel  16 lanes per env: 16-ary searches of the rings for the hop-2 / hop-1
-//                  boundaries (all four advanced together), the MI-ending event, RTT sums as
-//                  numpy's pairwise tree with each 128-sample leaf loaded in one round trip by
-//                  an 8-lane subgroup, metrics, history, observation, reward, done.
+//   retire_kernel  retire_env alone, 16 lanes per env: 16-ary searches of the rings for the
+//                  hop-2 / hop-1 boundaries (all four advanced together), the MI-ending event,
+//                  RTT sums as numpy's pairwise tree with each 128-sample leaf summed in one
+//                  round trip by an 8-lane subgroup, metrics, history, observation, reward, done.
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
