@@ -74,6 +74,20 @@ def cpu_baseline(seconds_budget=20.0, threads=1):
            "sample": "%d env-steps (%d-env x %d-step batches of the bench workload, Philox uniforms, "
                      "%.1f packets/step) on the C oracle, %d thread(s), %.1f s; host has %d cores"
                      % (done_steps, n_envs, n_steps, done_pk / done_steps, threads, t_used, os.cpu_count() or 1)}
+    # the same C oracle on every host core (envs are independent: one env batch per thread)
+    cores = os.cpu_count() or 1
+    if cores > 1:
+        n_all, steps_all, t_all, base_all = 8 * cores, 0, 0.0, 1 << 20
+        while t_all < 5.0:
+            acts = rs.uniform(-1, 1, (n_all, n_steps))
+            t0 = time.perf_counter()
+            oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=0, env_gid_base=base_all, n_threads=cores,
+                             want_obs=False)
+            t_all += time.perf_counter() - t0
+            steps_all += n_all * n_steps
+            base_all += n_all
+        out["all_cores"] = {"value": steps_all / t_all, "unit": "env steps/s", "cores": cores,
+                            "sample": "%d env-steps on %d threads, %.1f s" % (steps_all, cores, t_all)}
     # the same algorithm in the reference's own language (heapq + numpy), for scale: a few episodes
     from oracle.pcc_oracle_py import time_episodes
     py_steps, py_pk, py_s = time_episodes(1000, 2, n_steps=200)

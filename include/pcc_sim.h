@@ -166,7 +166,11 @@ enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKET
                                   own first), so the retire work fills the SIMDs idle during the send
                                   tail -- whenever the whole grid is resident at once (65 536 envs
                                   are) and fills at least half of the device; 0, or another grid size:
-                                  pcc_step_send + pcc_step_retire; 2: fused for small grids too */,
+                                  pcc_step_send + pcc_step_retire; 2: fused for small grids too.  The
+                                  fused step also needs the device to itself: it is not used while the
+                                  process holds more than one handle on the device (they could step
+                                  concurrently on different streams), and two PROCESSES sharing a GPU
+                                  must set 0 */,
        PCC_TUNE_HELP_LANES = 7 /* when at most this many lanes (default 16, 0..64) of a wavefront still
                                   have packets to send, the idle lanes compute their Philox blocks:
                                   the loss decisions of a lane's next 256 packets come from one block

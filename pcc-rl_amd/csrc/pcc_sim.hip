@@ -51,6 +51,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -1910,6 +1911,7 @@ struct pcc_sim {
     bool lockstep;      // every env was last reset by the same full reset (host knows when `done` fires)
     uint32_t host_steps;
     bool send_pending;  // pcc_step_send issued, pcc_step_retire not yet
+    bool counted;       // in g_handles_on_device
     bool fused_always;  // ... even for grids that fill less than half of the device (tests)
     bool fused_step;    // pcc_step runs step_kernel (send + work-stealing retire in one launch) when the grid fits
     int fused_capacity; // workgroups of step_kernel the device holds at once
@@ -1919,6 +1921,11 @@ struct pcc_sim {
 };
 
 namespace {
+
+// handles alive per device: the one-launch step needs the device to itself (two such grids on
+// different streams could each hold part of the CUs and wait for workgroups that cannot start)
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_handles_on_device[kMaxDevices];
 
 struct DeviceGuard {
     int prev = -1;
@@ -2202,6 +2209,8 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         }
         d.timeline = static_cast<uint64_t *>(sim->timeline_blob);
     }
+    if (device < kMaxDevices) g_handles_on_device[device].fetch_add(1);
+    sim->counted = true;
     *out = sim;
     return PCC_OK;
 }
@@ -2224,6 +2233,7 @@ int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words) {
 
 void pcc_destroy(pcc_sim_t *sim) {
     if (!sim) return;
+    if (sim->counted && sim->device < kMaxDevices) g_handles_on_device[sim->device].fetch_sub(1);
     DeviceGuard guard(sim->device);
     if (sim->timeline_blob) (void)hipFree(sim->timeline_blob);
 
@@ -2399,6 +2409,8 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
         // CUs, the fused step would retire a block's 64 envs with only its own four wavefronts
         const int64_t blocks = send_blocks(sim->d);
         fused = blocks <= sim->fused_capacity && blocks <= 0xFFFF && (sim->fused_always || 2 * blocks >= sim->fused_capacity);
+        // another handle on this device may be stepping on another stream at the same time
+        if (sim->device < kMaxDevices && g_handles_on_device[sim->device].load() > 1 && !sim->fused_always) fused = false;
     }
     int rc;
     if (fused) {
