@@ -220,6 +220,25 @@ __device__ __forceinline__ bool near_time(double a, double b) {
     return fabs(a - b) <= kNearTol * fmax(1.0, fabs(b));
 }
 
+// Ring accesses through explicit global-address-space pointers.  The ring addresses are loaded from
+// memory (tiers), which makes them "generic" pointers to the compiler -- flat_load / flat_store,
+// slower than global_load / global_store and counted against the LDS queue as well.
+typedef double gvec2 __attribute__((ext_vector_type(2)));
+#define PCC_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ double2 ld_rec(const double2 *p) {
+    const gvec2 v = *(const PCC_GLOBAL gvec2 *)(const void *)p;
+    double2 r;
+    r.x = v.x; r.y = v.y;
+    return r;
+}
+__device__ __forceinline__ void st_rec(double2 *p, const double2 &r) {
+    gvec2 v;
+    v.x = r.x; v.y = r.y;
+    *(PCC_GLOBAL gvec2 *)(void *)p = v;
+}
+__device__ __forceinline__ double ld_f64(const void *p) { return *(const PCC_GLOBAL double *)p; }
+__device__ __forceinline__ double ld_t1(const double2 *p) { return ld_f64(p); }  // .x of a record
+
 // the rings of one sender: accepted ring of `cap` records at base, dropped ring of 2 * cap after it
 struct RingRef {
     char *base;
@@ -297,8 +316,8 @@ __device__ __forceinline__ bool promote_rings(const Dev &D, uint32_t lane, uint3
     to.cap = tier_cap(D, got);
     to.base = D.tier_base[got < kMaxTiers ? got : 0] + (size_t)slot * tier_slot_bytes(D, got);
     const uint32_t h_a = rl_u32(ha, l), n_a = rl_u32(ta, l) - h_a, h_d = rl_u32(hd, l), n_d = rl_u32(td, l) - h_d;
-    for (uint32_t j = lane; j < n_a; j += kWave) to.accepted()[(h_a + j) & to.mask()] = from.accepted()[(h_a + j) & from.mask()];
-    for (uint32_t j = lane; j < n_d; j += kWave) to.dropped()[(h_d + j) & to.dmask()] = from.dropped()[(h_d + j) & from.dmask()];
+    for (uint32_t j = lane; j < n_a; j += kWave) st_rec(to.accepted() + ((h_a + j) & to.mask()), ld_rec(from.accepted() + ((h_a + j) & from.mask())));
+    for (uint32_t j = lane; j < n_d; j += kWave) st_rec(to.dropped() + ((h_d + j) & to.dmask()), ld_rec(from.dropped() + ((h_d + j) & from.dmask())));
     if (lane == l) {
         D.ring_base[k] = to.base;
         D.ring_tier[k] = (uint8_t)got;
@@ -443,7 +462,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
             rec.y = my_lat;
             const uint32_t off = my_drop ? cap_b + (((st.d + (uint32_t)__popcll(dm & lt)) << 4) & dmask_b)
                                          : (((st.a + (uint32_t)__popcll(am & lt)) << 4) & mask_b);
-            *reinterpret_cast<double2 *>(base + off) = rec;
+            st_rec(reinterpret_cast<double2 *>(base + off), rec);
         }
         st.a += (uint32_t)__popcll(am);
         st.d += (uint32_t)__popcll(dm);
@@ -586,7 +605,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                 const uint32_t cap_b = caps[s] << 4, mask_b = (caps[s] - 1u) << 4, dmask_b = (2u * caps[s] - 1u) << 4;
                 const uint32_t off = my_drop ? cap_b + (((st.d[s] + (uint32_t)__popcll(dm & lt)) << 4) & dmask_b)
                                              : (((st.a[s] + (uint32_t)__popcll(am & lt)) << 4) & mask_b);
-                *reinterpret_cast<double2 *>((s ? base1 : base0) + off) = rec;
+                st_rec(reinterpret_cast<double2 *>((s ? base1 : base0) + off), rec);
             }
             st.a[s] += (uint32_t)__popcll(am);
             st.d[s] += (uint32_t)__popcll(dm);
@@ -706,7 +725,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                         bool dropped;
                         const double2 rec = link_send(t, (loss_bits[k] >> j) & 1ull, dl, maxq, ebw, q, tu, dropped);
                         const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                        *reinterpret_cast<double2 *>(base + off) = rec;
+                        st_rec(reinterpret_cast<double2 *>(base + off), rec);
                         a += dropped ? 0u : 1u;
                         d += dropped ? 1u : 0u;
                         t += gap[0];  // ns:161
@@ -731,7 +750,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                             bool dropped;
                             const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
                             const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                            *reinterpret_cast<double2 *>(base + off) = rec;
+                            st_rec(reinterpret_cast<double2 *>(base + off), rec);
                             a += dropped ? 0u : 1u;
                             d += dropped ? 1u : 0u;
                             t += gap[0];  // ns:161
@@ -747,7 +766,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                             bool dropped;
                             const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
                             const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                            *reinterpret_cast<double2 *>(base + off) = rec;
+                            st_rec(reinterpret_cast<double2 *>(base + off), rec);
                             a += dropped ? 0u : 1u;
                             d += dropped ? 1u : 0u;
                             t += gap[0];  // ns:161
@@ -762,7 +781,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                         bool dropped;
                         const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
                         const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                        *reinterpret_cast<double2 *>(base + off) = rec;
+                        st_rec(reinterpret_cast<double2 *>(base + off), rec);
                         a += dropped ? 0u : 1u;
                         d += dropped ? 1u : 0u;
                         t += gap[0];
@@ -859,7 +878,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                             const uint32_t a_s = s1 ? ta[NS - 1] : ta[0], d_s = s1 ? td[NS - 1] : td[0];
                             const uint32_t off = dropped ? (s1 ? cap_bs[NS - 1] : cap_bs[0]) + ((d_s << 4) & (s1 ? dmask_bs[NS - 1] : dmask_bs[0]))
                                                          : ((a_s << 4) & (s1 ? mask_bs[NS - 1] : mask_bs[0]));
-                            *reinterpret_cast<double2 *>((s1 ? bases[NS - 1] : bases[0]) + off) = rec;
+                            st_rec(reinterpret_cast<double2 *>((s1 ? bases[NS - 1] : bases[0]) + off), rec);
                             const uint32_t acc = dropped ? 0u : 1u, drp = dropped ? 1u : 0u;
                             if (s1) {
                                 ta[NS - 1] += acc; td[NS - 1] += drp; sent[NS - 1]++;  // ns:260-262
@@ -886,7 +905,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                         const uint32_t a_s = s1 ? ta[NS - 1] : ta[0], d_s = s1 ? td[NS - 1] : td[0];
                         const uint32_t off = dropped ? (s1 ? cap_bs[NS - 1] : cap_bs[0]) + ((d_s << 4) & (s1 ? dmask_bs[NS - 1] : dmask_bs[0]))
                                                          : ((a_s << 4) & (s1 ? mask_bs[NS - 1] : mask_bs[0]));
-                        *reinterpret_cast<double2 *>((s1 ? bases[NS - 1] : bases[0]) + off) = rec;
+                        st_rec(reinterpret_cast<double2 *>((s1 ? bases[NS - 1] : bases[0]) + off), rec);
                         const uint32_t acc = dropped ? 0u : 1u, drp = dropped ? 1u : 0u;
                         if (s1) {
                             ta[NS - 1] += acc; td[NS - 1] += drp; sent[NS - 1]++;
@@ -995,7 +1014,7 @@ __device__ __forceinline__ uint32_t search_boundary(const Group &g, const double
         uint32_t sidx = lo + (g.lane + 1) * stride;
         if (sidx > hi) sidx = hi;
         sidx -= 1;
-        const bool pass = ring[sidx & mask].x + add < end;
+        const bool pass = ld_t1(ring + (sidx & mask)) + add < end;
         const uint32_t mfail = ~gballot(g, pass) & 0xFFFFu;
         if (!mfail) return hi;  // the last sample is record hi-1
         const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
@@ -1005,7 +1024,7 @@ __device__ __forceinline__ uint32_t search_boundary(const Group &g, const double
         if (hi < lo) hi = lo;
     }
     const uint32_t k = lo + g.lane;
-    const bool fail = k < hi && !(ring[k & mask].x + add < end);
+    const bool fail = k < hi && !(ld_t1(ring + (k & mask)) + add < end);
     const uint32_t m = gballot(g, fail);
     return m ? lo + (uint32_t)__ffs((int)m) - 1u : hi;
 }
@@ -1042,7 +1061,7 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
             if (x > hi[k]) x = hi[k];
             sidx[k] = x - 1;
             tsamp[k] = 0.0;
-            if (hi[k] - lo[k] > 12u) tsamp[k] = ring[k][sidx[k] & mask[k]].x;
+            if (hi[k] - lo[k] > 12u) tsamp[k] = ld_t1(ring[k] + (sidx[k] & mask[k]));
         }
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -1067,7 +1086,7 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
         base[k] = lo[k] - lo0[k] >= 2u ? lo[k] - 2u : lo0[k];
         const uint32_t idx = base[k] + g.lane;
         r[k].x = 0.0; r[k].y = 0.0;
-        if (idx < hi0[k]) r[k] = ring[k][idx & mask[k]];
+        if (idx < hi0[k]) r[k] = ld_rec(ring[k] + (idx & mask[k]));
     }
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -1098,9 +1117,9 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
 
 // move ring[k] in front of ring[p] (p <= k), keeping the order of the records in between
 __device__ __forceinline__ void rotate_to_front(double2 *ring, uint32_t mask, uint32_t p, uint32_t k) {
-    const double2 r = ring[k & mask];
-    for (uint32_t m = k; m > p; m--) ring[m & mask] = ring[(m - 1) & mask];
-    ring[p & mask] = r;
+    const double2 r = ld_rec(ring + (k & mask));
+    for (uint32_t m = k; m > p; m--) st_rec(ring + (m & mask), ld_rec(ring + ((m - 1) & mask)));
+    st_rec(ring + (p & mask), r);
 }
 
 // Records around a search transition b that may be out of event order: b-1 and b themselves plus
@@ -1111,9 +1130,9 @@ __device__ __forceinline__ void near_window(const double2 *ring, uint32_t mask, 
     g1 = b;
     if (b > h) {
         g0 = b - 1;
-        double t = ring[g0 & mask].x;
+        double t = ld_t1(ring + (g0 & mask));
         while (g0 > h) {
-            const double tp = ring[(g0 - 1) & mask].x;
+            const double tp = ld_t1(ring + ((g0 - 1) & mask));
             if (!near_time(tp, t)) break;
             t = tp;
             g0--;
@@ -1121,9 +1140,9 @@ __device__ __forceinline__ void near_window(const double2 *ring, uint32_t mask, 
     }
     if (b < tail) {
         g1 = b + 1;
-        double t = ring[b & mask].x;
+        double t = ld_t1(ring + (b & mask));
         while (g1 < tail) {
-            const double tn = ring[g1 & mask].x;
+            const double tn = ld_t1(ring + (g1 & mask));
             if (!near_time(tn, t)) break;
             t = tn;
             g1++;
@@ -1147,7 +1166,7 @@ __device__ __noinline__ DropFix fix_drop_boundary(double2 *ring, uint32_t mask, 
     near_window(ring, mask, h, tail, b, g0, g1);
     uint32_t p = g0;
     for (uint32_t k = g0; k < g1; k++) {
-        const double2 r = ring[k & mask];
+        const double2 r = ld_rec(ring + (k & mask));
         if (r.x + dl < end) {
             if (k != p) rotate_to_front(ring, mask, p, k);
             p++;
@@ -1157,7 +1176,7 @@ __device__ __noinline__ DropFix fix_drop_boundary(double2 *ring, uint32_t mask, 
     cand_t = INFINITY;
     cand_lat = 0.0;
     for (uint32_t k = p; k < g1; k++) {
-        const double2 r = ring[k & mask];
+        const double2 r = ld_rec(ring + (k & mask));
         if (r.x < end) {
             const double t2 = r.x + dl, l2 = r.y + dl;
             if (cand_idx == 0xFFFFFFFFu || t2 < cand_t || (t2 == cand_t && l2 < cand_lat)) {
@@ -1178,7 +1197,7 @@ __device__ __noinline__ Cand drop_hop1_candidate(const double2 *ring, uint32_t m
     near_window(ring, mask, h, tail, c, g0, g1);
     double cand_t = INFINITY, cand_lat = 0.0;
     for (uint32_t k = g0; k < g1; k++) {
-        const double2 r = ring[k & mask];
+        const double2 r = ld_rec(ring + (k & mask));
         if (!(r.x < end) && (r.x < cand_t || (r.x == cand_t && r.y < cand_lat))) { cand_t = r.x; cand_lat = r.y; }
     }
     Cand out;
@@ -1236,15 +1255,15 @@ __device__ __noinline__ LeafPair leaf_sum2(const double2 *ring, uint32_t mask, u
 #pragma unroll
     for (int b = 0; b < 8; b++) {
         v[b] = 0.;
-        if ((uint32_t)b < nblkA) v[b] = *reinterpret_cast<const double *>(base + ((oA + 128u * b) & bmask));
+        if ((uint32_t)b < nblkA) v[b] = ld_f64(base + ((oA + 128u * b) & bmask));
     }
-    if (sl < ntA) tvA = *reinterpret_cast<const double *>(base + ((((begA + 8u * nblkA + sl) << 4)) & bmask));
+    if (sl < ntA) tvA = ld_f64(base + ((((begA + 8u * nblkA + sl) << 4)) & bmask));
 #pragma unroll
     for (int b = 0; b < 8; b++) {
         v[8 + b] = 0.;
-        if ((uint32_t)b < n2) v[8 + b] = *reinterpret_cast<const double *>(base + ((o2 + 128u * b) & bmask));
+        if ((uint32_t)b < n2) v[8 + b] = ld_f64(base + ((o2 + 128u * b) & bmask));
     }
-    if (sl < ntB) tvB = *reinterpret_cast<const double *>(base + ((((begB + 8u * nblkB + sl) << 4)) & bmask));
+    if (sl < ntB) tvB = ld_f64(base + ((((begB + 8u * nblkB + sl) << 4)) & bmask));
     double ra = v[0] + dl, rb = v[8] + dl;
 #pragma unroll
     for (int b = 1; b < 8; b++)
@@ -1584,10 +1603,10 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
                 bool dropped;
                 const double2 rec = link_send(t, u < D.lr[i], dl, D.maxq[i], D.ebw[i], q, tu, dropped);
                 if (dropped) {
-                    if (lead) rd[s][td[s] & dmasks[s]] = rec;
+                    if (lead) st_rec(rd[s] + (td[s] & dmasks[s]), rec);
                     td[s]++;
                 } else {
-                    if (lead) ra[s][ta[s] & amask[s]] = rec;
+                    if (lead) st_rec(ra[s] + (ta[s] & amask[s]), rec);
                     ta[s]++;
                 }
                 if (ta[s] - ha[s] > amask[s] + 1u || td[s] - hd[s] > dmasks[s] + 1u) flags |= PCC_FLAG_RING_OVERFLOW;
