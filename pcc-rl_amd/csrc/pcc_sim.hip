@@ -1251,35 +1251,35 @@ __device__ __noinline__ LeafPair leaf_sum2(const double2 *ring, uint32_t mask, u
     const bool wideA = nblkA > 8;
     const uint32_t o2 = wideA ? oA + 1024u : ((begB + sl) << 4);  // upper bank: blocks 8.. of A, or B
     const uint32_t n2 = wideA ? nblkA - 8u : nblkB;
-    double v[16], tvA = 0., tvB = 0.;
+    // Slots without a sample hold -dl: (-dl) + dl is exactly +0.0 and x + 0.0 == x, so every add
+    // below is unconditional -- no compares, no selects -- and still numpy's value bit for bit.
+    const double none = -dl;
+    double v[16], tvA = none, tvB = none;
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        v[b] = 0.;
+        v[b] = none;
         if ((uint32_t)b < nblkA) v[b] = ld_f64(base + ((oA + 128u * b) & bmask));
     }
     if (sl < ntA) tvA = ld_f64(base + ((((begA + 8u * nblkA + sl) << 4)) & bmask));
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        v[8 + b] = 0.;
+        v[8 + b] = none;
         if ((uint32_t)b < n2) v[8 + b] = ld_f64(base + ((o2 + 128u * b) & bmask));
     }
     if (sl < ntB) tvB = ld_f64(base + ((((begB + 8u * nblkB + sl) << 4)) & bmask));
-    double ra = v[0] + dl, rb = v[8] + dl;
+    double ra = v[0] + dl, rb = 0.;
 #pragma unroll
-    for (int b = 1; b < 8; b++)
-        if ((uint32_t)b < nblkA) ra += v[b] + dl;
+    for (int b = 1; b < 8; b++) ra += v[b] + dl;
     if (wideA) {
 #pragma unroll
-        for (int b = 8; b < 16; b++)
-            if ((uint32_t)b < nblkA) ra += v[b] + dl;
+        for (int b = 8; b < 16; b++) ra += v[b] + dl;
     } else {
+        rb = v[8] + dl;
 #pragma unroll
-        for (int b = 1; b < 8; b++)
-            if ((uint32_t)b < nblkB) rb += v[8 + b] + dl;
+        for (int b = 1; b < 8; b++) rb += v[8 + b] + dl;
     }
-    const double fa = fold8(ra), fb = fold8(rb);
-    ra = nblkA ? fa : 0.;
-    rb = nblkB ? fb : 0.;
+    ra = fold8(ra);
+    rb = fold8(rb);
     // leftover sample e comes to lane 0 (and 8) of the row by a DPP shift; the moves are independent
     double ta[7], tb[7];
     ta[0] = tvA; tb[0] = tvB;
@@ -1291,8 +1291,8 @@ __device__ __noinline__ LeafPair leaf_sum2(const double2 *ring, uint32_t mask, u
     ta[6] = dpp_f64<0x106>(tvA); tb[6] = dpp_f64<0x106>(tvB);
 #pragma unroll
     for (int e = 0; e < 7; e++) {
-        if ((uint32_t)e < ntA) ra += ta[e] + dl;
-        if ((uint32_t)e < ntB) rb += tb[e] + dl;
+        ra += ta[e] + dl;
+        rb += tb[e] + dl;
     }
     LeafPair out;
     out.a = ra;
