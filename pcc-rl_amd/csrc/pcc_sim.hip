@@ -1679,18 +1679,22 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
 
         // history roll (so:64-66) + observation (ns:400-404, so:68-73), 16 lanes wide
         float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
+        // the new MI's features: feature f lands in entry keep + f, i.e. in lane (keep + f) % 16 of
+        // one pass.  The ids are wave-uniform (kernel arguments), so each value is picked with scalar
+        // compares and divided only when its scale is not 1 (so:193-206: the two rates)
+        float new_feat = 0.f;
+        for (int f = 0; f < D.F; f++) {
+            const int id = D.fid[f];
+            double val = m[0];
+#pragma unroll
+            for (int q = 1; q < PCC_N_METRICS; q++) val = (id == q) ? m[q] : val;
+            if (id == PCC_M_SEND_RATE || id == PCC_M_RECV_RATE) val = val / 1e7;
+            if (((keep + f) & (kGroup - 1)) == (int)g.lane) new_feat = (float)val;
+        }
         for (int base = 0; base < D.HF && !(D.debug_skip & 2); base += kGroup) {
             const int x = base + (int)g.lane;
-            float v = 0.f;
+            float v = new_feat;  // x in [keep, HF): F <= 16, so a lane owns at most one feature entry
             if (x < keep) v = small_hist ? (base ? old_row[1] : old_row[0]) : hist[x + D.F];
-            else if (x < D.HF) {
-                // fid[] sits in the kernel arguments: a per-lane index would be a memory load (a round
-                // trip per pass), a select over the statically indexed entries is not
-                int id = 0;
-#pragma unroll
-                for (int f = 0; f < kMaxFeatures; f++) id = (x - keep == f) ? D.fid[f] : id;
-                v = (float)(select_metric(m, id) / metric_scale(id));
-            }
             if (x < D.HF) {
                 hist[x] = v;
                 if (obs) obs[x] = v;
