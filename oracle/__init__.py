@@ -79,11 +79,20 @@ def lib():
         L.pcc_oracle_philox.argtypes = [_u32p, _u32p, _u32p]
         L.pcc_oracle_metric_table.argtypes = [_dp, _dp, _dp]
         L.pcc_oracle_mt_fill.argtypes = [ctypes.c_uint64, ctypes.c_long, _dp, ctypes.c_long]
+        L.pcc_oracle_use_cwnd.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.pcc_oracle_cwnd.restype = ctypes.c_long
+        L.pcc_oracle_cwnd.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.pcc_oracle_apply_cwnd_actions.argtypes = [ctypes.c_void_p, _dp, ctypes.c_double]
         L.pcc_oracle_run_batch.restype = ctypes.c_int
         L.pcc_oracle_run_batch.argtypes = [
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int,
             ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, _u64p,
             ctypes.c_long, _dp, ctypes.c_long, _dp, _dp, _dp, _dp, _dp, _dp, _dp, ctypes.c_int]
+        L.pcc_oracle_run_batch_cwnd.restype = ctypes.c_int
+        L.pcc_oracle_run_batch_cwnd.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int,
+            ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, _u64p,
+            ctypes.c_long, _dp, ctypes.c_long, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -161,8 +170,22 @@ class OracleEnv(object):
         self.L.pcc_oracle_reset(self.h, _ptr(obs))
         return obs[0] if self.n_senders == 1 else obs
 
+    def use_cwnd(self, on=True):
+        """The reference's dormant USE_CWND engine option (ns:54): window-limited sending, and
+        step() takes [rate action, cwnd action] (ns:376-377, 413-414)."""
+        self._cwnd = bool(on)
+        self.L.pcc_oracle_use_cwnd(self.h, 1 if on else 0)
+
+    def cwnd(self, sender=0):
+        return int(self.L.pcc_oracle_cwnd(self.h, sender))
+
     def step(self, action):
         a = np.atleast_1d(np.asarray(action, dtype=np.float64))
+        if getattr(self, "_cwnd", False):
+            a = a.reshape(self.n_senders, 2) if a.size == 2 * self.n_senders else a.reshape(1, 2)
+            c = np.ascontiguousarray(a[:, 1])
+            self.L.pcc_oracle_apply_cwnd_actions(self.h, _ptr(c), self.delta_scale)
+            a = np.ascontiguousarray(a[:, 0])
         obs = np.zeros((self.n_senders, self.HF))
         rew = np.zeros(self.n_senders)
         row = np.zeros((self.n_senders, STEP_COLS))
@@ -194,8 +217,10 @@ class OracleEnv(object):
 
 def run_batch(actions, n_senders=1, history_len=10, features=DEFAULT_FEATURES, mean_mode=MEAN_NUMPY,
               delta_scale=0.025, rng_mode=RNG_PHILOX, seed=0, env_gid_base=0, mt_seeds=None, mt_skip=5,
-              trace=None, params=None, n_episodes=1, n_threads=None, want_obs=True):
+              trace=None, params=None, n_episodes=1, n_threads=None, want_obs=True, cwnd_actions=None):
     """Run B independent envs for T steps.  actions: [B, T] or [B, T, n_senders].
+    cwnd_actions (same shape) switches the USE_CWND engine option on and supplies the second
+    action component.
 
     Returns dict(steps [B, S, T, 19], obs [B, S, T, H*F], obs0 [B, S, H*F],
                  params [B, 5+S], warm [B, 2]); S axis squeezed when n_senders == 1.
@@ -216,10 +241,11 @@ def run_batch(actions, n_senders=1, history_len=10, features=DEFAULT_FEATURES, m
     tr = None if trace is None else np.ascontiguousarray(trace, dtype=np.float64).reshape(B, -1)
     ms = None if mt_seeds is None else np.ascontiguousarray(mt_seeds, dtype=np.uint64)
     nt = n_threads if n_threads else (os.cpu_count() or 1)
-    bad = lib().pcc_oracle_run_batch(
+    ca = None if cwnd_actions is None else np.ascontiguousarray(cwnd_actions, dtype=np.float64).reshape(B, T, S)
+    bad = lib().pcc_oracle_run_batch_cwnd(
         B, S, T, n_episodes, history_len, _ptr(fids, _ip), len(fids), mean_mode, delta_scale, rng_mode,
         int(seed), int(env_gid_base), _ptr(ms, _u64p), int(mt_skip), _ptr(tr),
-        0 if tr is None else tr.shape[1], _ptr(p), _ptr(a), _ptr(steps), _ptr(obs), _ptr(obs0),
+        0 if tr is None else tr.shape[1], _ptr(p), _ptr(a), _ptr(ca), _ptr(steps), _ptr(obs), _ptr(obs0),
         _ptr(pout), _ptr(warm), nt)
     if bad:
         raise RuntimeError("loss-uniform trace ran out for env %d" % (bad - 1))

@@ -105,10 +105,15 @@ class Recorder(object):
 
 
 def run_env_episodes(ns, seed, n_steps, action_fn, history_len=10,
-                     features=DEFAULT_FEATURES, fixed=None, n_episodes=1):
-    """One reference env object driven for n_episodes; returns dict of arrays."""
+                     features=DEFAULT_FEATURES, fixed=None, n_episodes=1, cwnd=False):
+    """One reference env object driven for n_episodes; returns dict of arrays.
+
+    cwnd=True runs the engine with its dormant USE_CWND option on (ns:54; a module global the
+    engine reads at call time, set here from outside -- the reference file is not modified):
+    actions are then [rate action, cwnd action] pairs (ns:376-377, 413-414)."""
     rng = CountingRandom(seed)
     ns.random = rng
+    ns.USE_CWND = bool(cwnd)
     env = ns.SimulatedNetworkEnv(history_len=history_len, features=features)
     offsets = []
     orig_create = env.create_new_links_and_senders
@@ -139,10 +144,12 @@ def run_env_episodes(ns, seed, n_steps, action_fn, history_len=10,
         actions = action_fn(rs, n_steps)
         rec = Recorder()
         dones = []
+        cwnds = []
         for t in range(n_steps):
-            obs, reward, done, info = env.step([actions[t]])
+            obs, reward, done, info = env.step(actions[t] if cwnd else [actions[t]])
             rec.row(ns, env, env.net, sender, reward, env.run_dur, obs)
             dones.append(done)
+            cwnds.append(sender.cwnd)
         out.append(dict(params=np.array(params, dtype=np.float64),
                         queue=int(round(params[2])),
                         warm=np.array(warm, dtype=np.float64),
@@ -150,8 +157,10 @@ def run_env_episodes(ns, seed, n_steps, action_fn, history_len=10,
                         obs0=np.asarray(obs0, dtype=np.float64),
                         actions=np.asarray(actions, dtype=np.float64),
                         steps=np.array(rec.rows, dtype=np.float64),
+                        cwnd=np.array(cwnds, dtype=np.int64),
                         obs=np.array(rec.obs, dtype=np.float64),
                         done=np.array(dones, dtype=np.bool_)))
+    ns.USE_CWND = False
     return out
 
 
@@ -166,6 +175,7 @@ def pack(cases, keep_full_obs=2):
     d["obs0"] = np.stack([c["obs0"] for c in cases])
     d["actions"] = np.stack([c["actions"] for c in cases])
     d["steps"] = np.stack([c["steps"] for c in cases])         # [case, step, 7 + 12]
+    d["cwnd"] = np.stack([c["cwnd"] for c in cases])           # [case, step] window after the step's action
     n_feat_hist = cases[0]["obs"].shape[1]
     d["obs_tail"] = np.stack([c["obs"][:, n_feat_hist - c["n_features"]:] for c in cases])
     d["obs_full"] = np.stack([c["obs"] for c in cases[:keep_full_obs]])
@@ -186,6 +196,16 @@ def uniform_0_2(rs, n):
 def uniform_big(rs, n):
     # large swings, both signs: exercises the MIN_RATE/MAX_RATE clamps
     return rs.uniform(-30.0, 30.0, n)
+
+
+def uniform_pm1_pairs(rs, n):
+    # [rate action, cwnd action]: the window stays near its start of 25 packets, below most BDPs
+    return rs.uniform(-1.0, 1.0, (n, 2))
+
+
+def rate_pm1_cwnd_up(rs, n):
+    # the window grows ~5 %/step from 25: the env moves from window-limited to rate-limited
+    return np.stack([rs.uniform(-1.0, 1.0, n), rs.uniform(0.0, 4.0, n)], axis=1)
 
 
 def gen_single(ns, name, seeds, action_fn, n_steps=400, **kw):
@@ -299,6 +319,10 @@ def main():
         gen_single(ns, "fixed_lossy", [3], uniform_pm1, fixed=(300, 0.1, 50, 0.5, 400.0), n_steps=200)
         gen_single(ns, "fixed_deepq", [4], uniform_0_2, fixed=(100, 0.05, 2981, 0.0, 150.0), n_steps=200)
         gen_two_sender(ns, "two_sender", range(400, 406))
+        gen_single(ns, "cwnd_pm1", range(500, 508), uniform_pm1_pairs, cwnd=True)
+        gen_single(ns, "cwnd_grow", range(520, 524), rate_pm1_cwnd_up, n_steps=200, cwnd=True)
+        gen_single(ns, "cwnd_fixed_deepq", [5], rate_pm1_cwnd_up, fixed=(100, 0.05, 2981, 0.0, 150.0), n_steps=200,
+                   cwnd=True)
     finally:
         os.chdir(cwd)
 

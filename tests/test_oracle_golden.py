@@ -68,8 +68,11 @@ def check_episode(env, d, i, fixed=None):
     T = d["actions"].shape[1]
     HF = obs0.size
     nf = d["obs_tail"].shape[2]
+    cwnd = d["actions"].ndim == 3   # [rate action, cwnd action] pairs: the USE_CWND fixtures
     for t in range(T):
-        obs, rew, done, info = env.step([d["actions"][i, t]])
+        obs, rew, done, info = env.step(d["actions"][i, t] if cwnd else [d["actions"][i, t]])
+        if cwnd:
+            assert env.cwnd() == int(d["cwnd"][i, t])
         row = env.last_row[0]
         g = d["steps"][i, t]
         assert np.array_equal(row, g), (i, t, row - g)
@@ -117,6 +120,25 @@ def test_fixed_param_episodes_bit_exact(name):
         check_episode(env, d, i, fixed=(bw, dl, queue, loss, rate0))
         assert env.rng_draws == int(d["rng"][i][1])
         env.close()
+
+
+@pytest.mark.parametrize("name", ["cwnd_pm1", "cwnd_grow", "cwnd_fixed_deepq"])
+def test_use_cwnd_engine_option_bit_exact(name):
+    """The reference's dormant USE_CWND option (ns:54): window-limited sending incl. its quirk that
+    a SEND blocked by the window still passes through the link's queue and RNG (ns:158-175)."""
+    d = load(name)
+    feats = [str(f) for f in d["features"]]
+    fixed = tuple(d["fixed"]) if "fixed" in d else None
+    for i in range(d["seed"].shape[0]):
+        env = run_case_mt(d, i, int(d["history_len"]), feats)
+        env.use_cwnd(True)
+        check_episode(env, d, i, fixed=fixed)
+        assert env.rng_draws == int(d["rng"][i][1])
+        env.close()
+    if name == "cwnd_pm1":
+        assert (d["steps"][..., 0] == 0).any()      # some MIs are fully blocked by the window ...
+    else:
+        assert d["cwnd"].max() == 5000              # ... and the window can open up to MAX_CWND
 
 
 def test_two_sender_engine_bit_exact():
