@@ -87,6 +87,7 @@ enum {
     PCC_F_LAST_RETURN,   /* f64 [S][N]  return of the last finished episode            */
     PCC_F_TOTAL_SENT,    /* u64 [N]     packets sent since create (all episodes, all senders) */
     PCC_F_RING_TIER,     /* u8  [S][N]  tier of the sender's in-flight rings (0 = its own small rings) */
+    PCC_F_CWND,          /* u32 [N]     congestion window, packets (pcc_set_cwnd_mode)    (ns:227) */
     PCC_N_FIELDS
 };
 
@@ -183,6 +184,18 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
  * depend on it.  A good order deals the envs with the most predicted packets (run_dur * rate)
  * round-robin over the wavefronts (BatchedNetworkEnv(balance_every=...) does that). */
 int pcc_set_send_order(pcc_sim_t *sim, const uint32_t *order);
+
+/* The reference's dormant engine option USE_CWND (ns:54; off in the reference): window-limited
+ * sending.  A SEND event launches a packet only while fewer than cwnd packets are unacknowledged
+ * (ns:251-255; acknowledgements and loss reports arrive one RTT after the send, ns:264-273); a
+ * blocked SEND still passes through the link's queue and loss draw, as in the reference
+ * (ns:158-175).  Every new episode starts with cwnd = 25 (ns:209).  With the option on, the actions
+ * of pcc_step / pcc_step_send are [N][2] = (rate action, cwnd action) (ns:376-377, 412-414): the
+ * second moves the window like the first moves the rate (x (1 + a*delta_scale) or / (1 - a*
+ * delta_scale)), truncated to an integer and clamped to [4, 5000] (ns:33-34, 283-289).  One sender
+ * per env only; pcc_reset must follow.  This path is lane-serial (no wave path, no fused step
+ * speed-ups apply); it is exact like the others. */
+int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable);
 
 /* DELTA_SCALE (src/common/config.py:17, default 0.025) and MAX_STEPS (ns:41, default 400) */
 int pcc_set_delta_scale(pcc_sim_t *sim, double delta_scale);

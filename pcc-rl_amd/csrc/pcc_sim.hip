@@ -129,6 +129,11 @@ struct Dev {
     // per sender, [S][N]
     double *rate, *rate0, *next_send, *min_lat, *ep_return, *last_return;
     uint32_t *ha, *hd, *ta, *td, *mi_sent;  // accepted/dropped ring heads and tails
+    // the reference's dormant USE_CWND engine option (ns:54), one sender only
+    int use_cwnd;
+    uint32_t *cwnd;        // [N] congestion window, packets (ns:227: 25 for every new sender)
+    uint32_t *mi_draws;    // [N] link-entry draws of the MI made by the send half (a SEND the window blocks still draws)
+    uint32_t *ep_draws;    // [N] ... of the episode: the position in a replayed loss trace
     float *hist;    // [N][S][HF]
     double2 *ring;  // [N][S][2][cap]: accepted ring, dropped ring
 };
@@ -656,7 +661,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
         const int64_t k = (int64_t)s * D.n + ii;
         double rate = D.rate[k];
         if (!warm && live) {
-            const int64_t a = ii * NS + s;
+            const int64_t a = D.use_cwnd ? ii * 2 : ii * NS + s;  // USE_CWND: [rate action, cwnd action] per env
             double delta = actions_f64 ? ((const double *)actions)[a] : (double)((const float *)actions)[a];
             delta *= D.delta_scale;
             rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
@@ -702,6 +707,72 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
         const bool always = thr_d >= 4294967296.0;
         const uint32_t thr = always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
         char *base = rings[0].base;
+        if (D.use_cwnd) {
+            // ---- USE_CWND (ns:54, 251-255, 158-160): a SEND goes out only while fewer than cwnd
+            // packets are unacknowledged.  That couples the SEND stream to the notifications, so this
+            // path is lane-serial with two cursors over the lane's own rings: everything acknowledged
+            // or reported lost at or before the SEND time (ACK events sort before a SEND of the same
+            // time, ns:42-43) is no longer in flight.  A blocked SEND still passes through the link's
+            // queue and takes its loss draw (ns:170-175 are outside the `if`): it updates (q, tu) and
+            // the RNG position, but leaves no record and is not counted as sent.
+            uint32_t cw = D.cwnd[ii];
+            if (!warm && live) {  // apply_cwnd_delta + set_cwnd: ns:243-249, 283-289
+                const int64_t ai = ii * 2 + 1;
+                double delta = actions_f64 ? ((const double *)actions)[ai] : (double)((const float *)actions)[ai];
+                delta *= D.delta_scale;
+                const double c = delta >= 0.0 ? (double)cw * (1.0 + delta) : (double)cw / (1.0 - delta);
+                cw = c >= 5000.0 ? 5000u : (c < 4.0 ? 4u : (uint32_t)c);  // int(), then [MIN_CWND, MAX_CWND] (ns:33-34)
+                D.cwnd[ii] = cw;
+            }
+            const double2 *acc = rings[0].accepted(), *drp = rings[0].dropped();
+            const uint32_t amask_r = rings[0].mask(), dmask_r = rings[0].dmask();
+            double t = nsend[0];
+            uint32_t a = ta[0], d = td[0], pa = ha[0], pd = hd[0], draws = 0, nsent = 0;
+            const uint32_t ep0 = D.ep_draws[ii];
+            while (run && t < end) {
+                while (pa != a && ld_t1(acc + (pa & amask_r)) + dl <= t) pa++;
+                while (pd != d && ld_t1(drp + (pd & dmask_r)) + dl <= t) pd++;
+                uint32_t extra = 0;  // later members of a near group of drops that are due although record pd is not
+                if (pd != d) {
+                    double tp = ld_t1(drp + (pd & dmask_r));
+                    if (near_time(tp + dl, t)) {
+                        for (uint32_t k = pd + 1; k != d; k++) {
+                            const double tk = ld_t1(drp + (k & dmask_r));
+                            if (!near_time(tk, tp)) break;
+                            if (tk + dl <= t) extra++;
+                            tp = tk;
+                        }
+                    }
+                }
+                const bool can_send = (a - pa) + (d - pd) - extra < cw;
+                double u;
+                if (TRACE) {
+                    const uint64_t pos = (uint64_t)ep0 + draws;
+                    if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
+                    else u = trace[pos];
+                } else {
+                    u = philox_packet_uniform(D, gid, episode, mi, draws);
+                }
+                draws++;
+                bool dropped;
+                const double2 rec = link_send(t, u < lr, dl, maxq, ebw, q, tu, dropped);
+                if (can_send) {
+                    const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
+                    st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                    a += dropped ? 0u : 1u;
+                    d += dropped ? 1u : 0u;
+                    nsent++;
+                }
+                t += gap[0];  // ns:161: the next SEND is scheduled either way
+            }
+            if (live) {
+                D.mi_draws[ii] = draws;
+                D.ep_draws[ii] = ep0 + draws;
+            }
+            nsend[0] = t;
+            sent[0] = nsent;
+            ta[0] = a; td[0] = d;
+        } else {
         // heavy = many packets ahead, most of them drops (rate well above bw), and the wave path's
         // standing preconditions hold; everything else stays in the lane-serial loop
         const bool heavy = run && (heavy_wave || ((end - nsend[0]) > D.heavy_packets * gap[0] && gap[0] < D.heavy_rho * ebw &&
@@ -843,6 +914,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
         sent[0] = (a - ta[0]) + (d - td[0]);
         ta[0] = a; td[0] = d;
         if (D.timeline && heavy_now) tl_heavy_pk += sent[0];
+        }  // !use_cwnd
     } else {
         // two senders merged in (time, sender id) order: lane-serial rounds, then the tail of the
         // wave goes to the two-sender wave path
@@ -1594,15 +1666,27 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
                     uint32_t j = 0;
 #pragma unroll
                     for (int x = 0; x < NS; x++) j += sent[x];
+                    if (D.use_cwnd) j = D.mi_draws[i];  // draws, not packets: blocked SENDs drew too
                     u = philox_packet_uniform(D, D.gid_base + (uint32_t)i, D.episode[i] - 1,
                                               warm ? warm_mi : steps + 2, j);
                 }
+                if (D.use_cwnd && D.rng_mode == PCC_RNG_TRACE) {
+                    const uint32_t pos = D.ep_draws[i];
+                    if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
+                    else u = D.trace[i * D.trace_stride + pos];
+                }
+                // USE_CWND (ns:251-255): everything due before this event is retired, so what is in
+                // flight is exactly what the rings still hold
+                const bool can_send = !D.use_cwnd || (ta[s] - ha[s]) + (td[s] - hd[s]) < D.cwnd[i];
+                if (D.use_cwnd && lead) D.ep_draws[i] += 1u;
                 const double rate = D.rate[(int64_t)s * D.n + i];
-                sent[s]++;
+                sent[s] += can_send ? 1u : 0u;
                 nsend[s] = t + 1.0 / rate;
                 bool dropped;
                 const double2 rec = link_send(t, u < D.lr[i], dl, D.maxq[i], D.ebw[i], q, tu, dropped);
-                if (dropped) {
+                if (!can_send) {
+                    // blocked by the window: the link saw it (queue, draw), nothing is in flight
+                } else if (dropped) {
                     if (lead) st_rec(rd[s] + (td[s] & dmasks[s]), rec);
                     td[s]++;
                 } else {
@@ -1726,7 +1810,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         D.run_dur[i] = new_run_dur;
         // prediction for the next MI's send kernel: packets ~ MI length x current rate (the next
         // action moves the rate by at most a few percent)
-        D.heavy_flag[i] = new_run_dur * rate_sum > D.heavy_predict ? 1 : 0;
+        D.heavy_flag[i] = (!D.use_cwnd && new_run_dur * rate_sum > D.heavy_predict) ? 1 : 0;  // the window path is lane-serial
         D.steps[i] = steps + 1;
         const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
         D.done[i] = done;
@@ -1880,6 +1964,8 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
     D.steps[i] = 0;
     D.done[i] = 0;
     D.heavy_flag[i] = 0;  // the warm-up MIs and the first step run in the light wave
+    D.cwnd[i] = 25;       // ns:209, 227
+    D.mi_draws[i] = 0; D.ep_draws[i] = 0;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
@@ -1988,6 +2074,7 @@ size_t carve_state(Dev &d, char *base) {
     d.min_lat = c.take<double>(sn); d.ep_return = c.take<double>(sn); d.last_return = c.take<double>(sn);
     d.ha = c.take<uint32_t>(sn); d.hd = c.take<uint32_t>(sn); d.ta = c.take<uint32_t>(sn); d.td = c.take<uint32_t>(sn);
     d.mi_sent = c.take<uint32_t>(sn);
+    d.cwnd = c.take<uint32_t>(n); d.mi_draws = c.take<uint32_t>(n); d.ep_draws = c.take<uint32_t>(n);
     d.ring_base = c.take<char *>(sn);
     d.ring_held = c.take<uint32_t>(sn * kMaxTiers);
     d.ring_tier = c.take<uint8_t>(sn);
@@ -2342,6 +2429,15 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
     }
 }
 
+int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable) {
+    if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    if (enable && sim->d.ns != 1) return fail(PCC_EINVAL, "the congestion-window option supports one sender per env");
+    if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_cwnd_mode between pcc_step_send and pcc_step_retire");
+    sim->d.use_cwnd = enable ? 1 : 0;
+    sim->ever_reset = false;  // in-flight accounting differs: a reset must follow
+    return PCC_OK;
+}
+
 int pcc_set_delta_scale(pcc_sim_t *sim, double delta_scale) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     sim->d.delta_scale = delta_scale;
@@ -2476,6 +2572,7 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {
         case PCC_F_LAST_RETURN: src = d.last_return; bytes = sn * 8; break;
         case PCC_F_TOTAL_SENT: src = d.total_sent; bytes = n * 8; break;
         case PCC_F_RING_TIER: src = d.ring_tier; bytes = sn; break;
+        case PCC_F_CWND: src = d.cwnd; bytes = n * 4; break;
         default: return fail(PCC_EINVAL, "unknown field %d", field);
     }
     DeviceGuard guard(sim->device);

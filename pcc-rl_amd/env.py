@@ -54,7 +54,7 @@ class BatchedNetworkEnv(object):
 
     def __init__(self, n_envs, device="cuda", history_len=None, features=None, seed=0, n_senders=1,
                  link_params=None, env_gid_base=0, ring_capacity=0, auto_reset=True, delta_scale=None,
-                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False, balance_every=0):
+                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False, balance_every=0, use_cwnd=False):
         if history_len is None:
             history_len = arg_or_default("--history-len", default=10)
         if features is None:
@@ -85,6 +85,12 @@ class BatchedNetworkEnv(object):
         self._L = L
         check(L.pcc_set_delta_scale(self._h, float(DELTA_SCALE if delta_scale is None else delta_scale)))
         check(L.pcc_set_max_steps(self._h, self.max_steps))
+        # the reference's dormant USE_CWND engine option (ns:54): window-limited sending, actions
+        # become [rate action, cwnd action] (ns:376-377, 412-414)
+        self.use_cwnd = bool(use_cwnd)
+        self.action_dim = 2 if self.use_cwnd else 1
+        if self.use_cwnd:
+            check(L.pcc_set_cwnd_mode(self._h, 1))
 
         N, S, D = self.n_envs, self.n_senders, self.obs_dim
         with torch.cuda.device(self.device):
@@ -109,7 +115,8 @@ class BatchedNetworkEnv(object):
         single = get_min_obs_vector(self.features), get_max_obs_vector(self.features)
         self.single_observation_space = Box(np.tile(single[0], self.history_len), np.tile(single[1], self.history_len),
                                             dtype=np.float32)                       # ns:382-388
-        self.single_action_space = Box(np.array([-1e12] * 1), np.array([1e12] * 1), dtype=np.float32)  # ns:379
+        self.single_action_space = Box(np.array([-1e12] * self.action_dim), np.array([1e12] * self.action_dim),
+                                       dtype=np.float32)                             # ns:376-379
         self.observation_space = self.single_observation_space
         self.action_space = self.single_action_space
         self.num_envs = self.n_envs
@@ -215,10 +222,11 @@ class BatchedNetworkEnv(object):
             a = a.to(self.device)
         if a.dtype not in (torch.float32, torch.float64):
             a = a.to(torch.float32)
-        if a.numel() != self.n_envs * self.n_senders:
-            raise ValueError("actions has %d elements, expected n_envs*n_senders = %d"
-                             % (a.numel(), self.n_envs * self.n_senders))
-        return a.reshape(self.n_envs, self.n_senders).contiguous()
+        width = self.n_senders * self.action_dim
+        if a.numel() != self.n_envs * width:
+            raise ValueError("actions has %d elements, expected n_envs * %d = %d"
+                             % (a.numel(), width, self.n_envs * width))
+        return a.reshape(self.n_envs, width).contiguous()
 
     def rebalance(self):
         """Deal the envs over the send kernel's wavefronts by predicted packets in the next interval
@@ -345,9 +353,10 @@ class SimulatedNetworkEnv(object):
 
     metadata = {"render.modes": []}
 
-    def __init__(self, history_len=None, features=None, device="cuda", seed=0, link_params=None):
+    def __init__(self, history_len=None, features=None, device="cuda", seed=0, link_params=None, use_cwnd=False):
         self._env = BatchedNetworkEnv(1, device=device, history_len=history_len, features=features, seed=seed,
-                                      link_params=link_params, auto_reset=False, record_steps=True)
+                                      link_params=link_params, auto_reset=False, record_steps=True,
+                                      use_cwnd=use_cwnd)
         self.history_len = self._env.history_len
         self.features = self._env.features
         self.observation_space = self._env.single_observation_space
@@ -378,8 +387,11 @@ class SimulatedNetworkEnv(object):
     def step(self, actions):
         if self.run_dur is None:
             raise TypeError("step() called before reset(): run_dur is None")  # what ns:368,416 raises
-        a = float(np.asarray(actions, dtype=np.float64).reshape(-1)[0])       # ns:409-412: only action[0]
-        act = torch.tensor([[a]], dtype=torch.float64, device=self._env.device)
+        flat = np.asarray(actions, dtype=np.float64).reshape(-1)
+        a = [float(flat[0])]                                                  # ns:409-412: action[0] ...
+        if self._env.use_cwnd:
+            a.append(float(flat[1]))                                          # ... and action[1] with USE_CWND (ns:413-414)
+        act = torch.tensor([a], dtype=torch.float64, device=self._env.device)
         obs, reward, done, info = self._env.step(act)
         row = info["steps"][0].cpu().numpy()
         reward = float(row[native.STEP_COLUMNS.index("reward")])

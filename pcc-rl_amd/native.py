@@ -24,12 +24,12 @@ FIELDS = {
     "rate0": (12, "float64", True), "next_send": (13, "float64", True), "min_lat": (14, "float64", True),
     "acc_head": (15, "int32", True), "acc_tail": (16, "int32", True), "drop_head": (17, "int32", True),
     "drop_tail": (18, "int32", True), "ep_return": (19, "float64", True), "last_return": (20, "float64", True),
-    "total_sent": (21, "int64", False), "ring_tier": (22, "uint8", True),
+    "total_sent": (21, "int64", False), "ring_tier": (22, "uint8", True), "cwnd": (23, "int32", False),
 }
 
 # every symbol include/pcc_sim.h declares
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
-           "pcc_set_rng", "pcc_set_seed", "pcc_set_send_order", "pcc_set_tuning", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
+           "pcc_set_rng", "pcc_set_seed", "pcc_set_send_order", "pcc_set_tuning", "pcc_set_cwnd_mode", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
            "pcc_step_retire",
            "pcc_get_state", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline"]
 
@@ -70,6 +70,8 @@ def lib():
     L.pcc_set_send_order.restype = i32
     L.pcc_set_tuning.argtypes = [vp, i32, dbl]
     L.pcc_set_tuning.restype = i32
+    L.pcc_set_cwnd_mode.argtypes = [vp, i32]
+    L.pcc_set_cwnd_mode.restype = i32
     L.pcc_set_delta_scale.argtypes = [vp, dbl]
     L.pcc_set_max_steps.argtypes = [vp, i32]
     L.pcc_reset.argtypes = [vp, vp, vp, vp]

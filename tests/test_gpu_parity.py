@@ -427,3 +427,56 @@ def test_ring_pool_exhaustion_is_flagged(monkeypatch):
     with pytest.raises(pcc_rl_amd.PccError):
         env.check_flags()
     env.close()
+
+
+@pytest.mark.parametrize("name", ["cwnd_pm1", "cwnd_grow", "cwnd_fixed_deepq"])
+def test_use_cwnd_goldens_bit_exact(name):
+    """The reference's dormant USE_CWND engine option (window-limited sending, 2-D actions) on
+    traces of the unmodified reference, incl. its quirk that a blocked SEND still passes through the
+    link's queue and loss draw."""
+    d = load(name)
+    n = d["seed"].shape[0]
+    feats = [str(f) for f in d["features"]]
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, history_len=int(d["history_len"]), features=feats,
+                                       record_steps=True, auto_reset=False, use_cwnd=True)
+    p = d["params"]
+    env.set_link_params(p[:, 0], p[:, 1], np.round(p[:, 2]), p[:, 3], p[:, 4])
+    k = int((d["rng"][:, 1] - d["rng"][:, 0]).max())
+    trace = np.stack([oracle.mt_uniforms(int(s), k, skip=int(o)) for s, o in zip(d["seed"], d["rng"][:, 0])])
+    env.set_loss_trace(trace)
+    obs0 = env.reset().cpu().numpy()
+    assert np.array_equal(obs0, d["obs0"].astype(np.float32))
+    assert np.array_equal(env.state("now").cpu().numpy(), d["warm"][:, 0])
+    T = d["actions"].shape[1]
+    rows, cw = [], []
+    for t in range(T):
+        o, r, dn, info = env.step(d["actions"][:, t])          # [n, 2]
+        rows.append(info["steps"].clone())
+        cw.append(env.state("cwnd").clone())
+    env.check_flags()
+    steps = torch.stack(rows, 1).cpu().numpy()
+    assert np.array_equal(torch.stack(cw, 1).cpu().numpy(), d["cwnd"])
+    assert np.array_equal(steps[..., :3], d["steps"][..., :3])
+    assert np.array_equal(steps, d["steps"])
+    env.close()
+
+
+def test_use_cwnd_philox_batch_matches_oracle():
+    n_envs, n_steps, seed = 300, 120, 77
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=False,
+                                       use_cwnd=True)
+    env.reset()
+    rs = np.random.RandomState(seed)
+    acts = rs.uniform(-1, 1, (n_envs, n_steps, 2))
+    acts[..., 1] = rs.uniform(-1, 3, (n_envs, n_steps))      # windows drift up: blocked and unblocked phases
+    rows, obs = [], []
+    for t in range(n_steps):
+        o, r, dn, info = env.step(acts[:, t])
+        rows.append(info["steps"].clone()); obs.append(o.clone())
+    env.check_flags()
+    steps = torch.stack(rows, 1).cpu().numpy()
+    ref = oracle.run_batch(acts[..., 0], rng_mode=oracle.RNG_PHILOX, seed=seed, cwnd_actions=acts[..., 1])
+    assert np.array_equal(steps[..., :3], ref["steps"][..., :3])
+    assert np.array_equal(steps, ref["steps"])
+    assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), ref["obs"].astype(np.float32))
+    env.close()
