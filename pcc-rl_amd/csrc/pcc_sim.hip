@@ -143,17 +143,6 @@ struct Dev {
 // --------------------------------------------------------------------------------------
 __device__ __forceinline__ double max0(double x) { return x > 0.0 ? x : 0.0; }  // max(0.0, x)
 
-__device__ __forceinline__ bool rec_dropped(double2 r) { return __double_as_longlong(r.y) < 0; }
-
-// Python tuple order on (time, latency, dropped): the fields that can differ between two events
-// of the same kind of one sender (ns:111,161,178).  y carries the drop flag in its sign.
-__device__ __forceinline__ bool key_less(double ta, double ya, double tb, double yb) {
-    if (ta != tb) return ta < tb;
-    const double la = fabs(ya), lb = fabs(yb);
-    if (la != lb) return la < lb;
-    return (__double_as_longlong(ya) >= 0) && (__double_as_longlong(yb) < 0);
-}
-
 __device__ __forceinline__ uint64_t mul_wide_u32(uint32_t a, uint32_t b) {
     uint64_t r;
     asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "vcc");
@@ -289,13 +278,6 @@ __device__ __forceinline__ double rl_f64(double v, uint32_t l) {
 __device__ __forceinline__ uint64_t rl_u64(uint64_t v, uint32_t l) {
     const uint32_t lo = rl_u32((uint32_t)v, l), hi = rl_u32((uint32_t)(v >> 32), l);
     return ((uint64_t)hi << 32) | lo;
-}
-// make a wave-uniform value provably uniform for the compiler (scalar registers, scalar branches)
-__device__ __forceinline__ uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ double uni_f64(double v) {
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
 }
 // Move the rings of sender k (lane `l` of the wavefront owns it) to a free slot of tier >= want:
 // all 64 lanes copy the live records [ha, ta) / [hd, td); ring indices stay what they are, only
@@ -1509,11 +1491,6 @@ __device__ __forceinline__ void mi_metrics(uint32_t sent, uint32_t acked, uint32
     m[PCC_M_SEND_RATIO] = (m[PCC_M_RECV_RATE] > 0.0 && m[PCC_M_SEND_RATE] < 1000.0 * m[PCC_M_RECV_RATE])
                               ? m[PCC_M_SEND_RATE] / m[PCC_M_RECV_RATE] : 1.0;
     m[PCC_M_LATENCY_RATIO] = cm > 0.0 ? lat / cm : 1.0;
-}
-
-// scale of metric id (so:193-206: 1e7 for the two rate metrics, 1 otherwise) without a table load
-__device__ __forceinline__ double metric_scale(int id) {
-    return (id == PCC_M_SEND_RATE || id == PCC_M_RECV_RATE) ? 1e7 : 1.0;
 }
 
 // m[id] for a per-lane id without an indexed (= scratch memory) array: OR of masked bit patterns
