@@ -480,3 +480,33 @@ def test_use_cwnd_philox_batch_matches_oracle():
     assert np.array_equal(steps, ref["steps"])
     assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), ref["obs"].astype(np.float32))
     env.close()
+
+
+def test_grouped_env_is_the_same_envs_on_several_streams():
+    """GroupedNetworkEnv: groups stepped on their own streams give the numbers of one batch."""
+    n, T, seed = 512, 80, 9
+    one = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=seed, auto_reset=False)
+    grp = pcc_rl_amd.GroupedNetworkEnv(n, 4, device=DEV, seed=seed, auto_reset=False)
+    o1 = one.reset().clone()
+    og = grp.reset()
+    assert torch.equal(o1, og)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    acts = torch.rand((T, n), generator=gen, device=DEV) * 2 - 1
+    ref_obs, ref_rew = [], []
+    for t in range(T):
+        o, r, d, _ = one.step(acts[t])
+        ref_obs.append(o.clone()); ref_rew.append(r.clone())
+    got_obs = [[None] * 4 for _ in range(T)]
+    got_rew = [[None] * 4 for _ in range(T)]
+    m = grp.group_size
+    for g in range(4):                      # each group runs ahead on its own: no lock step between groups
+        for t in range(T):
+            o, r, d, _ = grp.step_group(g, acts[t, g * m:(g + 1) * m])
+            with torch.cuda.stream(grp.streams[g]):
+                got_obs[t][g] = o.clone(); got_rew[t][g] = r.clone()
+    grp.synchronize()
+    grp.check_flags()
+    for t in range(T):
+        assert torch.equal(torch.cat(got_obs[t], 0), ref_obs[t]), t
+        assert torch.equal(torch.cat(got_rew[t], 0), ref_rew[t]), t
+    one.close(); grp.close()
