@@ -29,12 +29,12 @@ from pcc_rl_amd import distributed as pdist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Algorithmic bytes per env-step: 450 B of fixed traffic + 32 B per packet
-# (one 16-B in-flight record written at send, read at completion).  A step is ONE launch
-# (step_kernel: a workgroup sends for its 64 envs, then retires them).  With --split the two
-# halves run as separate launches (send_kernel, retire_kernel) and are timed apart: the send half
-# reads the action (4), link parameters (32), and reads+writes link state (2x16) and sender
-# rate/next_send/cursors (2x26) = 120 B, and writes the 16-B record; the retire half owns the
-# remaining 330 B (state, history, obs/reward/done) and reads the record.
+# (one 16-B in-flight record written at send, read at completion).  A step is two launches,
+# timed apart with HIP events: send_kernel (dominant) reads the action (4), link parameters (32),
+# and reads+writes link state (2x16) and sender rate/next_send/cursors (2x26) = 120 B, and writes
+# the 16-B record; retire_kernel owns the remaining 330 B (state, history, obs/reward/done) and
+# reads the record.  With --fused the step is ONE launch (step_kernel: a workgroup sends for its
+# 64 envs, then retires envs of whichever blocks are done) and carries all 450 + 32 P bytes.
 B_FIXED_SEND, B_FIXED_RETIRE, B_PACKET_HALF = 120, 330, 16
 
 
@@ -42,7 +42,7 @@ def pmc_traffic():
     """HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     separate passes over this same script; see profiles/README.md).  Counters cannot be read from
     inside the process, so the figure is the profile's, labelled with its source."""
-    for name in ("r01_v7_pmc_hbm.json", "r01_v6_pmc_hbm.json"):
+    for name in ("r01_v8_pmc_hbm.json", "r01_v7_pmc_hbm.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -140,9 +140,9 @@ def main():
                     help="also measure the same envs as this many independent groups on their own streams "
                          "(supplementary field async_groups; how well the groups overlap depends on how HIP maps "
                          "the streams to hardware queues)")
-    ap.add_argument("--no-fuse", action="store_true", help="pcc_step as two launches instead of the fused step_kernel")
-    ap.add_argument("--split", action="store_true",
-                    help="run the step as two launches (send_kernel + retire_kernel) and time them apart")
+    ap.add_argument("--fused", action="store_true",
+                    help="run the step as the one-launch step_kernel (send + work-stealing retire) instead of the "
+                         "default two launches (send_kernel, retire_kernel; timed apart)")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (lets the N > 1 path run on a 1-GPU box with gloo)")
     args = ap.parse_args()
@@ -163,10 +163,13 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = 64
     actions = torch.rand((pool, N), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
-    if args.no_fuse or args.share_device:
-        # two processes on one GPU cannot both have their whole grid resident: the one-launch step's
-        # retire queue would wait for workgroups that are not running
-        env.set_tuning(fused_step=0)
+    args.split = not args.fused
+    if args.fused:
+        if args.share_device:
+            # two processes on one GPU cannot both have their whole grid resident: the one-launch
+            # step's retire queue would wait for workgroups that are not running
+            raise SystemExit("--fused cannot be combined with --share-device")
+        env.set_tuning(fused_step=1)
     env.reset()
     returns_gathered = 0
     gather_buf = torch.empty((world * N,), dtype=torch.float32, device=dev) if world > 1 else None
@@ -260,9 +263,12 @@ def main():
                                "algorithmic_bytes_per_env_step": B_FIXED_SEND + B_FIXED_RETIRE + 2 * B_PACKET_HALF * pk_per_step}
         pmc, src = pmc_traffic()
         kname = out["roofline"]["kernel"]
-        if pmc and N == 65536 and kname in pmc:
+        if pmc and N == 65536 and kname in pmc and pmc[kname].get("launches", 0) >= 50:
             out["roofline"]["traffic"] = pmc[kname]["hbm_bytes_per_launch_raw"]
             out["roofline"]["traffic_source"] = src + " (raw FETCH_SIZE+WRITE_SIZE, KB units x 1024)"
+            for other in out["roofline"].get("other_kernels", []):
+                if other["kernel"] in pmc and pmc[other["kernel"]].get("launches", 0) >= 50:
+                    other["traffic"] = pmc[other["kernel"]]["hbm_bytes_per_launch_raw"]
         if world == 1 and args.groups > 1:
             out["async_groups"] = async_groups(N, dev, K, W, args.groups)
         if not args.no_cpu_baseline and world == 1:

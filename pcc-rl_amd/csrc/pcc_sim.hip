@@ -1098,40 +1098,43 @@ template <int K>
 __device__ __forceinline__ void search_many(const Group &g, const double2 *const (&ring)[K], const uint32_t (&mask)[K],
                                             const uint32_t (&lo0)[K], const uint32_t (&hi0)[K], const double (&add)[K],
                                             double end, Bound (&out)[K]) {
-    uint32_t lo[K], hi[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) { lo[k] = lo0[k]; hi[k] = hi0[k]; }
+    static_assert(K == 4 && kGroup == 16, "one search per quad of the 16-lane group");
+    // Narrowing rounds: search q belongs to lanes 4q..4q+3, which sample the ends of 4 equal
+    // sub-ranges -- all four searches in the same instructions, 16 scattered lines per round instead
+    // of 64 (the retire half is bound by the rate of scattered memory operations), at the price of
+    // one or two more rounds than a 16-way split would need.
+    const uint32_t q = g.lane >> 2, j = g.lane & 3u;
+    uint32_t lo_m = q == 0 ? lo0[0] : q == 1 ? lo0[1] : q == 2 ? lo0[2] : lo0[3];
+    uint32_t hi_m = q == 0 ? hi0[0] : q == 1 ? hi0[1] : q == 2 ? hi0[2] : hi0[3];
+    const double2 *ring_m = q == 0 ? ring[0] : q == 1 ? ring[1] : q == 2 ? ring[2] : ring[3];
+    const uint32_t mask_m = q == 0 ? mask[0] : q == 1 ? mask[1] : q == 2 ? mask[2] : mask[3];
+    const double add_m = q == 0 ? add[0] : q == 1 ? add[1] : q == 2 ? add[2] : add[3];
     for (;;) {
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < K; k++) any |= (hi[k] - lo[k] > 12u);
-        if (!any) break;
-        double tsamp[K];
-        uint32_t sidx[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const uint32_t stride = (hi[k] - lo[k] + kGroup - 1) / kGroup;
-            uint32_t x = lo[k] + (g.lane + 1) * stride;
-            if (x > hi[k]) x = hi[k];
-            sidx[k] = x - 1;
-            tsamp[k] = 0.0;
-            if (hi[k] - lo[k] > 12u) tsamp[k] = ld_t1(ring[k] + (sidx[k] & mask[k]));
-        }
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            if (hi[k] - lo[k] > 12u) {
-                const uint32_t mfail = ~gballot(g, tsamp[k] + add[k] < end) & 0xFFFFu;
-                if (!mfail) {
-                    lo[k] = hi[k];  // the last sample is record hi-1: everything passes
-                } else {
-                    const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
-                    const uint32_t s_f = gbcast(sidx[k], f);
-                    if (f) lo[k] = gbcast(sidx[k], f - 1) + 1;
-                    hi[k] = s_f < lo[k] ? lo[k] : s_f;
-                }
+        const bool active = hi_m - lo_m > 12u;
+        if (!gballot(g, active)) break;
+        const uint32_t stride = (hi_m - lo_m + 3u) / 4u;
+        uint32_t x = lo_m + (j + 1u) * stride;
+        if (x > hi_m) x = hi_m;
+        const uint32_t sidx = x - 1u;
+        double tsamp = 0.0;
+        if (active) tsamp = ld_t1(ring_m + (sidx & mask_m));
+        const uint32_t mfail = ~(gballot(g, tsamp + add_m < end) >> (4u * q)) & 0xFu;
+        // samples of my quad's failing probe f and of the probe before it (every lane shuffles)
+        const uint32_t f = mfail ? (uint32_t)__ffs((int)mfail) - 1u : 0u;
+        const uint32_t s_f = gbcast(sidx, 4u * q + f);
+        const uint32_t s_p = gbcast(sidx, 4u * q + (f ? f - 1u : 0u));
+        if (active) {
+            if (!mfail) {
+                lo_m = hi_m;  // the last sample is record hi-1: everything passes
+            } else {
+                if (f) lo_m = s_p + 1u;
+                hi_m = s_f < lo_m ? lo_m : s_f;
             }
         }
     }
+    uint32_t lo[K], hi[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { lo[k] = gbcast(lo_m, 4u * k); hi[k] = gbcast(hi_m, 4u * k); }
     // final step: lane l looks at record base + l, base = lo - 2 (clamped to the ring's start)
     double2 r[K];
     uint32_t base[K];
@@ -2226,7 +2229,9 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.help_lanes = 16;
     d.send_envs_per_wave = 64;
     d.heavy_predict = 4096.0;
-    sim->fused_step = !(getenv("PCC_FUSED_STEP") && atoi(getenv("PCC_FUSED_STEP")) == 0);
+    // two launches measure a little faster and steadier than the one-launch step since the retire
+    // half runs at 5 waves/SIMD on its own (0.56 vs 0.58 ms at 65 536 envs): opt-in
+    sim->fused_step = getenv("PCC_FUSED_STEP") && atoi(getenv("PCC_FUSED_STEP")) != 0;
     sim->steal_tag = 1;  // the zero-initialised ready list must not look published
     sim->fused_capacity_key = -1;
     d.debug_skip = getenv("PCC_DEBUG_SKIP") ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;

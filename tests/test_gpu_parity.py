@@ -158,11 +158,14 @@ def test_auto_reset_and_second_episode_match_oracle():
     env.close()
 
 
-def test_conservation_and_queue_bounds_at_full_size():
+@pytest.mark.parametrize("fused", [0, 1])
+def test_conservation_and_queue_bounds_at_full_size(fused):
     """Size-independent properties at BASELINE's 65 536 envs: every packet sent is acked, lost
-    or still in flight; the queue never exceeds its limit; clocks only move forward."""
+    or still in flight; the queue never exceeds its limit; clocks only move forward.  Both as two
+    launches (the default) and as the one-launch step, which at this size fills the device."""
     N = 65536
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=DEV, seed=0, record_steps=True, auto_reset=False)
+    env.set_tuning(fused_step=fused)
     env.reset()
     gen = torch.Generator(device=DEV).manual_seed(0)
     sent0 = (env.state("acc_tail") + env.state("drop_tail"))[0].clone().long()

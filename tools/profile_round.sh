@@ -11,6 +11,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o 
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $O/pmc_write.log 2>&1
 python $R/tools/pmc_aggregate.py $O/pmc_hbm.json $O/pmc_fetch $O/pmc_write > /dev/null
-timeout 200 python $R/bench.py --no-cpu-baseline --split > $O/bench_split.log 2>&1
+timeout 200 python $R/bench.py --no-cpu-baseline --fused > $O/bench_fused.log 2>&1
 find $O -name "*kernel_stats.csv" | head -3
 tail -c 1500 $O/bench.log

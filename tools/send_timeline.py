@@ -19,6 +19,7 @@ import pcc_rl_amd
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 dev = torch.device("cuda:0")
 env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
+env.set_tuning(fused_step=1 if os.environ.get("PCC_TL_FUSED", "1") != "0" else 0)
 for k, v in os.environ.items():
     if k.startswith("PCC_TUNE_"):
         env.set_tuning(**{k[9:].lower(): float(v)})
