@@ -161,7 +161,7 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
 enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_SEND_ENVS_PER_WAVE = 4 /* envs per 64-lane wavefront in the send kernel, 1..64 */,
        PCC_TUNE_HEAVY_PREDICT = 5 /* predicted packets per interval above which an env is sent by the
-                                    block's second ("heavy") wavefront from the start; default 4096 */,
+                                    block's heavy wavefronts from the start; default 3072 */,
        PCC_TUNE_FUSED_STEP = 6 /* 0 (default): pcc_step = pcc_step_send + pcc_step_retire, two launches.
                                   1: pcc_step is ONE launch (step_kernel) -- every workgroup sends for its
                                   64 envs, then retires envs of whichever blocks are done sending (its own
@@ -175,7 +175,10 @@ enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKET
        PCC_TUNE_HELP_LANES = 7 /* when at most this many lanes (default 16, 0..64) of a wavefront still
                                   have packets to send, the idle lanes compute their Philox blocks:
                                   the loss decisions of a lane's next 256 packets come from one block
-                                  per idle lane instead of 64 blocks of its own */ };
+                                  per idle lane instead of 64 blocks of its own */,
+       PCC_TUNE_SEND_WAVES = 8 /* wavefronts per block of envs in send_kernel (2..8): one light wavefront
+                                  plus heavy ones that share the block's envs predicted heavy (idle ones
+                                  exit at once) */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* Load balancing of the send kernel: order is a device array [N] holding a permutation of the env

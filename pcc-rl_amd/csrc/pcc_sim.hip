@@ -112,7 +112,7 @@ struct Dev {
     uint64_t *timeline;  // profiling only (PCC_DEBUG_TIMELINE env): 8 words per send wavefront, see pcc_debug_timeline
     int debug_skip;  // profiling only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs
     double heavy_packets, heavy_rho;  // tuning: when the send kernel hands an env to the wave path
-    uint32_t round_packets, takeover_lanes, send_envs_per_wave, help_lanes;
+    uint32_t round_packets, takeover_lanes, send_envs_per_wave, help_lanes, send_waves;
     double heavy_predict;  // predicted packets per MI above which an env goes to the heavy wave
     double lo[5], hi[5];
     int rng_mode;
@@ -1036,10 +1036,12 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
     if (flags) D.flags[i] |= flags;
 }
 
+constexpr uint32_t kMaxSendWaves = 8;  // per block of envs: one light wavefront + heavy ones (they exit at once when idle)
+
 template <int NS, bool TRACE>
-__global__ __launch_bounds__(2 * kWave) void send_kernel(Dev D, uint32_t block0, int warm, uint32_t warm_mi,
-                                                         const void *actions, int actions_f64) {
-    send_wave<NS, TRACE>(D, block0 + blockIdx.x, threadIdx.x, 1u, warm, warm_mi, actions, actions_f64);
+__global__ __launch_bounds__(kMaxSendWaves * kWave) void send_kernel(Dev D, uint32_t block0, int warm, uint32_t warm_mi,
+                                                                     const void *actions, int actions_f64) {
+    send_wave<NS, TRACE>(D, block0 + blockIdx.x, threadIdx.x, blockDim.x / kWave - 1u, warm, warm_mi, actions, actions_f64);
 }
 
 // ======================================================================================
@@ -2075,7 +2077,7 @@ int launch_send_blocks(pcc_sim_t *sim, uint32_t block0, uint32_t n_blocks, int w
                        const void *actions, int actions_f64, hipStream_t st) {
     const Dev &d = sim->d;
     const bool tr = d.rng_mode == PCC_RNG_TRACE;
-    const dim3 sgrid(n_blocks), sblock(2 * kWave);
+    const dim3 sgrid(n_blocks), sblock(d.send_waves * kWave);
     if (d.ns == 1) {
         if (tr) hipLaunchKernelGGL((send_kernel<1, true>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
         else hipLaunchKernelGGL((send_kernel<1, false>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
@@ -2227,8 +2229,9 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.round_packets = 256;
     d.takeover_lanes = 2;
     d.help_lanes = 16;
+    d.send_waves = 4;
     d.send_envs_per_wave = 64;
-    d.heavy_predict = 4096.0;
+    d.heavy_predict = 3072.0;
     // two launches measure a little faster and steadier than the one-launch step since the retire
     // half runs at 5 waves/SIMD on its own (0.56 vs 0.58 ms at 65 536 envs): opt-in
     sim->fused_step = getenv("PCC_FUSED_STEP") && atoi(getenv("PCC_FUSED_STEP")) != 0;
@@ -2405,6 +2408,10 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             return PCC_OK;
         case PCC_TUNE_HEAVY_PREDICT: sim->d.heavy_predict = value; return PCC_OK;
         case PCC_TUNE_FUSED_STEP: sim->fused_step = value != 0.0; sim->fused_always = value == 2.0; return PCC_OK;
+        case PCC_TUNE_SEND_WAVES:
+            if (!(value >= 2.0 && value <= (double)kMaxSendWaves)) return fail(PCC_EINVAL, "send_waves out of range");
+            sim->d.send_waves = (uint32_t)value;
+            return PCC_OK;
         case PCC_TUNE_HELP_LANES:
             if (!(value >= 0.0 && value <= 64.0)) return fail(PCC_EINVAL, "help_lanes out of range");
             sim->d.help_lanes = (uint32_t)value;

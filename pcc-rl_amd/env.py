@@ -170,12 +170,14 @@ class BatchedNetworkEnv(object):
         self._trace = t
 
     def set_tuning(self, heavy_packets=None, heavy_rho=None, round_packets=None, takeover_lanes=None,
-                   send_envs_per_wave=None, heavy_predict=None, fused_step=None, help_lanes=None):
+                   send_envs_per_wave=None, heavy_predict=None, fused_step=None, help_lanes=None, send_waves=None):
         """Performance knobs of the step kernels (results do not depend on them)."""
         if fused_step is not None:
             check(self._L.pcc_set_tuning(self._h, 6, float(fused_step)))
         if help_lanes is not None:
             check(self._L.pcc_set_tuning(self._h, 7, float(help_lanes)))
+        if send_waves is not None:
+            check(self._L.pcc_set_tuning(self._h, 8, float(send_waves)))
         if heavy_predict is not None:
             check(self._L.pcc_set_tuning(self._h, 5, float(heavy_predict)))
         if send_envs_per_wave is not None:

@@ -228,6 +228,8 @@ def test_old_gym_adapter_drop_in():
     dict(help_lanes=64, takeover_lanes=0, heavy_predict=1e18),   # every round after the first with helper-drawn loss bits
     dict(help_lanes=0),                                          # never
     dict(fused_step=0),                                          # pcc_step as two launches
+    dict(send_waves=2, heavy_predict=64.0),                      # one heavy wavefront takes every flagged env
+    dict(send_waves=8, heavy_predict=64.0),                      # seven of them share the flagged envs
     dict(fused_step=2),                                          # one launch: send + work-stealing retire
     dict(fused_step=2, heavy_predict=64.0, takeover_lanes=1),    # ... with all three heavy wavefronts busy
 ])
