@@ -154,7 +154,7 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
 
 /* Performance knobs of the send kernel; results never depend on them (every send path is exact).
  * Each lane sends its env's packets in rounds of ROUND_PACKETS (default 256); when at most
- * TAKEOVER_LANES (default 2) lanes of a wavefront still have packets left after a round, those
+ * TAKEOVER_LANES (default 1) lanes of a wavefront still have packets left after a round, those
  * envs are finished by the whole wavefront, 64 packets per pass.  An env predicted to send more
  * than HEAVY_PACKETS packets with bw/rate below HEAVY_RHO skips the lane rounds entirely
  * (default: off, HEAVY_PACKETS = 1e18). */
