@@ -42,7 +42,7 @@ def pmc_traffic():
     """HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     separate passes over this same script; see profiles/README.md).  Counters cannot be read from
     inside the process, so the figure is the profile's, labelled with its source."""
-    for name in ("r01_v8_pmc_hbm.json", "r01_v7_pmc_hbm.json"):
+    for name in ("r01_v9_pmc_hbm.json", "r01_v8_pmc_hbm.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
