@@ -10,7 +10,7 @@ gen = torch.Generator(device=dev).manual_seed(1234)
 acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
 env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
 def run(**knobs):
-    base = dict(takeover_lanes=2, help_lanes=16, heavy_predict=3072.0, round_packets=256, send_waves=4)
+    base = dict(takeover_lanes=1, help_lanes=16, heavy_predict=3072.0, round_packets=256, send_waves=4)
     base.update(knobs)
     env.set_tuning(**base)
     env.reset()
@@ -22,7 +22,7 @@ def run(**knobs):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / K * 1e3
 res = []
-for knobs in [dict(takeover_lanes=t, heavy_predict=float(h), round_packets=r) for t in (0, 1) for h in (2816, 3072) for r in (256, 512)] + [dict(takeover_lanes=1, help_lanes=32), dict(takeover_lanes=1, heavy_predict=2560.0)]:
+for knobs in [dict(send_waves=w, heavy_predict=float(h)) for w in (4, 6, 8) for h in (2048, 2560, 3072)] + [dict(send_waves=3), dict(send_waves=5, heavy_predict=2560.0)]:
     ms = run(**knobs)
     res.append((knobs, ms))
     print(knobs, "%.4f ms/step" % ms, flush=True)
