@@ -606,11 +606,11 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                                           const uint32_t n_heavy_waves, int warm, uint32_t warm_mi, const void *actions,
                                           int actions_f64) {
     const uint32_t lane = tid & (kWave - 1);
-    // Two wavefronts per block of envs.  Wave 0 ("light") runs the lane-per-env rounds for the envs
-    // NOT flagged heavy; wave 1 ("heavy") sends the flagged envs one after the other with all 64
-    // lanes (heavy_mi).  The flag is the previous retire's prediction for this MI -- a performance
-    // hint only, every path is exact -- and the two waves touch disjoint envs, so nothing is shared.
-    // Lanes without an env stay in the kernel: the wave path needs all 64 lanes as workers.
+    // 1 + n_heavy_waves wavefronts per block of envs.  Wave 0 ("light") runs the lane-per-env rounds
+    // for the envs NOT flagged heavy; waves 1.. ("heavy") share the flagged envs round-robin and send
+    // each with all 64 lanes (heavy_mi).  The flag is the previous retire's prediction for this MI --
+    // a performance hint only, every path is exact -- and the waves touch disjoint envs, so nothing
+    // is shared.  Lanes without an env stay in the kernel: the wave path needs all 64 lanes as workers.
     const bool heavy_wave = tid >= kWave;
     const int64_t slot = (int64_t)block * D.send_envs_per_wave + lane;
     const bool in_range = lane < D.send_envs_per_wave && slot < D.n;
@@ -618,7 +618,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
     // over the wavefronts) only changes who waits for whom, never a result
     const int64_t i = (in_range && D.send_order) ? (int64_t)D.send_order[slot] : slot;
     const bool flagged = in_range && D.heavy_flag[in_range ? i : 0] != 0;
-    // several heavy wavefronts (the fused step has three) deal the flagged envs of the block round-robin
+    // the heavy wavefronts (three by default, send_waves - 1) deal the flagged envs of the block round-robin
     const uint32_t flag_rank = (uint32_t)__popcll(__ballot(flagged) & ((1ull << lane) - 1ull));
     const bool mine = heavy_wave ? (flagged && flag_rank % n_heavy_waves == tid / kWave - 1u) : !flagged;
     const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]) && mine;
@@ -764,9 +764,11 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
         bool heavy_now = heavy;
         bool active = run && !heavy;
         uint32_t blk = 0;  // Philox block = packets sent in this MI / 4
-        // Lane-serial rounds of at most kRound packets per env.  After a round, if only one or two
-        // lanes of the wave still have packets to send, they are the tail everybody else would wait
-        // for: hand them to the wave path, which sends one env's packets 2-5x faster than one lane.
+        // Lane-serial rounds of round_packets packets per env.  After a round, if at most
+        // takeover_lanes (default: one) lanes of the wave still have packets to send, they are the
+        // tail everybody else would wait for: they go to the wave path, which sends ONE env's packets
+        // faster than a lone lane does; with a few lanes left, the idle lanes draw for them instead
+        // (helped rounds).
         bool helped = false;
         uint64_t loss_bits[4] = {0, 0, 0, 0};  // helped round: bit j of [k] = loss decision of packet 4j + k of the round
         for (;;) {
