@@ -31,7 +31,7 @@ class PyOracleEnv(object):
     """Single env, 1 or 2 senders, reference life cycle: construct, reset(), step(a)..."""
 
     def __init__(self, seed=0, history_len=10, features=("sent latency inflation", "latency ratio", "send ratio"),
-                 n_senders=1, delta_scale=0.025, fixed=None, ctor_draws=5):
+                 n_senders=1, delta_scale=0.025, fixed=None, ctor_draws=5, use_cwnd=False):
         self.rng = random.Random(seed)
         for _ in range(ctor_draws):           # the constructor's discarded parameter draws (ns:366)
             self.rng.random()
@@ -39,6 +39,7 @@ class PyOracleEnv(object):
         self.H, self.S, self.delta_scale, self.fixed = history_len, n_senders, delta_scale, fixed
         self.run_dur = None
         self.draws = ctor_draws
+        self.use_cwnd = use_cwnd          # ns:54: window-limited sending, [rate action, cwnd action] per step
 
     # ---- parameters and reset: ns:454-484
     def _new_params(self):
@@ -58,6 +59,8 @@ class PyOracleEnv(object):
         self.q, self.tq = 0.0, 0.0
         self.rate = rates
         self.rate0 = list(rates)
+        self.cwnd = [25] * self.S           # ns:209, 227
+        self.in_flight = [0] * self.S       # bytes_in_flight / BYTES_PER_PACKET (ns:215)
 
     def reset(self):
         self._new_params()
@@ -99,11 +102,17 @@ class PyOracleEnv(object):
                     else:
                         self.acked[s] += 1
                         self.rtts[s].append(lat)
+                    self.in_flight[s] -= 1    # ns:269, 273
                 else:   # return link: never queued on, so its latency is dl + max(0, 0 - t) (ns:66-70)
                     ll = dl + max(0.0, 0.0 - (t - 0.0))
                     push(heap, (t + ll, s, ACK, hop + 1, lat + ll, dropped))
             else:
-                self.sent[s] += 1
+                # ns:158-160, 251-255: a SEND the window blocks launches no packet, but the link lines
+                # below (ns:170-175) still run for it: queue update and loss draw
+                launched = (not self.use_cwnd) or self.in_flight[s] < self.cwnd[s]
+                if launched:
+                    self.sent[s] += 1
+                    self.in_flight[s] += 1
                 push(heap, (t + (1.0 / self.rate[s]), s, SEND, 0, 0.0, False))
                 qd = max(0.0, self.q - (t - self.tq))
                 ll = dl + qd
@@ -118,7 +127,8 @@ class PyOracleEnv(object):
                     else:
                         self.q += extra
                         ok = True
-                push(heap, (t + ll, s, ACK, 1, 0.0 + ll, not ok))
+                if launched:
+                    push(heap, (t + ll, s, ACK, 1, 0.0 + ll, not ok))
 
     # ---- the 12 metrics of sender s for the MI just run: so:110-191
     def _metrics(self, s, update_min):
@@ -157,6 +167,13 @@ class PyOracleEnv(object):
     def step(self, action):
         if self.run_dur is None:
             raise TypeError("step() before reset()")
+        if self.use_cwnd:                  # ns:412-414 (one sender): action = [rate action, cwnd action]
+            a = np.asarray(action, dtype=np.float64).reshape(self.S, 2)
+            for s in range(self.S):
+                d = float(a[s, 1]) * self.delta_scale   # ns:243-249, 283-289
+                c = int(self.cwnd[s] * (1.0 + d)) if d >= 0.0 else int(self.cwnd[s] / (1.0 - d))
+                self.cwnd[s] = min(max(c, 4), 5000)
+            action = a[:, 0]
         acts = [float(action)] if np.ndim(action) == 0 else [float(a) for a in action]
         for s in range(self.S):
             d = acts[s] * self.delta_scale

@@ -57,3 +57,14 @@ def test_two_senders():
             for s in range(2):
                 assert np.array_equal(np.array(env.last_rows[s], dtype=np.float64), d["steps"][i, s, t]), (i, s, t)
                 assert np.array_equal(obs[s][-3:], d["obs_tail"][i, s, t])
+
+
+def test_use_cwnd_option():
+    d = load("cwnd_pm1")
+    for i in (0, 3):
+        env = PyOracleEnv(seed=int(d["seed"][i]), use_cwnd=True)
+        check(env, d, i)
+    d = load("cwnd_grow")
+    env = PyOracleEnv(seed=int(d["seed"][0]), use_cwnd=True)
+    check(env, d, 0)
+    assert env.cwnd[0] == int(d["cwnd"][0, -1])
