@@ -338,6 +338,11 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                                          SendState &st) {
     const uint32_t mask_b = (cap - 1u) << 4, dmask_b = (2u * cap - 1u) << 4, cap_b = cap << 4;
     const uint64_t lt = (1ull << lane) - 1ull;
+    // loss decisions of 256 packets at a time: every lane draws one Philox block (4 packets), four
+    // ballots keep the bits -- bit b of lb[k] is packet lb_base + 4 b + k -- and four passes use them
+    uint64_t lb[4] = {0, 0, 0, 0};
+    uint32_t lb_base = 0;
+    bool lb_valid = false;
     while (st.t < end) {
         const double t0 = st.t;
         // ---- loss decisions of the next 64 packets, one per lane
@@ -348,11 +353,18 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
             if ((int64_t)pos < D.trace_stride) u = trace[pos];
             rnd = u < lr;
         } else {
-            const uint32_t j = st.sent + lane;
-            uint32_t w[4];
-            philox4x32_10(j >> 2, mi, episode, gid, D.key0, D.key1, w);
-            const uint32_t x = (j & 3u) == 0 ? w[0] : (j & 3u) == 1 ? w[1] : (j & 3u) == 2 ? w[2] : w[3];
-            rnd = always || x < thr;
+            const uint32_t j0 = st.sent;  // wave-uniform
+            if (!lb_valid || j0 < lb_base || j0 + kWave > lb_base + 4u * kWave) {
+                lb_base = j0 & ~3u;
+                uint32_t w[4];
+                philox4x32_10((lb_base >> 2) + lane, mi, episode, gid, D.key0, D.key1, w);
+#pragma unroll
+                for (int k = 0; k < 4; k++) lb[k] = __ballot(always || w[k] < thr);
+                lb_valid = true;
+            }
+            const uint32_t p = j0 + lane - lb_base;  // this lane's packet inside the cached window
+            const uint64_t m = (p & 3u) == 0 ? lb[0] : (p & 3u) == 1 ? lb[1] : (p & 3u) == 2 ? lb[2] : lb[3];
+            rnd = (m >> (p >> 2)) & 1ull;
         }
         const uint64_t rmask = __ballot(rnd);
 
