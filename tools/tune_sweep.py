@@ -22,7 +22,7 @@ def run(**knobs):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / K * 1e3
 res = []
-for knobs in [dict(send_waves=w, heavy_predict=float(h)) for w in (4, 6, 8) for h in (2048, 2560, 3072)] + [dict(send_waves=3), dict(send_waves=5, heavy_predict=2560.0)]:
+for knobs in [dict(), dict(send_envs_per_wave=48), dict(send_envs_per_wave=32), dict(send_envs_per_wave=32, heavy_predict=4096.0), dict(send_envs_per_wave=32, send_waves=2, heavy_predict=4096.0), dict(send_envs_per_wave=64, help_lanes=24)]:
     ms = run(**knobs)
     res.append((knobs, ms))
     print(knobs, "%.4f ms/step" % ms, flush=True)
