@@ -140,9 +140,6 @@ def main():
                     help="also measure the same envs as this many independent groups on their own streams "
                          "(supplementary field async_groups; how well the groups overlap depends on how HIP maps "
                          "the streams to hardware queues)")
-    ap.add_argument("--fused", action="store_true",
-                    help="run the step as the one-launch step_kernel (send + work-stealing retire) instead of the "
-                         "default two launches (send_kernel, retire_kernel; timed apart)")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (lets the N > 1 path run on a 1-GPU box with gloo)")
     args = ap.parse_args()
@@ -163,13 +160,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = 64
     actions = torch.rand((pool, N), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
-    args.split = not args.fused
-    if args.fused:
-        if args.share_device:
-            # two processes on one GPU cannot both have their whole grid resident: the one-launch
-            # step's retire queue would wait for workgroups that are not running
-            raise SystemExit("--fused cannot be combined with --share-device")
-        env.set_tuning(fused_step=1)
+    args.split = True
     env.reset()
     returns_gathered = 0
     gather_buf = torch.empty((world * N,), dtype=torch.float32, device=dev) if world > 1 else None

@@ -95,7 +95,7 @@ enum {
 #define PCC_FLAG_TRACE_OVERRUN 2u  /* PCC_RNG_TRACE ran past trace_stride */
 #define PCC_FLAG_POOL_EXHAUSTED 8u /* a sender needed a bigger ring tier and every pool from that tier up was empty (it may
                                       then also overflow: RING_OVERFLOW); raise the pools with PCC_RING_POOLS */
-#define PCC_FLAG_INTERNAL 4u       /* (env 0 only) the fused step's retire queue timed out: results invalid, a bug */
+#define PCC_FLAG_INTERNAL 4u       /* reserved (a queue protocol of an earlier build; never set) */
 
 /* last error text of the calling thread ("" if none) */
 const char *pcc_last_error(void);
@@ -119,9 +119,10 @@ const char *pcc_last_error(void);
  *                   pools that by default hold 1/2, 1/8, 1/32 of the senders at once
  *                   (environment variable PCC_RING_POOLS="2,8,32" sets the divisors; 1 =
  *                   worst case).  An empty pool is flagged (PCC_FLAG_POOL_EXHAUSTED), never
- *                   silent.  Pool rings are held until the env is reset.  The point of the
- *                   tiers is address-space locality (TLB reach), not only memory: 65 536 envs
- *                   take 6.4 GB instead of 103 GB.  pcc_device_bytes reports the total.
+ *                   silent.  Pool rings are held until the env is reset.  The tiers are about
+ *                   memory, not speed (a pointer-chase microbenchmark shows TLB reach is not what
+ *                   bounds these kernels): 65 536 envs take 6.4 GB instead of 103 GB.
+ *                   pcc_device_bytes reports the total.
  *   device_id       HIP device ordinal (-1 = current device).
  * No env is usable before pcc_reset.
  */
@@ -152,41 +153,20 @@ int pcc_set_rng(pcc_sim_t *sim, int mode, const double *trace, int64_t trace_str
  * seed(), ns:396-398, creates an RNG nothing reads; here it does what a caller expects.) */
 int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
 
-/* Performance knobs of the send kernel; results never depend on them (every send path is exact).
- * Each lane sends its env's packets in rounds of ROUND_PACKETS (default 256); when at most
- * TAKEOVER_LANES (default 1) lanes of a wavefront still have packets left after a round, those
- * envs are finished by the whole wavefront, 64 packets per pass.  An env predicted to send more
- * than HEAVY_PACKETS packets with bw/rate below HEAVY_RHO skips the lane rounds entirely
- * (default: off, HEAVY_PACKETS = 1e18). */
-enum { PCC_TUNE_HEAVY_PACKETS = 0, PCC_TUNE_HEAVY_RHO = 1, PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
-       PCC_TUNE_SEND_ENVS_PER_WAVE = 4 /* envs per 64-lane wavefront in the send kernel, 1..64 */,
-       PCC_TUNE_HEAVY_PREDICT = 5 /* predicted packets per interval above which an env is sent by the
-                                    block's heavy wavefronts from the start; default 3072 */,
-       PCC_TUNE_FUSED_STEP = 6 /* 0 (default): pcc_step = pcc_step_send + pcc_step_retire, two launches.
-                                  1: pcc_step is ONE launch (step_kernel) -- every workgroup sends for its
-                                  64 envs, then retires envs of whichever blocks are done sending (its own
-                                  first), so the retire work fills the SIMDs idle during the send tail --
-                                  whenever the whole grid is resident at once (65 536 envs are) and fills
-                                  at least half of the device; 2: also for small grids.  The one-launch
-                                  step needs the device to itself: it is not used while the process holds
-                                  more than one handle on the device, and two PROCESSES sharing a GPU must
-                                  not use it.  Measured at 65 536 envs: 0.58 ms against 0.56 ms for the two
-                                  launches (whose retire half runs at higher occupancy on its own) */,
-       PCC_TUNE_HELP_LANES = 7 /* when at most this many lanes (default 16, 0..64) of a wavefront still
-                                  have packets to send, the idle lanes compute their Philox blocks:
-                                  the loss decisions of a lane's next 256 packets come from one block
-                                  per idle lane instead of 64 blocks of its own */,
-       PCC_TUNE_SEND_WAVES = 8 /* wavefronts per block of envs in send_kernel (2..8): one light wavefront
-                                  plus heavy ones that share the block's envs predicted heavy (idle ones
-                                  exit at once) */ };
+/* Performance knobs of the send half; results never depend on them (every send path is exact).
+ * The retire half files every env by its predicted packet count for the next interval; the send
+ * half's persistent wavefronts take work items off those lists, heaviest first.  An env predicted
+ * above HEAVY_PREDICT packets is an item of its own, sent by all 64 lanes of a wavefront 256 packets
+ * per pass; lighter envs go SEND_ENVS_PER_WAVE (64) of about the same length at a time to one
+ * wavefront, a lane each, in rounds of ROUND_PACKETS (default 256); when at most TAKEOVER_LANES
+ * (default 1) lanes still have packets left after a round, those envs are finished by the whole
+ * wavefront.  (Keys 0, 1, 6, 7 belonged to mechanisms of earlier builds and are rejected.) */
+enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
+       PCC_TUNE_SEND_ENVS_PER_WAVE = 4 /* envs per light work item, 1..64 */,
+       PCC_TUNE_HEAVY_PREDICT = 5 /* predicted packets per interval above which an env is a work item of
+                                    its own (wave path); default 1024, 0 = every env, >= 1e9 = none */,
+       PCC_TUNE_SEND_WAVES = 8 /* persistent send wavefronts per compute unit, 1..32 (default 16) */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
-
-/* Load balancing of the send kernel: order is a device array [N] holding a permutation of the env
- * ids (slot -> env); lane `slot % 64` of wavefront `slot / 64` sends for env order[slot].  NULL =
- * identity.  Read at every following pcc_step / pcc_reset, so it must stay valid; results never
- * depend on it.  A good order deals the envs with the most predicted packets (run_dur * rate)
- * round-robin over the wavefronts (BatchedNetworkEnv(balance_every=...) does that). */
-int pcc_set_send_order(pcc_sim_t *sim, const uint32_t *order);
 
 /* The reference's dormant engine option USE_CWND (ns:54; off in the reference): window-limited
  * sending.  A SEND event launches a packet only while fewer than cwnd packets are unacknowledged
@@ -196,8 +176,8 @@ int pcc_set_send_order(pcc_sim_t *sim, const uint32_t *order);
  * of pcc_step / pcc_step_send are [N][2] = (rate action, cwnd action) (ns:376-377, 412-414): the
  * second moves the window like the first moves the rate (x (1 + a*delta_scale) or / (1 - a*
  * delta_scale)), truncated to an integer and clamped to [4, 5000] (ns:33-34, 283-289).  One sender
- * per env only; pcc_reset must follow.  This path is lane-serial (no wave path, no fused step
- * speed-ups apply); it is exact like the others. */
+ * per env only; pcc_reset must follow.  This path is lane-serial (no wave path); it is exact like
+ * the others. */
 int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable);
 
 /* DELTA_SCALE (src/common/config.py:17, default 0.025) and MAX_STEPS (ns:41, default 400) */
@@ -252,15 +232,23 @@ int pcc_metric_info(int id, double *min_val, double *max_val, double *scale);
 int64_t pcc_device_bytes(const pcc_sim_t *sim);
 
 /* Profiling aid, no reference counterpart.  When the handle was created with the environment
- * variable PCC_DEBUG_TIMELINE=1, every send wavefront of the LAST step leaves 8 words: start, end
+ * variable PCC_DEBUG_TIMELINE=1, every work item of the LAST send launch leaves 8 words: start, end
  * of its lane rounds, end (100 MHz device ticks), envs it sent with the wave path, packets it
- * sent, packets of its largest env, packets sent by the wave path, live lanes.  Wavefront w of
- * env block b (send_envs_per_wave envs) is at word (2*b + w) * 8; w = 1 is the block's heavy
- * wavefront.  After those 2 * blocks entries come `blocks` workgroup entries of the fused step:
- * block published, workgroup exit, retire items it processed.  Synchronizes the device.  Returns
- * the number of words (3 * blocks * 8) -- copied, or needed when out is NULL; 0 when the timeline is
- * off, < 0 on error. */
+ * sent, packets of its largest env, packets sent by the wave path, live lanes -- item t at word
+ * 8 t, items in the order they were handed out (heaviest first).  After the items come 16 words per
+ * retire workgroup (time by phase, summed over its wavefronts).  Synchronizes the device.  Returns
+ * the number of words -- copied, or needed when out is NULL; 0 when the timeline is off, < 0 on
+ * error. */
 int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words);
+
+/* Profiling only (handles created with PCC_DEBUG_TIMELINE=1): counters of the send half's wave passes
+ * since creation or the last reset of the counters -- out16[0..3] passes by regime (A "always empty",
+ * B with the token scan, B without it, serial), [4..7] packets they carried, [8] B passes that could
+ * not commit a packet, [9] passes refused for the send-time preconditions, [10] for the queue
+ * preconditions, [11] envs sent as heavy items, [12] envs taken over from lane rounds, [13] / [14]
+ * shader cycles spent in committed / serial passes, [15] work items of the last send launch.
+ * Synchronizes the device.  No reference counterpart. */
+int pcc_debug_pass_stats(pcc_sim_t *sim, uint64_t *out16, int reset);
 
 #ifdef __cplusplus
 }

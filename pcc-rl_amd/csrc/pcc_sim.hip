@@ -31,17 +31,15 @@
 // is promoted into (by its whole wavefront, at the start of an MI that could overflow them).
 //
 // Kernels per step:
-//   step_kernel    (pcc_step when the grid fills the device) one launch: a workgroup sends for
-//                  its 64 envs -- send_wave: a light wavefront with one lane per env, up to three
-//                  heavy wavefronts that send one env at a time with all 64 lanes -- publishes
-//                  the block, and its wavefronts then retire envs of whichever blocks are
-//                  published (retire_env, work stealing off a global queue).
-//   send_kernel    send_wave alone: apply the action, run the SEND recurrence up to the MI end,
-//                  append records (no loads in the loop).
-//   retire_kernel  retire_env alone, 16 lanes per env: 16-ary searches of the rings for the
-//                  hop-2 / hop-1 boundaries (all four advanced together), the MI-ending event,
-//                  RTT sums as numpy's pairwise tree with each 128-sample leaf summed in one
-//                  round trip by an 8-lane subgroup, metrics, history, observation, reward, done.
+//   send_kernel    persistent wavefronts take work items off the class lists the previous retire filed,
+//                  heaviest first (send_item): a light item is 64 envs of about the same predicted
+//                  packet count sent lane-per-env in rounds (no loads in the loop); a heavy item is one
+//                  env sent by all 64 lanes, 256 packets per pass, from closed forms (heavy_mi).
+//   retire_kernel  retire_env, 16 lanes per env: searches of the rings for the hop-2 / hop-1
+//                  boundaries (all four advanced together), the MI-ending event, RTT sums as numpy's
+//                  pairwise tree with each 128-sample leaf summed in one round trip by an 8-lane
+//                  subgroup, metrics, history, observation, reward, done; then files every env by
+//                  its predicted packet count for the next send.
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
@@ -108,23 +106,25 @@ struct Dev {
     uint32_t key0, key1, gid_base;
     double delta_scale;
     uint32_t max_steps;
-    uint32_t *steal;     // step_kernel's retire queue: [0] blocks done sending, [1] next item, [2..] ready list
+    uint32_t *cls_count;  // [2][kClsStride] work lists of the send half (two buffers): envs per class, item cursor
+    uint32_t *cls_list;   // [2][kClasses][N] env ids by class
+    uint32_t *cursors;    // [3][kShards][kCursorStride] item cursors of the two list buffers (third block unused)
     uint64_t *timeline;  // profiling only (PCC_DEBUG_TIMELINE env): 8 words per send wavefront, see pcc_debug_timeline
+    unsigned long long *pass_stats;  // profiling only (same switch): counters of the wave passes, see pcc_debug_pass_stats
+    int pass_counters;               // ... per-pass counters on (PCC_DEBUG_TIMELINE=2: contended atomics, they slow the passes down)
+    uint32_t send_wg_waves;  // tuning: wavefronts per send workgroup (each works on its own)
     int debug_skip;  // profiling only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs
-    double heavy_packets, heavy_rho;  // tuning: when the send kernel hands an env to the wave path
-    uint32_t round_packets, takeover_lanes, send_envs_per_wave, help_lanes, send_waves;
+    uint32_t round_packets, takeover_lanes, send_envs_per_wave, send_waves;
     double heavy_predict;  // predicted packets per MI above which an env goes to the heavy wave
     double lo[5], hi[5];
     int rng_mode;
     const double *trace;
     int64_t trace_stride;
     const double *p_bw, *p_dl, *p_queue, *p_loss, *p_rate0;
-    const uint32_t *send_order;  // optional [N]: send-kernel slot -> env id (load balancing), else identity
     // link + env state, [N]
     double *bw, *dl, *lr, *maxq, *ebw, *q, *tu, *now, *run_dur;
     uint32_t *steps, *episode, *flags;
     uint8_t *done, *resetting;
-    uint8_t *heavy_flag;   // [N] env predicted (by the previous retire) to send many packets in its next MI
     unsigned long long *total_sent;
     // per sender, [S][N]
     double *rate, *rate0, *next_send, *min_lat, *ep_return, *last_return;
@@ -320,17 +320,63 @@ struct SendState {  // wave-uniform while an env is processed by the whole wave
     uint32_t a, d, sent, flags;
 };
 
-// One monitor interval of SENDs for ONE env by all 64 lanes (NS = 1).  Exact, not approximate:
-//   * inside one binade, t_{k+1} = fl(t_k + gap) advances by a constant G = t_1 - t_0 (an exact
-//     multiple of ulp(t)), so lane k owns send time t_0 + k*G -- checked each pass (two equal
-//     increments, t_0 >= 128*gap so k*G is exact, no binade crossing within the pass);
-//   * once ulp(t) >= ulp(q) (t, tu >= maxq) the drain q - (t_k - tu) is exact, so between two
-//     accepted packets the queue seen by packet k is max(0, q_m - (t_k - t_m)) whatever the
-//     tail drops / random losses in between (they leave exactly that state behind), and the
-//     tail-drop test is monotone in k.  The only serial dependence left is from one ACCEPTED
-//     packet to the next: under overload that is ~1 in rate/bw packets;
-//   * a pass whose preconditions fail sends one packet with the serial recurrence instead.
-// Records leave as two dense runs (accepted / dropped) -> coalesced stores.
+// ---- pieces of the wave pass ---------------------------------------------------------------
+// Lindley map b -> max(b + s, c) of the token bucket (see heavy_mi); maps compose as
+// (s2, c2) after (s1, c1) = (s1 + s2, max(c1 + s2, c2)), so the tokens every lane starts with come
+// from one prefix scan of the lanes' composites: six DPP steps, no LDS.
+constexpr int kLindNone = -(1 << 28);  // "-inf" with room for every shift a pass can add
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void lind_step(int &s, int &c) {
+    // lanes without a source (start of a row / rows the mask leaves out) read the identity map
+    const int ps = __builtin_amdgcn_update_dpp(0, s, CTRL, ROW_MASK, 0xF, false);
+    const int pc = __builtin_amdgcn_update_dpp(kLindNone, c, CTRL, ROW_MASK, 0xF, false);
+    const int nc = pc + s > c ? pc + s : c;  // this lane's map after the source's
+    s = ps + s;
+    c = nc;
+}
+
+// exclusive prefix over the 64 lanes: on return (s, c) is the composite of all lower lanes' maps
+__device__ __forceinline__ void lind_exclusive_scan(int &s, int &c) {
+    lind_step<0x111, 0xF>(s, c);  // row_shr:1
+    lind_step<0x112, 0xF>(s, c);  // row_shr:2
+    lind_step<0x114, 0xF>(s, c);  // row_shr:4
+    lind_step<0x118, 0xF>(s, c);  // row_shr:8  -> inclusive inside each row of 16
+    lind_step<0x142, 0xA>(s, c);  // row_bcast:15 into rows 1 and 3
+    lind_step<0x143, 0xC>(s, c);  // row_bcast:31 into rows 2 and 3 -> inclusive over the wave
+    s = __builtin_amdgcn_update_dpp(0, s, 0x138, 0xF, 0xF, false);          // wave_shr:1
+    c = __builtin_amdgcn_update_dpp(kLindNone, c, 0x138, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ double pow2_f64(int e_unbiased) {  // 2^e for a normal result
+    return __hiloint2double((e_unbiased + 1023) << 20, 0);
+}
+
+// One monitor interval of SENDs for ONE env by all 64 lanes (NS = 1), up to 256 packets per pass:
+// lane l owns pass positions 4l..4l+3 = one Philox block.  Exact, not approximate -- every pass
+// reproduces the per-packet recurrence of Link.packet_enters_link (ns:66-84) bit for bit; the
+// argument is spelled out (and machine-checked against the plain recurrence, on fuzzed states and on
+// the MI start states of whole episodes) in tests/models/send_pass_model.c, which mirrors this
+// function operation by operation.
+//   * Send times: inside one binade t_{k+1} = fl(t_k + gap) advances by a constant G = t_1 - t_0,
+//     an exact multiple of ulp(t), so position k is sent at t_0 + k G -- checked per pass (two
+//     equal increments, t_0 >= 512 gap so that k G is exact, no binade crossing inside the pass).
+//   * Regime A, "always empty": gap >= 1/bw and the first packet already finds the queue drained.
+//     Then every packet does: latency dl, accepted unless lost at random, queue = 1/bw behind it.
+//   * Regime B, "backlogged in one binade": with t, tu >= maxq the drain q - (t - tu) is exact, and
+//     while the queue never empties and q stays inside one binade [2^e, 2^(e+1)) every quantity is a
+//     multiple of u = ulp(q) and fl(1/bw + x) = x + R, R = 1/bw rounded to a multiple of u.  After j
+//     accepted packets the queue seen at t is exactly x = q0 + j R - (t - tu0), and "accepted" is a
+//     token bucket: packet k is accepted iff it is not a random loss and j(k) < N_k =
+//     floor((maxq - R - q0 + (t_k - tu0)) / R) + 1.  b_k = N_k - j(k) follows Lindley's recursion
+//     b' = max(b - m, 0) + a (m: not lost, a: token arrivals), a (max,+)-linear map: one prefix scan
+//     gives all 256 decisions.  When the queue has room for >= 300 packets, or the sender is slower
+//     than the link, tokens never run out and the scan is skipped.  A packet that breaks a
+//     precondition (queue empties, q leaves the binade) is detected per packet; the pass commits the
+//     prefix before the first such packet.
+//   * Otherwise (episode start, binade changes, ties of the rounding of 1/bw): a few packets with the
+//     plain recurrence, wave-uniform.
+// Records leave in send order as dense runs per ring -> coalesced stores.
 template <bool TRACE>
 __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl, double lr, uint32_t thr, bool always,
                                          double maxq, double ebw, double gap, double end, uint32_t episode,
@@ -338,134 +384,363 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                                          SendState &st) {
     const uint32_t mask_b = (cap - 1u) << 4, dmask_b = (2u * cap - 1u) << 4, cap_b = cap << 4;
     const uint64_t lt = (1ull << lane) - 1ull;
-    // loss decisions of 256 packets at a time: every lane draws one Philox block (4 packets), four
-    // ballots keep the bits -- bit b of lb[k] is packet lb_base + 4 b + k -- and four passes use them
-    uint64_t lb[4] = {0, 0, 0, 0};
-    uint32_t lb_base = 0;
-    bool lb_valid = false;
+    constexpr uint32_t kPass = 4u * kWave;
+    uint32_t serial_len = 8;
+    uint32_t chain_left = 0;  // passes to send by the accept chain before the closed forms are tried again
     while (st.t < end) {
+        const uint64_t dbg_c0 = D.pass_counters ? __builtin_readcyclecounter() : 0;
         const double t0 = st.t;
-        // ---- loss decisions of the next 64 packets, one per lane
-        bool rnd;
-        if (TRACE) {
-            const uint64_t pos = (uint64_t)st.a + st.d + lane;
-            double u = 1.0;
-            if ((int64_t)pos < D.trace_stride) u = trace[pos];
-            rnd = u < lr;
-        } else {
-            const uint32_t j0 = st.sent;  // wave-uniform
-            if (!lb_valid || j0 < lb_base || j0 + kWave > lb_base + 4u * kWave) {
-                lb_base = j0 & ~3u;
-                uint32_t w[4];
-                philox4x32_10((lb_base >> 2) + lane, mi, episode, gid, D.key0, D.key1, w);
-#pragma unroll
-                for (int k = 0; k < 4; k++) lb[k] = __ballot(always || w[k] < thr);
-                lb_valid = true;
-            }
-            const uint32_t p = j0 + lane - lb_base;  // this lane's packet inside the cached window
-            const uint64_t m = (p & 3u) == 0 ? lb[0] : (p & 3u) == 1 ? lb[1] : (p & 3u) == 2 ? lb[2] : lb[3];
-            rnd = (m >> (p >> 2)) & 1ull;
-        }
-        const uint64_t rmask = __ballot(rnd);
-
         const double t1s = t0 + gap;
         const double G = t1s - t0;
         const double t2s = t1s + gap;
-        const double tend = t0 + 64.0 * G;
-        const bool ok = (t2s - t1s == G) && (t0 >= 128.0 * gap) &&
-                        (exponent_bits(t0) == exponent_bits(tend)) && (st.tu >= maxq) && (st.tu + st.tu >= tend) &&
-                        (G > 0.0);
-        double my_t = 0.0, my_lat = 0.0;
-        bool my_drop = true;
-        uint32_t nv;
-        if (!ok) {
-            // ---- serial pass: up to 64 packets with the plain recurrence, wave-uniform (every lane
-            // computes the same values; lane k keeps packet k's record), exact with no precondition
-            double t = t0;
-            // packets certainly before `end` (two of margin for the rounding of t += gap) run under a
-            // scalar loop counter; the rest with the exit test, kept scalar through readfirstlane
-            const double ahead = (end - t0) / gap - 2.0;
-            const uint32_t nsafe = (uint32_t)__builtin_amdgcn_readfirstlane(
-                (int)(ahead >= 64.0 ? 64u : (ahead > 0.0 ? (uint32_t)ahead : 0u)));
-            uint32_t k = 0;
-            for (; k < nsafe; k++) {
-                bool dropped;
-                const double2 rec = link_send(t, (rmask >> k) & 1ull, dl, maxq, ebw, st.q, st.tu, dropped);
-                if (lane == k) { my_t = rec.x; my_lat = rec.y; my_drop = dropped; }
-                t += gap;  // ns:161
+        const double tend = t0 + (double)kPass * G;
+        // positions whose send time leaves the binade of t0 are not part of the pass (t0 + k G would not be
+        // exact there): the pass ends at lim = min(end, top of the binade)
+        const double ttop = pow2_f64((int)exponent_bits(t0) - 1022);
+        const double lim = end < ttop ? end : ttop;
+        const bool ok_t = (t2s - t1s == G) && (G > 0.0) && (t0 >= ((double)kPass + 4.0) * gap) &&
+                          (exponent_bits(t0) == exponent_bits(t2s));
+        const uint32_t skip = st.sent & 3u;  // positions of lane 0's Philox block that were sent before this pass
+        const double D0 = t0 - st.tu;
+        const double x0 = st.q - D0;         // the queue the first packet sees (before max0), ns:66-67
+        // ---- regime (wave-uniform)
+        int regime = 0;  // 0 serial, 1 = A, 2 = B
+        uint32_t e = 0;
+        double u = 0.0, R = 0.0;
+        int64_t Q0i = 0, D0i = 0, Gi = 0, Ri = 0, Ci = 0;
+        bool maxq_above = false, free_mode = false;
+        if (ok_t && chain_left == 0u) {
+            if (G >= ebw && !(x0 > 0.0)) {
+                regime = 1;
+            } else {
+                e = exponent_bits(st.q);
+                const uint32_t eb = exponent_bits(ebw);
+                bool ok = (st.q > 0.0) && e > 64u && e < 1100u && (st.tu + st.tu >= tend) && (x0 > 0.0) &&
+                          (eb <= e) && exponent_bits(st.tu) >= e && exponent_bits(maxq) >= e;
+                if (ok) {
+                    u = pow2_f64((int)e - 1023 - 52);
+                    const double inv_u = pow2_f64(-((int)e - 1023 - 52));
+                    const double probe = pow2_f64((int)e - 1023);
+                    R = (eb == e) ? ebw : (probe + ebw) - probe;
+                    const double err = ebw - R;
+                    const bool tie = fabs(err) == 0.5 * u;
+                    const double span = (D0 + (double)kPass * G) * inv_u;  // everything in units of u must fit an int64
+                    ok = span < 4.0e18 && R > 0.0;
+                    if (ok) {
+                        Q0i = (int64_t)(st.q * inv_u);
+                        D0i = (int64_t)(D0 * inv_u);
+                        Gi = (int64_t)(G * inv_u);
+                        Ri = (int64_t)(R * inv_u);
+                        // room in the queue in packets (estimate): with >= 300 no packet of this pass can be
+                        // tail-dropped and the token arithmetic is not needed (maxq / u may not fit an int64)
+                        const double room = ((maxq - R) - x0) / R;
+                        free_mode = room >= 300.0;
+                        const int64_t Mi = free_mode ? 0 : (int64_t)(maxq * inv_u);
+                        Ci = (Mi - Ri) - Q0i + D0i;  // tokens before packet k: floor((Ci + Ri + k Gi) / Ri) >= 0
+                        // a tie rounds to even: x + R holds only while every x is an even multiple of u
+                        if (tie && ((Q0i | D0i | Gi) & 1)) ok = false;
+                        maxq_above = exponent_bits(maxq) > e;
+                        // the first packet would already take q out of the binade: no point in trying
+                        const uint32_t es0 = exponent_bits(x0 + R);
+                        if (es0 < e || (es0 > e && maxq_above)) ok = false;
+                    }
+                }
+                if (ok) regime = 2;
             }
-            for (; k < 64u && __builtin_amdgcn_readfirstlane((int)(t < end)); k++) {
-                bool dropped;
-                const double2 rec = link_send(t, (rmask >> k) & 1ull, dl, maxq, ebw, st.q, st.tu, dropped);
-                if (lane == k) { my_t = rec.x; my_lat = rec.y; my_drop = dropped; }
-                t += gap;  // ns:161
-            }
-            nv = k;
-            st.t = t;
-        } else {
-            // ---- accept-to-accept pass over 64 packets
-            const double tk = t0 + (double)lane * G;
-            const bool valid = tk < end;
-            const uint64_t vmask = __ballot(valid);
-            nv = (uint32_t)__popcll(vmask);  // valid lanes are a prefix (tk increases)
-            // Phase 1 -- the chain from one ACCEPTED packet to the next, nothing else: with (qm, tm)
-            // the link state the last accepted packet left, every lane tests "would I be tail-dropped";
-            // the first lane that is neither that nor a random loss is the next accepted packet.  Its
-            // (queue after, time) go to lane #accept of seg_q/seg_t.
-            double qm = st.q, tm = st.tu;
-            uint64_t open = vmask & ~rmask;          // lanes that can still be the next accepted packet
-            uint64_t amask = 0;                      // accepted lanes
-            uint32_t na = 0;
-            double seg_q = 0.0, seg_t = 0.0;         // lane j: link state after the j-th accepted packet
-            while (open) {
-                const double qc = max0(qm - (tk - tm));  // queue seen by packet k if nothing was accepted since tm
-                const bool full = ebw + qc > maxq;       // monotone non-increasing in k
-                const uint64_t cm = open & ~__ballot(full);
-                if (!cm) break;
-                const uint32_t ks = (uint32_t)__ffsll((unsigned long long)cm) - 1u;
-                qm = rl_f64(ebw + qc, ks);               // ns:82
-                tm = rl_f64(tk, ks);                     // ns:76
-                if (lane == na) { seg_q = qm; seg_t = tm; }
-                na++;
-                amask |= 1ull << ks;
-                open &= ~((2ull << ks) - 1ull);          // lanes after ks
-            }
-            // Phase 2 -- every lane finishes its own packet from the state its segment started with:
-            // segment = number of accepted packets before this lane (0 = the state the pass began with)
-            const uint32_t seg = (uint32_t)__popcll(amask & lt);
-            const int src = seg ? (int)seg - 1 : 0;
-            double q_seg = __shfl(seg_q, src);
-            double t_seg = __shfl(seg_t, src);
-            if (!seg) { q_seg = st.q; t_seg = st.tu; }
-            const double qc = max0(q_seg - (tk - t_seg));
-            my_lat = dl + qc;                            // ns:170
-            my_drop = !((amask >> lane) & 1ull);
-            const double my_q_after = my_drop ? qc : ebw + qc;  // link state this packet leaves unless a random loss
-            my_t = tk + my_lat;                          // ns:174
-            // link state after the pass = what the last packet that was not a random loss left (ns:75-82)
-            const uint64_t touch = vmask & ~rmask;
-            if (touch) {
-                const uint32_t kl = 63u - (uint32_t)__clzll((long long)touch);
-                st.q = rl_f64(my_q_after, kl);
-                st.tu = rl_f64(tk, kl);
-            }
-            st.t = t0 + (double)nv * G;                  // exact: the (nv)-th send time
         }
-        // ---- the pass's records leave as two dense runs: coalesced stores
-        const bool valid = lane < nv;
-        if (TRACE && (int64_t)((uint64_t)st.a + st.d + nv) > D.trace_stride) st.flags |= PCC_FLAG_TRACE_OVERRUN;
-        const uint64_t dm = __ballot(valid && my_drop), am = __ballot(valid && !my_drop);
-        if (valid) {
-            double2 rec;
-            rec.x = my_t;
-            rec.y = my_lat;
-            const uint32_t off = my_drop ? cap_b + (((st.d + (uint32_t)__popcll(dm & lt)) << 4) & dmask_b)
-                                         : (((st.a + (uint32_t)__popcll(am & lt)) << 4) & mask_b);
-            st_rec(reinterpret_cast<double2 *>(base + off), rec);
+
+        if (regime != 0) {
+            // ---- loss decisions of the lane's four positions (bit i: lost at random, ns:73)
+            const int kbase = 4 * (int)lane - (int)skip;  // packet index (within the pass) of position 0 of this lane
+            uint32_t rnd4 = 0;
+            if (TRACE) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k = kbase + i;
+                    const int64_t pos = (int64_t)((uint64_t)st.a + st.d) + k;
+                    double uu = 1.0;
+                    if (k >= 0 && pos < D.trace_stride) uu = trace[pos];
+                    rnd4 |= (uu < lr ? 1u : 0u) << i;
+                }
+            } else {
+                uint32_t w[4];
+                philox4x32_10((st.sent >> 2) + lane, mi, episode, gid, D.key0, D.key1, w);
+#pragma unroll
+                for (int i = 0; i < 4; i++) rnd4 |= ((always || w[i] < thr) ? 1u : 0u) << i;
+            }
+            // ---- which positions hold a packet of this MI, and which of those reach the queue
+            uint32_t ex4 = 0, m4 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k = kbase + i;
+                const double tki = t0 + (double)(k < 0 ? 0 : k) * G;  // exact
+                const bool ex = k >= 0 && tki < lim;
+                ex4 |= (ex ? 1u : 0u) << i;
+                m4 |= ((ex && !((rnd4 >> i) & 1u)) ? 1u : 0u) << i;
+            }
+            // what the lane keeps of its four positions: accepted / flagged bits, and the queue (before
+            // max0) and the accepted count at its first position -- the rest is replayed when needed
+            uint32_t acc4 = 0, flag4 = 0;
+            double x_base = 0.0;
+            int j_base = 0;
+            if (regime == 1) {
+                acc4 = m4;
+#pragma unroll
+                for (int i = 0; i < 4; i++) j_base += (int)__popcll(__ballot((acc4 >> i) & 1u) & lt);
+            } else {
+                const bool over = !free_mode && Gi < Ri;  // overdriven and close to full: the token scan decides
+                const int k0 = kbase < 0 ? 0 : kbase;
+                int b = 0, N = 0;
+                uint32_t a4 = 0;
+                if (over) {
+                    // tokens at the lane's first packet: one division, double estimate + exact correction
+                    const int64_t num = Ci + Ri + (int64_t)k0 * Gi;  // >= 0
+                    N = (int)((double)num * (1.0 / (double)Ri));
+                    int64_t rem = num - (int64_t)N * Ri;
+                    if (rem < 0) { N--; rem += Ri; }
+                    if (rem >= Ri) { N++; rem -= Ri; }
+                    int ssum = 0, cmax = kLindNone;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        int a = 0;
+                        if (kbase + i >= 0) {  // arrivals run on past the MI end: harmless
+                            rem += Gi;
+                            if (rem >= Ri) { rem -= Ri; a = 1; }
+                        }
+                        a4 |= (uint32_t)a << i;
+                        const int sft = a - (int)((m4 >> i) & 1u);
+                        cmax = cmax + sft > a ? cmax + sft : a;  // this packet's map after the earlier ones
+                        ssum += sft;
+                    }
+                    const int b0 = __builtin_amdgcn_readfirstlane(N);  // lane 0's first packet is packet 0
+                    lind_exclusive_scan(ssum, cmax);
+                    b = b0 + ssum > cmax ? b0 + ssum : cmax;
+                    j_base = N - b;
+                } else {
+                    // the first packet of the pass meets the threshold test like any other; after it, with the
+                    // sender slower than the link (or >= 300 packets of room), a token is always there:
+                    // accepted = not lost, accepted before the lane = a prefix popcount
+                    acc4 = m4;
+                    if (lane == 0 && !(free_mode || Ci >= 0)) acc4 &= ~(1u << skip);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) j_base += (int)__popcll(__ballot((acc4 >> i) & 1u) & lt);
+                }
+                // exact base: x = (Q0 + j R - D0 - k0 G) u in integers, one exact conversion
+                const int64_t xi = Q0i + (int64_t)j_base * Ri - D0i - (int64_t)k0 * Gi;
+                x_base = (double)xi * u;
+                double x = x_base;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bool m = (m4 >> i) & 1u;
+                    bool a;
+                    if (over) {
+                        a = m && b > 0;
+                        acc4 |= (a ? 1u : 0u) << i;
+                    } else {
+                        a = (acc4 >> i) & 1u;
+                    }
+                    const double sx = x + R;  // the queue behind this packet if it is accepted (ns:82)
+                    const uint32_t es = exponent_bits(sx);
+                    const bool f = m && (!(x > 0.0) || es < e || (es > e && maxq_above));
+                    flag4 |= (f ? 1u : 0u) << i;
+                    if (kbase + i >= 0) {
+                        if (over) b = (b - (m ? 1 : 0) > 0 ? b - (m ? 1 : 0) : 0) + (int)((a4 >> i) & 1u);
+                        x = (a ? sx : x) - G;  // exact: multiples of u below 2^(e+1)
+                    }
+                }
+            }
+            // ---- the pass stops at the first position that is past the MI end or breaks a precondition
+            uint32_t stop4 = (~ex4 | flag4) & 0xFu;
+            if (lane == 0) stop4 &= ~((1u << skip) - 1u);  // positions before `skip` are not part of the pass
+            const uint64_t stop_lanes = __ballot(stop4 != 0u);
+            uint32_t p_stop = kPass, j_stop;
+            bool stopped_by_flag = false;
+            if (stop_lanes) {
+                const uint32_t ls = (uint32_t)__ffsll((unsigned long long)stop_lanes) - 1u;
+                const uint32_t is = ((uint32_t)__ffs((int)stop4) - 1u) & 3u;
+                p_stop = 4u * ls + rl_u32(is, ls);
+                j_stop = rl_u32((uint32_t)j_base + (uint32_t)__popc(acc4 & ((1u << is) - 1u)), ls);
+                stopped_by_flag = rl_u32((flag4 >> is) & 1u, ls) != 0u;
+            } else {
+                j_stop = rl_u32((uint32_t)j_base + (uint32_t)__popc(acc4), kWave - 1u);
+            }
+            const uint32_t ncommit = p_stop - skip;
+            // q hovering around a power of two (or a queue that keeps running empty) breaks a pass after a
+            // few packets every time: send the next stretch by the accept chain, which has no such
+            // precondition, then try again
+            if (stopped_by_flag && ncommit < 32u) chain_left = 4u;
+            if (ncommit) {
+                if (TRACE && (int64_t)((uint64_t)st.a + st.d + ncommit) > D.trace_stride) st.flags |= PCC_FLAG_TRACE_OVERRUN;
+                // ---- records, in send order per ring (the lane replays its positions); the link state
+                // behind the last packet that reached the queue
+                double last_q = 0.0, last_t = 0.0;
+                bool have_last = false;
+                double x = x_base;
+                uint32_t j = (uint32_t)j_base;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t p = 4u * lane + (uint32_t)i;
+                    const bool a = (acc4 >> i) & 1u;
+                    if (p >= skip && p < p_stop) {
+                        const uint32_t kk = p - skip;             // packets of the pass before this one
+                        const double tki = t0 + (double)kk * G;   // exact
+                        const double qc = regime == 1 ? 0.0 : max0(x);  // ns:66-67
+                        double2 rec;
+                        rec.y = dl + qc;                          // ns:170
+                        rec.x = tki + rec.y;                      // ns:174
+                        const uint32_t off = a ? (((st.a + j) << 4) & mask_b) : cap_b + (((st.d + (kk - j)) << 4) & dmask_b);
+                        st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                        if ((m4 >> i) & 1u) {
+                            have_last = true;
+                            last_t = tki;
+                            last_q = regime == 1 ? ebw + 0.0 : (a ? x + R : x);  // ns:75-82
+                        }
+                    }
+                    if (kbase + i >= 0) {
+                        x = (a ? x + R : x) - G;
+                        j += a ? 1u : 0u;
+                    }
+                }
+                const uint64_t lm = __ballot(have_last);
+                if (lm) {
+                    const uint32_t ll = 63u - (uint32_t)__clzll((long long)lm);
+                    st.q = rl_f64(last_q, ll);
+                    st.tu = rl_f64(last_t, ll);
+                }
+                if (D.pass_counters && lane == 0) {
+                    const int c = regime == 1 ? 0 : (!free_mode && Gi < Ri) ? 1 : 2;
+                    atomicAdd(&D.pass_stats[c], 1ull);
+                    atomicAdd(&D.pass_stats[4 + c], (unsigned long long)ncommit);
+                    atomicAdd(&D.pass_stats[13], (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));
+                }
+                st.t = (t0 + (double)(ncommit - 1u) * G) + gap;  // ns:161 on the last packet's (exact) send time
+                st.a += j_stop;
+                st.d += ncommit - j_stop;
+                st.sent += ncommit;
+                serial_len = 8;
+                continue;
+            }
+            if (D.pass_counters && lane == 0) atomicAdd(&D.pass_stats[8], 1ull);  // nothing to commit: first packet flagged
+        } else if (D.pass_counters && lane == 0) {
+            atomicAdd(&D.pass_stats[ok_t ? 10 : 9], 1ull);
         }
-        st.a += (uint32_t)__popcll(am);
-        st.d += (uint32_t)__popcll(dm);
-        st.sent += nv;
+        // ---- serial pass: up to serial_len packets with the plain recurrence, wave-uniform (every lane
+        // computes the same values; lane k keeps packet k's record), exact with no precondition
+        {
+            bool rnd;
+            if (TRACE) {
+                const uint64_t pos = (uint64_t)st.a + st.d + lane;
+                double uu = 1.0;
+                if ((int64_t)pos < D.trace_stride) uu = trace[pos];
+                rnd = uu < lr;
+            } else {
+                const uint32_t jp = st.sent + lane;
+                uint32_t w[4];
+                philox4x32_10(jp >> 2, mi, episode, gid, D.key0, D.key1, w);
+                const uint32_t xw = (jp & 3u) == 0 ? w[0] : (jp & 3u) == 1 ? w[1] : (jp & 3u) == 2 ? w[2] : w[3];
+                rnd = always || xw < thr;
+            }
+            const uint64_t rmask = __ballot(rnd);
+            double my_t = 0.0, my_lat = 0.0;
+            bool my_drop = true;
+            uint32_t nv;
+            if (chain_left) chain_left--;
+            const double tend64 = t0 + 64.0 * G;
+            const bool ok_chain = (t2s - t1s == G) && (G > 0.0) && (t0 >= 128.0 * gap) &&
+                                  (exponent_bits(t0) == exponent_bits(tend64)) && (st.tu >= maxq) &&
+                                  (st.tu + st.tu >= tend64);
+            if (ok_chain) {
+                // ---- accept-to-accept pass over 64 packets, one per lane.  With t, tu >= maxq the drain
+                // q - (t - tu) is exact, so between two ACCEPTED packets the queue seen by packet k is
+                // max(0, q_m - (t_k - t_m)) whatever tail drops and random losses lie in between, and the
+                // tail-drop test is monotone in k.  Phase 1 is the chain from one accepted packet to the
+                // next (ballot of "not lost, not full", first set lane, readlanes), every floating-point
+                // step the reference's own; phase 2 lets every lane finish its packet from the state its
+                // segment started with.
+                const double tk = t0 + (double)lane * G;
+                const bool vk = tk < end;
+                const uint64_t vmask = __ballot(vk);
+                nv = (uint32_t)__popcll(vmask);  // valid lanes are a prefix (tk increases)
+                double qm = st.q, tm = st.tu;
+                uint64_t open = vmask & ~rmask;          // lanes that can still be the next accepted packet
+                uint64_t amask = 0;                      // accepted lanes
+                uint32_t na = 0;
+                double seg_q = 0.0, seg_t = 0.0;         // lane j: link state after the j-th accepted packet
+                while (open) {
+                    const double qc = max0(qm - (tk - tm));  // queue seen by packet k if nothing was accepted since tm
+                    const bool full = ebw + qc > maxq;       // monotone non-increasing in k
+                    const uint64_t cm = open & ~__ballot(full);
+                    if (!cm) break;
+                    const uint32_t ks = (uint32_t)__ffsll((unsigned long long)cm) - 1u;
+                    qm = rl_f64(ebw + qc, ks);               // ns:82
+                    tm = rl_f64(tk, ks);                     // ns:76
+                    if (lane == na) { seg_q = qm; seg_t = tm; }
+                    na++;
+                    amask |= 1ull << ks;
+                    open &= ~((2ull << ks) - 1ull);          // lanes after ks
+                }
+                const uint32_t seg = (uint32_t)__popcll(amask & lt);
+                const int src = seg ? (int)seg - 1 : 0;
+                double q_seg = __shfl(seg_q, src);
+                double t_seg = __shfl(seg_t, src);
+                if (!seg) { q_seg = st.q; t_seg = st.tu; }
+                const double qc = max0(q_seg - (tk - t_seg));
+                my_lat = dl + qc;                            // ns:170
+                my_drop = !((amask >> lane) & 1ull);
+                const double my_q_after = my_drop ? qc : ebw + qc;  // link state this packet leaves unless a random loss
+                my_t = tk + my_lat;                          // ns:174
+                const uint64_t touch = vmask & ~rmask;
+                if (touch) {
+                    const uint32_t kl = 63u - (uint32_t)__clzll((long long)touch);
+                    st.q = rl_f64(my_q_after, kl);
+                    st.tu = rl_f64(tk, kl);
+                }
+                if (nv) st.t = (t0 + (double)(nv - 1u) * G) + gap;  // ns:161 on the last packet's (exact) send time
+            } else {
+                double t = t0;
+                // packets certainly before `end` (two of margin for the rounding of t += gap) run under a
+                // scalar loop counter; the rest with the exit test, kept scalar through readfirstlane
+                const double ahead = (end - t0) / gap - 2.0;
+                uint32_t nsafe = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)(ahead >= 64.0 ? 64u : (ahead > 0.0 ? (uint32_t)ahead : 0u)));
+                if (nsafe > serial_len) nsafe = serial_len;
+                uint32_t k = 0;
+                for (; k < nsafe; k++) {
+                    bool dropped;
+                    const double2 rec = link_send(t, (rmask >> k) & 1ull, dl, maxq, ebw, st.q, st.tu, dropped);
+                    if (lane == k) { my_t = rec.x; my_lat = rec.y; my_drop = dropped; }
+                    t += gap;  // ns:161
+                }
+                for (; k < serial_len && __builtin_amdgcn_readfirstlane((int)(t < end)); k++) {
+                    bool dropped;
+                    const double2 rec = link_send(t, (rmask >> k) & 1ull, dl, maxq, ebw, st.q, st.tu, dropped);
+                    if (lane == k) { my_t = rec.x; my_lat = rec.y; my_drop = dropped; }
+                    t += gap;  // ns:161
+                }
+                nv = k;
+                st.t = t;
+                if (serial_len < 64u) serial_len *= 2u;
+            }
+            const bool valid = lane < nv;
+            if (TRACE && (int64_t)((uint64_t)st.a + st.d + nv) > D.trace_stride) st.flags |= PCC_FLAG_TRACE_OVERRUN;
+            const uint64_t dm = __ballot(valid && my_drop), am = __ballot(valid && !my_drop);
+            if (valid) {
+                double2 rec;
+                rec.x = my_t;
+                rec.y = my_lat;
+                const uint32_t off = my_drop ? cap_b + (((st.d + (uint32_t)__popcll(dm & lt)) << 4) & dmask_b)
+                                             : (((st.a + (uint32_t)__popcll(am & lt)) << 4) & mask_b);
+                st_rec(reinterpret_cast<double2 *>(base + off), rec);
+            }
+            st.a += (uint32_t)__popcll(am);
+            st.d += (uint32_t)__popcll(dm);
+            st.sent += nv;
+            if (D.pass_counters && lane == 0) {
+                atomicAdd(&D.pass_stats[3], 1ull);
+                atomicAdd(&D.pass_stats[7], (unsigned long long)nv);
+                atomicAdd(&D.pass_stats[14], (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));
+            }
+        }
     }
 }
 
@@ -613,28 +888,17 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
     }
 }
 
+// One work item of the send half: the SEND events of the coming monitor interval for the envs the
+// lanes of this wavefront were given (lane l: env i, or none).  A light item is up to 64 envs of about
+// the same predicted packet count, sent lane-per-env in rounds; a heavy item (`heavy_wave`) is ONE env
+// sent by all 64 lanes (heavy_mi).  Which path sends an env is a performance choice only: every path
+// is exact.  Lanes without an env stay in: the wave path needs all 64 lanes as workers.
 template <int NS, bool TRACE>
-__device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, const uint32_t tid,
-                                          const uint32_t n_heavy_waves, int warm, uint32_t warm_mi, const void *actions,
-                                          int actions_f64) {
-    const uint32_t lane = tid & (kWave - 1);
-    // 1 + n_heavy_waves wavefronts per block of envs.  Wave 0 ("light") runs the lane-per-env rounds
-    // for the envs NOT flagged heavy; waves 1.. ("heavy") share the flagged envs round-robin and send
-    // each with all 64 lanes (heavy_mi).  The flag is the previous retire's prediction for this MI --
-    // a performance hint only, every path is exact -- and the waves touch disjoint envs, so nothing
-    // is shared.  Lanes without an env stay in the kernel: the wave path needs all 64 lanes as workers.
-    const bool heavy_wave = tid >= kWave;
-    const int64_t slot = (int64_t)block * D.send_envs_per_wave + lane;
-    const bool in_range = lane < D.send_envs_per_wave && slot < D.n;
-    // which env this lane sends for: a caller-supplied order (e.g. heaviest envs dealt round-robin
-    // over the wavefronts) only changes who waits for whom, never a result
-    const int64_t i = (in_range && D.send_order) ? (int64_t)D.send_order[slot] : slot;
-    const bool flagged = in_range && D.heavy_flag[in_range ? i : 0] != 0;
-    // the heavy wavefronts (three by default, send_waves - 1) deal the flagged envs of the block round-robin
-    const uint32_t flag_rank = (uint32_t)__popcll(__ballot(flagged) & ((1ull << lane) - 1ull));
-    const bool mine = heavy_wave ? (flagged && flag_rank % n_heavy_waves == tid / kWave - 1u) : !flagged;
-    const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]) && mine;
-    if (heavy_wave && !__ballot(live)) return;
+__device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, const int64_t i, const bool in_range,
+                                          const bool heavy_wave, const uint32_t tl_slot, int warm, uint32_t warm_mi,
+                                          const void *actions, int actions_f64) {
+    const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]);
+    if (!__ballot(live)) return;
     const int64_t ii = live ? i : 0;
     const uint64_t tl0 = D.timeline ? wall_clock64() : 0;
     uint64_t tl1 = 0, tl_heavy = 0, tl_heavy_pk = 0;
@@ -701,6 +965,9 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
         const bool always = thr_d >= 4294967296.0;
         const uint32_t thr = always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
         char *base = rings[0].base;
+        // profiling only: the lanes write into the rings of 64 NEIGHBOURING envs instead of their own (wrong results;
+        // isolates what the placement of a sorted item's rings costs)
+        if (D.debug_skip & 16) base = D.tier_base[0] + (size_t)(((uint64_t)tl_slot * 64u + lane) % (uint64_t)D.n) * tier_slot_bytes(D, 0);
         if (D.use_cwnd) {
             // ---- USE_CWND (ns:54, 251-255, 158-160): a SEND goes out only while fewer than cwnd
             // packets are unacknowledged.  That couples the SEND stream to the notifications, so this
@@ -767,10 +1034,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
             sent[0] = nsent;
             ta[0] = a; td[0] = d;
         } else {
-        // heavy = many packets ahead, most of them drops (rate well above bw), and the wave path's
-        // standing preconditions hold; everything else stays in the lane-serial loop
-        const bool heavy = run && (heavy_wave || ((end - nsend[0]) > D.heavy_packets * gap[0] && gap[0] < D.heavy_rho * ebw &&
-                                                  tu >= maxq && nsend[0] >= 128.0 * gap[0]));
+        const bool heavy = run && heavy_wave;
         double t = nsend[0];
         uint32_t a = ta[0], d = td[0];
         bool heavy_now = heavy;
@@ -779,28 +1043,10 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
         // Lane-serial rounds of round_packets packets per env.  After a round, if at most
         // takeover_lanes (default: one) lanes of the wave still have packets to send, they are the
         // tail everybody else would wait for: they go to the wave path, which sends ONE env's packets
-        // faster than a lone lane does; with a few lanes left, the idle lanes draw for them instead
-        // (helped rounds).
-        bool helped = false;
-        uint64_t loss_bits[4] = {0, 0, 0, 0};  // helped round: bit j of [k] = loss decision of packet 4j + k of the round
+        // faster than a lone lane does.  (The envs of a light item were filed together because they
+        // are about the same length, so the lanes normally finish within a round of each other.)
         for (;;) {
-            if (active && helped) {
-                for (uint32_t j = 0; j < 64u && t < end; j++) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (k > 0 && !(t < end)) break;
-                        bool dropped;
-                        const double2 rec = link_send(t, (loss_bits[k] >> j) & 1ull, dl, maxq, ebw, q, tu, dropped);
-                        const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                        st_rec(reinterpret_cast<double2 *>(base + off), rec);
-                        a += dropped ? 0u : 1u;
-                        d += dropped ? 1u : 0u;
-                        t += gap[0];  // ns:161
-                    }
-                    blk++;
-                }
-                active = t < end;
-            } else if (active) {
+            if (active) {
                 if (!TRACE) {
                     // four packets per Philox block, no loads, no data-dependent branches.  The first
                     // `safe` packets are certainly before `end` (t advances by gap up to rounding; two
@@ -810,14 +1056,14 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                     uint32_t budget4 = D.round_packets / 4 - safe4;
                     for (; safe4; safe4--) {
                         uint32_t w[4];
-                        philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                        if (D.debug_skip & 8) { w[0] = blk * 2654435761u; w[1] = w[0] ^ gid; w[2] = w[1] * 40503u; w[3] = w[2] ^ mi; } else philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
                         blk++;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             bool dropped;
                             const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
                             const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                            st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                            if (!(D.debug_skip & 4)) st_rec(reinterpret_cast<double2 *>(base + ((D.debug_skip & 16) ? (off & 8176u) : off)), rec);
                             a += dropped ? 0u : 1u;
                             d += dropped ? 1u : 0u;
                             t += gap[0];  // ns:161
@@ -825,7 +1071,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                     }
                     for (; budget4 && t < end; budget4--) {
                         uint32_t w[4];
-                        philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                        if (D.debug_skip & 8) { w[0] = blk * 2654435761u; w[1] = w[0] ^ gid; w[2] = w[1] * 40503u; w[3] = w[2] ^ mi; } else philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
                         blk++;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
@@ -833,7 +1079,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                             bool dropped;
                             const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
                             const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                            st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                            if (!(D.debug_skip & 4)) st_rec(reinterpret_cast<double2 *>(base + ((D.debug_skip & 16) ? (off & 8176u) : off)), rec);
                             a += dropped ? 0u : 1u;
                             d += dropped ? 1u : 0u;
                             t += gap[0];  // ns:161
@@ -862,29 +1108,8 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
                 heavy_now = heavy_now || active;
                 break;
             }
-            helped = !TRACE && (uint32_t)__popcll(am) <= D.help_lanes;
-            if (helped) {
-                // Few lanes left: the idle lanes draw for them.  For each active lane all 64 lanes
-                // compute one Philox block each (blocks blk .. blk+63 of that env = its next 256
-                // packets) and the loss decisions come back as four ballots, so the lane's round
-                // below runs without a single Philox round of its own.
-                uint64_t m = am;
-                while (m) {
-                    const uint32_t l = (uint32_t)__ffsll((unsigned long long)m) - 1u;
-                    m &= m - 1ull;
-                    uint32_t w[4];
-                    philox4x32_10(rl_u32(blk, l) + lane, rl_u32(mi, l), rl_u32(episode, l), rl_u32(gid, l), D.key0, D.key1, w);
-                    const uint32_t thr_l = rl_u32(thr, l);
-                    const bool always_l = rl_u32(always ? 1u : 0u, l) != 0u;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint64_t bm = __ballot(always_l || w[k] < thr_l);
-                        if (lane == l) loss_bits[k] = bm;
-                    }
-                }
-            }
         }
-        // heavy envs of this wave (standing or tail take-over), one after the other, 64 lanes each
+        // the envs for the wave path (a heavy item's env, or the tail of a light item), one after the other
         uint64_t hm = __ballot(heavy_now);
         if (D.timeline) {
             tl1 = wall_clock64();
@@ -896,6 +1121,7 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
             const uint32_t l = (uint32_t)__ffsll((unsigned long long)hm) - 1u;
             hm &= hm - 1ull;
             SendState st;
+            if (D.pass_counters && lane == 0) atomicAdd(&D.pass_stats[heavy_wave ? 11 : 12], 1ull);
             st.q = rl_f64(q, l); st.tu = rl_f64(tu, l); st.t = rl_f64(t, l);
             st.a = rl_u32(a, l); st.d = rl_u32(d, l); st.flags = 0;
             st.sent = (st.a - rl_u32(ta[0], l)) + (st.d - rl_u32(td[0], l));  // packets of this MI already sent by the lane
@@ -1030,8 +1256,8 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
             const uint64_t other = __shfl_xor(mx, o);
             mx = other > mx ? other : mx;
         }
-        if (lane == 0 && tid < 2 * kWave) {
-            uint64_t *w = D.timeline + ((int64_t)block * 2 + (heavy_wave ? 1 : 0)) * 8;
+        if (lane == 0) {
+            uint64_t *w = D.timeline + (int64_t)tl_slot * 8;
             w[0] = tl0; w[1] = tl1; w[2] = wall_clock64(); w[3] = tl_heavy; w[4] = sum; w[5] = mx; w[6] = hp;
             w[7] = (uint64_t)__popcll(__ballot(live));
         }
@@ -1050,12 +1276,105 @@ __device__ __forceinline__ void send_wave(const Dev &D, const uint32_t block, co
     if (flags) D.flags[i] |= flags;
 }
 
-constexpr uint32_t kMaxSendWaves = 8;  // per block of envs: one light wavefront + heavy ones (they exit at once when idle)
+// ---- work lists ----------------------------------------------------------------------------
+// The retire half knows every env's packet count of the NEXT monitor interval to within the effect
+// of one action (run_dur x rate), so it files the env under one of kClasses geometric classes
+// (class c >= 1: [8 * 1.25^(c-1), 8 * 1.25^c) packets; c = 0: fewer than 8).  The send half's work
+// items come off those lists, heaviest class first: every env of a class at or above the heavy
+// threshold is an item of its own (wave path), the envs of a lighter class go 64 at a time to
+// lane-per-env rounds -- lanes of about the same length, so a wavefront's lanes finish together.
+// Persistent wavefronts take the items off one atomic cursor: longest first, nobody waits for a
+// neighbour.  The lists are a permutation of the envs whatever the predictions say (a reset in
+// between leaves stale predictions: harmless).
+constexpr int kClasses = 32;
+constexpr int kClsStride = kClasses + 2;  // per buffer: kClasses counts, the item cursor, spare
+
+__device__ __forceinline__ int class_of(float pred) {
+    if (!(pred >= 8.0f)) return 0;
+    const int c = 1 + (int)(__log2f(pred * 0.125f) * 3.1062837f);  // 1 / log2(1.25)
+    return c < kClasses - 1 ? c : kClasses - 1;
+}
+
+// read_buf < 0: no lists (after a reset, and for the warm-up intervals): the items are the envs in
+// index order, 64 (send_envs_per_wave) at a time.  zero_buf: the buffer the coming retire launch files
+// into; its counters are cleared here.
+// Hand-out: item t belongs to shard t % kShards; wavefront w starts with item w (no atomic) and then
+// claims the next item of its shard from the shard's cursor -- one returning device-scope atomic on
+// one word saturates near 90 claims/us, 16 words in separate cache lines do not -- and helps the other
+// shards when its own is empty (a plain look at their cursors first: no atomic on an empty shard).
+constexpr uint32_t kShards = 16;
+constexpr uint32_t kCursorStride = 32;  // words between shard cursors: one 128-byte line each
 
 template <int NS, bool TRACE>
-__global__ __launch_bounds__(kMaxSendWaves * kWave) void send_kernel(Dev D, uint32_t block0, int warm, uint32_t warm_mi,
-                                                                     const void *actions, int actions_f64) {
-    send_wave<NS, TRACE>(D, block0 + blockIdx.x, threadIdx.x, blockDim.x / kWave - 1u, warm, warm_mi, actions, actions_f64);
+__global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf, int zero_buf, int warm, uint32_t warm_mi,
+                                                         const void *actions, int actions_f64) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;  // every wavefront works on its own
+    const uint32_t n_waves = gridDim.x * (blockDim.x / kWave);                      // a multiple of kShards
+    const uint32_t E = D.send_envs_per_wave;
+    if (wave == 0 && zero_buf >= 0) {
+        if (lane < (uint32_t)kClsStride) D.cls_count[zero_buf * kClsStride + lane] = 0u;
+        if (lane < kShards) D.cursors[((uint32_t)zero_buf * kShards + lane) * kCursorStride] = 0u;
+    }
+    // ---- item table: lane l < kClasses holds class kClasses-1-l (heaviest first)
+    const bool listed = read_buf >= 0;
+    const int cls_mine = kClasses - 1 - (int)lane;
+    const int cls_heavy = D.use_cwnd ? kClasses : (D.heavy_predict >= 1e9 ? kClasses : class_of((float)D.heavy_predict));
+    uint32_t n_mine = 0, items_mine = 0;
+    if (listed && lane < (uint32_t)kClasses) {
+        n_mine = D.cls_count[read_buf * kClsStride + cls_mine];
+        items_mine = cls_mine >= cls_heavy ? n_mine : (n_mine + E - 1) / E;
+    }
+    uint32_t incl = items_mine;  // inclusive prefix over lanes 0..31
+    for (int o = 1; o < kClasses; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o) incl += up;
+    }
+    const uint32_t n_items = listed ? rl_u32(incl, kClasses - 1) : (uint32_t)((D.n + E - 1) / E);
+    // the table goes to LDS (one copy per wavefront: no barrier needed), not to registers the items need
+    __shared__ uint32_t s_tab[4][3][kClasses];
+    uint32_t (*tab)[kClasses] = s_tab[threadIdx.x / kWave];
+    if (lane < (uint32_t)kClasses) { tab[0][lane] = incl; tab[1][lane] = items_mine; tab[2][lane] = n_mine; }
+    if (D.pass_stats && wave == 0 && lane == 0) D.pass_stats[15] = n_items;
+    uint32_t *cursors = D.cursors + (uint32_t)(listed ? read_buf : 2) * kShards * kCursorStride;
+    const uint32_t s_mine = wave % kShards, c0 = n_waves / kShards;
+    uint32_t t = wave;  // the first item: no claim
+    for (;;) {
+        if (t >= n_items) {
+            t = 0xFFFFFFFFu;
+            if (lane == 0 && listed) {
+                for (uint32_t k = 0; k < kShards && t == 0xFFFFFFFFu; k++) {
+                    const uint32_t sh = (s_mine + k) % kShards;
+                    uint32_t *cur = cursors + sh * kCursorStride;
+                    const uint32_t seen = __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint64_t)(seen + c0) * kShards + sh >= n_items) continue;  // looks empty: no atomic
+                    const uint64_t cand = (uint64_t)(atomicAdd(cur, 1u) + c0) * kShards + sh;
+                    if (cand < n_items) t = (uint32_t)cand;
+                }
+            }
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            if (t == 0xFFFFFFFFu) break;
+        }
+        int64_t i;
+        bool has, heavy = false;
+        if (listed) {
+            const uint64_t above = __ballot(lane < (uint32_t)kClasses && tab[0][lane & (kClasses - 1)] > t);
+            const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
+            const int cls = kClasses - 1 - (int)L;
+            const uint32_t off = t - (tab[0][L] - tab[1][L]);
+            const uint32_t n_cls = tab[2][L];
+            const uint32_t *list = D.cls_list + ((size_t)read_buf * kClasses + cls) * (size_t)D.n;
+            heavy = cls >= cls_heavy;
+            const uint32_t idx = heavy ? off : off * E + lane;
+            has = heavy ? lane == 0 : (lane < E && idx < n_cls);
+            i = has ? (int64_t)list[idx] : 0;
+        } else {
+            i = (int64_t)t * E + lane;
+            has = lane < E && i < D.n;
+        }
+        send_item<NS, TRACE>(D, lane, i, has, heavy, t, warm, warm_mi, actions, actions_f64);
+        t = listed ? n_items /* forces a claim */ : t + n_waves /* without lists the items are dealt statically */;
+    }
 }
 
 // ======================================================================================
@@ -1520,11 +1839,12 @@ __device__ __forceinline__ double select_metric(const double (&m)[PCC_N_METRICS]
     return __longlong_as_double((long long)bits);
 }
 
+// Returns the env's predicted packet count for the next monitor interval (< 0: nothing to report).
 template <int NS>
-__device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const Group g, int warm, uint32_t warm_mi,
-                                           int last_warm, float *obs_out, float *reward_out, uint8_t *done_out,
-                                           double *steps_out) {
-    if (warm && !D.resetting[i]) return;
+__device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const Group g, int warm, uint32_t warm_mi,
+                                            int last_warm, float *obs_out, float *reward_out, uint8_t *done_out,
+                                            double *steps_out) {
+    if (warm && !D.resetting[i]) return -1.0f;
     const bool lead = g.lane == 0;
     // profiling only: where a wavefront's retire time goes (lane 0's view), summed per workgroup
     const bool tl = D.timeline != nullptr && (threadIdx.x & (kWave - 1)) == 0;
@@ -1714,7 +2034,7 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
     }
     if (warm) {  // reset(): the two warm-up MIs are not recorded (ns:478-479)
         if (lead && last_warm) D.resetting[i] = 0;
-        return;
+        return -1.0f;
     }
 
     // ---- metrics, history, observation, reward: ns:416-438 with so:44-73
@@ -1804,9 +2124,6 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
         if (steps_out)
             for (int s = 0; s < NS; s++) steps_out[(i * NS + s) * PCC_STEP_COLS + PCC_COL_RUN_DUR] = new_run_dur;
         D.run_dur[i] = new_run_dur;
-        // prediction for the next MI's send kernel: packets ~ MI length x current rate (the next
-        // action moves the rate by at most a few percent)
-        D.heavy_flag[i] = (!D.use_cwnd && new_run_dur * rate_sum > D.heavy_predict) ? 1 : 0;  // the window path is lane-serial
         D.steps[i] = steps + 1;
         const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
         D.done[i] = done;
@@ -1814,110 +2131,36 @@ __device__ __forceinline__ void retire_env(const Dev &D, const int64_t i, const 
     }
     PCC_TL_STAMP(11)  // outputs
 #undef PCC_TL_STAMP
+    // prediction for the next MI's send half: packets ~ MI length x current rate (the next action
+    // moves the rate by at most a few percent)
+    return (float)(new_run_dur * rate_sum);
 }
 
 template <int NS>
-__global__ __launch_bounds__(kRetireBlock, 5) void retire_kernel(Dev D, int64_t slot0, int64_t slot_end, int warm,
-                                                              uint32_t warm_mi, int last_warm, float *obs_out,
-                                                              float *reward_out, uint8_t *done_out, double *steps_out) {
+__global__ __launch_bounds__(kRetireBlock, 5) void retire_kernel(Dev D, int fill_buf, int warm, uint32_t warm_mi,
+                                                              int last_warm, float *obs_out, float *reward_out,
+                                                              uint8_t *done_out, double *steps_out) {
     const uint32_t tid = threadIdx.x;
     Group g;
     g.lane = tid & (kGroup - 1);
     g.shift = (tid & (kWave - 1)) & ~(uint32_t)(kGroup - 1);
-    // slots [slot0, slot_end) of the send order: the envs one chunk's send launch transmitted for
-    const int64_t slot = slot0 + (int64_t)blockIdx.x * (kRetireBlock / kGroup) + (tid / kGroup);
-    if (slot >= slot_end) return;
-    const int64_t i = D.send_order ? (int64_t)D.send_order[slot] : slot;
-    retire_env<NS>(D, i, g, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out);
-}
-
-// ======================================================================================
-// step_kernel: one whole monitor interval per launch.  A workgroup of four wavefronts owns a block
-// of 64 envs: wavefront 0 sends for the light envs lane-per-env, wavefronts 1-3 share the envs predicted
-// heavy (send_wave), then all four retire envs, each wavefront 4 at a time.
-// Send times are tail-bound -- a few wavefronts carry envs with thousands of packets while most
-// finish early -- so a separate retire launch waits for the slowest wavefront of the whole chip
-// with most SIMDs idle.  Here a workgroup that is done sending publishes its block in a ready list
-// and then its wavefronts take retire items (4 envs of a ready block) off a global queue until none are left:
-// early finishers retire their own envs and then wait for the stragglers' blocks, whose retire work
-// is spread over all the waiting workgroups the moment they finish sending.  Which workgroup
-// retires an env never changes a result.
-//   steal[0]  blocks published so far (monotone over steps; base_ready = its value at launch)
-//   steal[1]  items claimed so far (monotone; every wavefront ends with exactly one failed claim)
-//   steal[2+k] the k-th block to finish this step, tagged with the step number
-// Waiting is only safe when every workgroup of the grid is resident: the host launches this kernel
-// only for grids the device holds at once (pcc_step falls back to send_kernel + retire_kernel).
-// ======================================================================================
-constexpr int kStepWaves = 4;
-constexpr uint32_t kStealSpinLimit = 1u << 20;  // x ~1 us: a bug must not hang the GPU
-
-template <int NS, bool TRACE>
-__global__ __launch_bounds__(kStepWaves * kWave, 4) void step_kernel(Dev D, uint32_t base_ready, uint32_t base_next,
-                                                                  uint32_t tag, const void *actions, int actions_f64,
-                                                                  float *obs_out, float *reward_out, uint8_t *done_out,
-                                                                  double *steps_out) {
-    const uint32_t tid = threadIdx.x;
-
-    if (D.timeline && tid == 2 * kWave) {  // the workgroup's exit stamp and item count are accumulated atomically below
-        uint64_t *w = D.timeline + (int64_t)2 * D.n * 8 + (int64_t)blockIdx.x * 16;
-        for (int x = 1; x < 16; x++) w[x] = 0;
-    }
-    send_wave<NS, TRACE>(D, blockIdx.x, tid, kStepWaves - 1u, 0, 0u, actions, actions_f64);  // wavefront 0 light, 1-3 heavy
-    // the records and cursors the send wavefronts wrote are read by whoever retires the block
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const int64_t i = (int64_t)blockIdx.x * (kRetireBlock / kGroup) + (tid / kGroup);
+    float pred = -1.0f;
+    if (i < D.n) pred = retire_env<NS>(D, i, g, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out);
+    if (fill_buf < 0) return;  // warm-up intervals do not file (kernel-uniform)
+    // ---- file the block's envs in the class lists of the next send (see "work lists"): ranks inside
+    // the block by LDS atomics, one global atomic per class the block holds
+    __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
+    if (tid < (uint32_t)kClasses) s_cnt[tid] = 0u;
     __syncthreads();
-    constexpr uint32_t kPerItem = kWave / kGroup;  // envs per retire item: one per 16-lane group of a wavefront
-    const uint32_t items_per_block = (D.send_envs_per_wave + kPerItem - 1) / kPerItem;
-    const uint32_t total_items = gridDim.x * items_per_block;
-    uint64_t tl_sent = 0;
-    if (tid == 0) {
-        const uint32_t pos = atomicAdd(&D.steal[0], 1u) - base_ready;
-        __hip_atomic_store(&D.steal[2 + pos], (tag << 16) | blockIdx.x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (D.timeline) tl_sent = wall_clock64();
-    }
-    // from here on the wavefronts are on their own: each claims items until none are left
-    const uint32_t lane = tid & (kWave - 1);
-    Group g;
-    g.lane = tid & (kGroup - 1);
-    g.shift = lane & ~(uint32_t)(kGroup - 1);
-    uint32_t n_items = 0;
-    for (;;) {
-        uint32_t t = 0, v = 0;
-        if (lane == 0) {
-            t = atomicAdd(&D.steal[1], 1u) - base_next;
-            if (t < total_items) {
-                const uint32_t k = t / items_per_block;
-                uint32_t spins = 0;
-                while (((v = __hip_atomic_load(&D.steal[2 + k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 16) != tag) {
-                    __builtin_amdgcn_s_sleep(32);
-                    if (++spins > kStealSpinLimit) break;
-                }
-                if ((v >> 16) != tag) {  // never expected: flag it instead of hanging
-                    D.flags[0] |= PCC_FLAG_INTERNAL;
-                    t = 0xFFFFFFFFu;
-                }
-            }
-        }
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-        if (t >= total_items) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const uint32_t b = v & 0xFFFFu;
-        const uint32_t in_block = (t % items_per_block) * kPerItem + lane / kGroup;
-        const int64_t slot = (int64_t)b * D.send_envs_per_wave + in_block;
-        if (in_block < D.send_envs_per_wave && slot < D.n) {
-            const int64_t i = D.send_order ? (int64_t)D.send_order[slot] : slot;
-            retire_env<NS>(D, i, g, 0, 0u, 0, obs_out, reward_out, done_out, steps_out);
-        }
-        n_items++;
-    }
-    if (D.timeline && lane == 0) {
-        // block-level words after the 2 x n_envs wavefront entries: sent/published, last exit, items retired here
-        uint64_t *w = D.timeline + (int64_t)2 * D.n * 8 + (int64_t)blockIdx.x * 16;
-        if (tid == 0) w[0] = tl_sent;
-        atomicMax(reinterpret_cast<unsigned long long *>(&w[1]), (unsigned long long)wall_clock64());
-        atomicAdd(reinterpret_cast<unsigned long long *>(&w[2]), (unsigned long long)n_items);
-    }
+    const bool files = g.lane == 0 && pred >= 0.0f;
+    const int cls = class_of(pred);
+    uint32_t rank = 0;
+    if (files) rank = atomicAdd(&s_cnt[cls], 1u);
+    __syncthreads();
+    if (tid < (uint32_t)kClasses && s_cnt[tid]) s_base[tid] = atomicAdd(&D.cls_count[fill_buf * kClsStride + tid], s_cnt[tid]);
+    __syncthreads();
+    if (files) D.cls_list[((size_t)fill_buf * kClasses + cls) * (size_t)D.n + s_base[cls] + rank] = (uint32_t)i;
 }
 
 // ======================================================================================
@@ -1959,7 +2202,6 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
     D.run_dur[i] = 3 * lat;   // ns:467
     D.steps[i] = 0;
     D.done[i] = 0;
-    D.heavy_flag[i] = 0;  // the warm-up MIs and the first step run in the light wave
     D.cwnd[i] = 25;       // ns:209, 227
     D.mi_draws[i] = 0; D.ep_draws[i] = 0;
 #pragma unroll
@@ -2016,21 +2258,14 @@ struct pcc_sim {
     bool lockstep;      // every env was last reset by the same full reset (host knows when `done` fires)
     uint32_t host_steps;
     bool send_pending;  // pcc_step_send issued, pcc_step_retire not yet
-    bool counted;       // in g_handles_on_device
-    bool fused_always;  // ... even for grids that fill less than half of the device (tests)
-    bool fused_step;    // pcc_step runs step_kernel (send + work-stealing retire in one launch) when the grid fits
-    int fused_capacity; // workgroups of step_kernel the device holds at once
-    int fused_capacity_key;
-    uint32_t steal_ready_base, steal_next_base;  // values the two queue counters start a step with
-    uint32_t steal_tag;                          // step number, tags the ready list entries
+    int read_buf;       // work-list buffer the next send launch reads (-1: none valid, items in index order)
+    int fill_buf;       // ... the next retire launch files into
+    int cu_count;       // compute units of the device
+    void *list_blob;    // the class lists (Dev::cls_list)
+    size_t list_bytes;
 };
 
 namespace {
-
-// handles alive per device: the one-launch step needs the device to itself (two such grids on
-// different streams could each hold part of the CUs and wait for workgroups that cannot start)
-constexpr int kMaxDevices = 64;
-std::atomic<int> g_handles_on_device[kMaxDevices];
 
 struct DeviceGuard {
     int prev = -1;
@@ -2063,8 +2298,9 @@ size_t carve_state(Dev &d, char *base) {
     d.maxq = c.take<double>(n); d.ebw = c.take<double>(n); d.q = c.take<double>(n);
     d.tu = c.take<double>(n); d.now = c.take<double>(n); d.run_dur = c.take<double>(n);
     d.steps = c.take<uint32_t>(n); d.episode = c.take<uint32_t>(n); d.flags = c.take<uint32_t>(n);
-    d.steal = c.take<uint32_t>(n + 2);
-    d.done = c.take<uint8_t>(n); d.resetting = c.take<uint8_t>(n); d.heavy_flag = c.take<uint8_t>(n);
+    d.cls_count = c.take<uint32_t>(2 * kClsStride);
+    d.cursors = c.take<uint32_t>(3 * 16 * 32);
+    d.done = c.take<uint8_t>(n); d.resetting = c.take<uint8_t>(n);
     d.total_sent = c.take<unsigned long long>(n);
     d.rate = c.take<double>(sn); d.rate0 = c.take<double>(sn); d.next_send = c.take<double>(sn);
     d.min_lat = c.take<double>(sn); d.ep_return = c.take<double>(sn); d.last_return = c.take<double>(sn);
@@ -2085,85 +2321,52 @@ int check_hip(hipError_t err, const char *what) {
 }
 
 dim3 lane_grid(const Dev &d) { return dim3((unsigned)((d.n + kWave - 1) / kWave)); }
-// SEND half of one monitor interval for the env blocks [block0, block0 + n_blocks) of
-// send_envs_per_wave envs each: all envs (warm = 0) or the envs being reset (warm = 1)
-int launch_send_blocks(pcc_sim_t *sim, uint32_t block0, uint32_t n_blocks, int warm, uint32_t warm_mi,
-                       const void *actions, int actions_f64, hipStream_t st) {
+
+// SEND half of one monitor interval: all envs (warm = 0) or the envs being reset (warm = 1).
+// Persistent single-wavefront workgroups, send_waves per compute unit, take work items off the class
+// lists the last retire launch filed (sim->read_buf) -- or the envs in index order when there are none.
+int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, const void *actions, int actions_f64, hipStream_t st) {
     const Dev &d = sim->d;
     const bool tr = d.rng_mode == PCC_RNG_TRACE;
-    const dim3 sgrid(n_blocks), sblock(d.send_waves * kWave);
+    const int read_buf = warm ? -1 : sim->read_buf;
+    // items <= chunks + heavy envs <= about n; more wavefronts than items would only take a failed claim each
+    int64_t waves = (int64_t)sim->cu_count * d.send_waves;
+    const int64_t chunks = (d.n + d.send_envs_per_wave - 1) / d.send_envs_per_wave;
+    const int64_t most = read_buf < 0 ? chunks : d.n;
+    if (waves > most) waves = most;
+    const int64_t unit = (int64_t)kShards * d.send_wg_waves;  // whole workgroups, a multiple of kShards wavefronts
+    waves = (waves + unit - 1) / unit * unit;
+    const dim3 sgrid((unsigned)(waves / d.send_wg_waves)), sblock(kWave * d.send_wg_waves);
     if (d.ns == 1) {
-        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<1, false>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
+        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<1, false>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, actions, actions_f64);
     } else {
-        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<2, false>), sgrid, sblock, 0, st, d, block0, warm, warm_mi, actions, actions_f64);
+        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<2, false>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, actions, actions_f64);
     }
     return check_hip(hipGetLastError(), "send kernel launch");
 }
 
-// RETIRE half for the send-order slots [slot0, slot_end)
-int launch_retire_slots(pcc_sim_t *sim, int64_t slot0, int64_t slot_end, int warm, uint32_t warm_mi, int last_warm,
-                        float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
-    const Dev &d = sim->d;
-    const int64_t per_block = kRetireBlock / kGroup;
-    const dim3 grid((unsigned)((slot_end - slot0 + per_block - 1) / per_block));
-    if (d.ns == 1)
-        hipLaunchKernelGGL(retire_kernel<1>, grid, dim3(kRetireBlock), 0, st, d, slot0, slot_end, warm, warm_mi,
-                           last_warm, obs_out, reward_out, done_out, steps_out);
-    else
-        hipLaunchKernelGGL(retire_kernel<2>, grid, dim3(kRetireBlock), 0, st, d, slot0, slot_end, warm, warm_mi,
-                           last_warm, obs_out, reward_out, done_out, steps_out);
-    return check_hip(hipGetLastError(), "retire kernel launch");
-}
-
-uint32_t send_blocks(const Dev &d) { return (uint32_t)((d.n + d.send_envs_per_wave - 1) / d.send_envs_per_wave); }
-
-int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, const void *actions, int actions_f64, hipStream_t st) {
-    return launch_send_blocks(sim, 0, send_blocks(sim->d), warm, warm_mi, actions, actions_f64, st);
-}
-
+// RETIRE half; a launch that is not a warm-up interval also files every env in the work lists of the
+// next send (buffer sim->fill_buf, cleared by the send launch before it)
 int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, float *obs_out, float *reward_out,
                   uint8_t *done_out, double *steps_out, hipStream_t st) {
-    return launch_retire_slots(sim, 0, sim->d.n, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out, st);
-}
-
-// one whole MI in one launch (step_kernel); only for grids the device holds at once
-int launch_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_out, float *reward_out,
-                uint8_t *done_out, double *steps_out, hipStream_t st) {
     const Dev &d = sim->d;
-    const bool tr = d.rng_mode == PCC_RNG_TRACE;
-    const uint32_t blocks = send_blocks(d);
-    const dim3 grid(blocks), block(kStepWaves * kWave);
-    const uint32_t br = sim->steal_ready_base, bn = sim->steal_next_base, tag = sim->steal_tag & 0xFFFFu;
-    if (d.ns == 1) {
-        if (tr) hipLaunchKernelGGL((step_kernel<1, true>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
-        else hipLaunchKernelGGL((step_kernel<1, false>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
-    } else {
-        if (tr) hipLaunchKernelGGL((step_kernel<2, true>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
-        else hipLaunchKernelGGL((step_kernel<2, false>), grid, block, 0, st, d, br, bn, tag, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
+    const int64_t per_block = kRetireBlock / kGroup;
+    const dim3 grid((unsigned)((d.n + per_block - 1) / per_block));
+    const int fill = warm ? -1 : sim->fill_buf;
+    if (d.ns == 1)
+        hipLaunchKernelGGL(retire_kernel<1>, grid, dim3(kRetireBlock), 0, st, d, fill, warm, warm_mi, last_warm, obs_out,
+                           reward_out, done_out, steps_out);
+    else
+        hipLaunchKernelGGL(retire_kernel<2>, grid, dim3(kRetireBlock), 0, st, d, fill, warm, warm_mi, last_warm, obs_out,
+                           reward_out, done_out, steps_out);
+    const int rc = check_hip(hipGetLastError(), "retire kernel launch");
+    if (rc == PCC_OK && !warm) {
+        sim->read_buf = sim->fill_buf;
+        sim->fill_buf ^= 1;
     }
-    const uint32_t per_item = kWave / kGroup;
-    const uint32_t items = blocks * ((d.send_envs_per_wave + per_item - 1) / per_item);
-    sim->steal_ready_base += blocks;
-    sim->steal_next_base += items + blocks * kStepWaves;  // every wavefront ends with exactly one failed claim
-    sim->steal_tag++;
-    return check_hip(hipGetLastError(), "step kernel launch");
-}
-
-// workgroups of step_kernel resident at once on this device, for the handle's instantiation
-int step_capacity(pcc_sim_t *sim) {
-    const Dev &d = sim->d;
-    const bool tr = d.rng_mode == PCC_RNG_TRACE;
-    int per_cu = 0;
-    hipError_t e;
-    if (d.ns == 1) e = tr ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<1, true>, kStepWaves * kWave, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<1, false>, kStepWaves * kWave, 0);
-    else e = tr ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<2, true>, kStepWaves * kWave, 0)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<2, false>, kStepWaves * kWave, 0);
-    hipDeviceProp_t prop;
-    if (e != hipSuccess || hipGetDeviceProperties(&prop, sim->device) != hipSuccess) return 0;
-    return per_cu * prop.multiProcessorCount;
+    return rc;
 }
 
 int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, const void *actions, int actions_f64,
@@ -2239,20 +2442,14 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.key0 = (uint32_t)seed; d.key1 = (uint32_t)(seed >> 32); d.gid_base = env_gid_base;
     d.delta_scale = 0.025;  // src/common/config.py:17
     d.max_steps = 400;      // ns:41
-    d.heavy_packets = 1e18;  // standing classification off: the tail take-over alone measured best
     d.round_packets = 256;
     d.takeover_lanes = 1;  // measured with three heavy wavefronts per block: 1 -> 0.487, 2 -> 0.516, 3 -> 0.595 ms/step
-    d.help_lanes = 16;
-    d.send_waves = 4;
+    d.send_waves = 16;  // persistent send wavefronts per compute unit (4 per SIMD at <= 128 VGPRs)
     d.send_envs_per_wave = 64;
-    d.heavy_predict = 3072.0;
-    // two launches measure a little faster and steadier than the one-launch step since the retire
-    // half runs at 5 waves/SIMD on its own (0.56 vs 0.58 ms at 65 536 envs): opt-in
-    sim->fused_step = getenv("PCC_FUSED_STEP") && atoi(getenv("PCC_FUSED_STEP")) != 0;
-    sim->steal_tag = 1;  // the zero-initialised ready list must not look published
-    sim->fused_capacity_key = -1;
+    d.heavy_predict = 1024.0;
+    d.send_wg_waves = getenv("PCC_SEND_WG_WAVES") ? (uint32_t)atoi(getenv("PCC_SEND_WG_WAVES")) : 4u;
+    if (d.send_wg_waves < 1u || d.send_wg_waves > 4u) d.send_wg_waves = 4u;
     d.debug_skip = getenv("PCC_DEBUG_SKIP") ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;
-    d.heavy_rho = 0.45;
     const double lo[5] = {100, 0.05, 0, 0.0, 0.3}, hi[5] = {500, 0.5, 8, 0.05, 1.5};  // ns:355-358,466
     memcpy(d.lo, lo, sizeof lo); memcpy(d.hi, hi, sizeof hi);
     d.rng_mode = PCC_RNG_PHILOX;
@@ -2323,9 +2520,19 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
             return fail(PCC_ENOMEM, "hipMalloc for the debug timeline failed");
         }
         d.timeline = static_cast<uint64_t *>(sim->timeline_blob);
+        d.pass_stats = reinterpret_cast<unsigned long long *>(d.timeline + (size_t)n_envs * 24);  // past everything the timeline uses
+        d.pass_counters = atoi(getenv("PCC_DEBUG_TIMELINE")) >= 2;
     }
-    if (device < kMaxDevices) g_handles_on_device[device].fetch_add(1);
-    sim->counted = true;
+    // the send half's work lists: two buffers of kClasses lists, each able to hold every env
+    sim->list_bytes = (size_t)2 * kClasses * (size_t)n_envs * sizeof(uint32_t);
+    if (hipMalloc(&sim->list_blob, sim->list_bytes) != hipSuccess) {
+        pcc_destroy(sim);
+        return fail(PCC_ENOMEM, "hipMalloc(%zu) for the send work lists failed", sim->list_bytes);
+    }
+    d.cls_list = static_cast<uint32_t *>(sim->list_blob);
+    sim->read_buf = -1;
+    sim->fill_buf = 0;
+    sim->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = sim;
     return PCC_OK;
 }
@@ -2333,24 +2540,38 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
 int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words) {
     if (!sim || !sim->timeline_blob) return 0;
     DeviceGuard guard(sim->device);
-    const int64_t blocks = send_blocks(sim->d);
-    const int64_t total = blocks * 2 * 8 + blocks * 16;
+    unsigned long long items = 0;
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(&items, sim->d.pass_stats + 15, sizeof items, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(PCC_EHIP, "reading the debug timeline failed");
+    const int64_t rblocks = (sim->d.n + kRetireBlock / kGroup - 1) / (kRetireBlock / kGroup);
+    const int64_t total = (int64_t)items * 8 + rblocks * 16;
     if (!out || n_words <= 0) return total;
     if (n_words < total) return fail(PCC_EINVAL, "pcc_debug_timeline needs room for %lld words", (long long)total);
     const char *src = static_cast<const char *>(sim->timeline_blob);
-    if (hipDeviceSynchronize() != hipSuccess ||
-        hipMemcpy(out, src, (size_t)blocks * 2 * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(out + blocks * 2 * 8, src + (size_t)sim->d.n * 2 * 8 * sizeof(uint64_t),
-                  (size_t)blocks * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipMemcpy(out, src, (size_t)items * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(out + items * 8, src + (size_t)sim->d.n * 2 * 8 * sizeof(uint64_t), (size_t)rblocks * 16 * sizeof(uint64_t),
+                  hipMemcpyDeviceToHost) != hipSuccess)
         return fail(PCC_EHIP, "reading the debug timeline failed");
     return total;
 }
 
+int pcc_debug_pass_stats(pcc_sim_t *sim, uint64_t *out16, int reset) {
+    if (!sim || !out16) return fail(PCC_EINVAL, "NULL argument");
+    if (!sim->d.pass_stats) return fail(PCC_ESTATE, "pass statistics are off (create the handle with PCC_DEBUG_TIMELINE=1)");
+    DeviceGuard guard(sim->device);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(out16, sim->d.pass_stats, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        (reset && hipMemset(sim->d.pass_stats, 0, 16 * sizeof(uint64_t)) != hipSuccess))
+        return fail(PCC_EHIP, "reading the pass statistics failed");
+    return PCC_OK;
+}
+
 void pcc_destroy(pcc_sim_t *sim) {
     if (!sim) return;
-    if (sim->counted && sim->device < kMaxDevices) g_handles_on_device[sim->device].fetch_sub(1);
     DeviceGuard guard(sim->device);
     if (sim->timeline_blob) (void)hipFree(sim->timeline_blob);
+    if (sim->list_blob) (void)hipFree(sim->list_blob);
 
     if (sim->state_blob) (void)hipFree(sim->state_blob);
     for (int c = 0; c < kMaxTiers; c++) {
@@ -2360,7 +2581,7 @@ void pcc_destroy(pcc_sim_t *sim) {
     delete sim;
 }
 
-int64_t pcc_device_bytes(const pcc_sim_t *sim) { return sim ? (int64_t)(sim->state_bytes + sim->ring_bytes) : 0; }
+int64_t pcc_device_bytes(const pcc_sim_t *sim) { return sim ? (int64_t)(sim->state_bytes + sim->ring_bytes + sim->list_bytes) : 0; }
 
 int pcc_set_link_params(pcc_sim_t *sim, const double *bw, const double *dl, const double *queue, const double *loss,
                         const double *rate0) {
@@ -2394,12 +2615,6 @@ int pcc_set_rng(pcc_sim_t *sim, int mode, const double *trace, int64_t trace_str
     return fail(PCC_EINVAL, "unknown rng mode %d", mode);
 }
 
-int pcc_set_send_order(pcc_sim_t *sim, const uint32_t *order) {
-    if (!sim) return fail(PCC_EINVAL, "sim is NULL");
-    sim->d.send_order = order;
-    return PCC_OK;
-}
-
 int pcc_set_seed(pcc_sim_t *sim, uint64_t seed) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     sim->d.key0 = (uint32_t)seed;
@@ -2410,8 +2625,6 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed) {
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     switch (key) {
-        case PCC_TUNE_HEAVY_PACKETS: sim->d.heavy_packets = value; return PCC_OK;
-        case PCC_TUNE_HEAVY_RHO: sim->d.heavy_rho = value; return PCC_OK;
         case PCC_TUNE_ROUND_PACKETS:
             if (value < 4 || value > 1048576) return fail(PCC_EINVAL, "round_packets out of range");
             sim->d.round_packets = ((uint32_t)value + 3u) & ~3u;
@@ -2421,14 +2634,9 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             sim->d.send_envs_per_wave = (uint32_t)value;
             return PCC_OK;
         case PCC_TUNE_HEAVY_PREDICT: sim->d.heavy_predict = value; return PCC_OK;
-        case PCC_TUNE_FUSED_STEP: sim->fused_step = value != 0.0; sim->fused_always = value == 2.0; return PCC_OK;
         case PCC_TUNE_SEND_WAVES:
-            if (!(value >= 2.0 && value <= (double)kMaxSendWaves)) return fail(PCC_EINVAL, "send_waves out of range");
+            if (!(value >= 1.0 && value <= 32.0)) return fail(PCC_EINVAL, "send_waves out of range");
             sim->d.send_waves = (uint32_t)value;
-            return PCC_OK;
-        case PCC_TUNE_HELP_LANES:
-            if (!(value >= 0.0 && value <= 64.0)) return fail(PCC_EINVAL, "help_lanes out of range");
-            sim->d.help_lanes = (uint32_t)value;
             return PCC_OK;
         case PCC_TUNE_TAKEOVER_LANES:
             if (value < 0 || value > 64) return fail(PCC_EINVAL, "takeover_lanes out of range");
@@ -2469,6 +2677,7 @@ int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream)
         sim->ever_reset = true;
         sim->lockstep = true;
         sim->host_steps = 0;
+        sim->read_buf = -1;  // the filed predictions describe the links that were just replaced
     } else {
         sim->lockstep = false;  // some envs are now at a different step count
     }
@@ -2525,28 +2734,8 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_step between pcc_step_send and pcc_step_retire");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    bool fused = sim->fused_step;
-    if (fused) {
-        // the occupancy answer depends on the kernel instantiation (senders, rng mode)
-        const int key = sim->d.ns * 2 + (sim->d.rng_mode == PCC_RNG_TRACE ? 1 : 0);
-        if (sim->fused_capacity_key != key) {
-            sim->fused_capacity = step_capacity(sim);
-            sim->fused_capacity_key = key;
-        }
-        // small grids leave most of the chip empty: two launches spread the retire work over all
-        // CUs, the fused step would retire a block's 64 envs with only its own four wavefronts
-        const int64_t blocks = send_blocks(sim->d);
-        fused = blocks <= sim->fused_capacity && blocks <= 0xFFFF && (sim->fused_always || 2 * blocks >= sim->fused_capacity);
-        // another handle on this device may be stepping on another stream at the same time
-        if (sim->device < kMaxDevices && g_handles_on_device[sim->device].load() > 1 && !sim->fused_always) fused = false;
-    }
-    int rc;
-    if (fused) {
-        rc = launch_step(sim, actions, actions_f64, obs_out, reward_out, done_out, steps_out, st);
-    } else {
-        rc = launch_send(sim, 0, 0, actions, actions_f64, st);
-        if (rc == PCC_OK) rc = launch_retire(sim, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
-    }
+    int rc = launch_send(sim, 0, 0, actions, actions_f64, st);
+    if (rc == PCC_OK) rc = launch_retire(sim, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
     return after_mi(sim, obs_out, auto_reset, st);
 }

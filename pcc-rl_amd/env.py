@@ -54,7 +54,7 @@ class BatchedNetworkEnv(object):
 
     def __init__(self, n_envs, device="cuda", history_len=None, features=None, seed=0, n_senders=1,
                  link_params=None, env_gid_base=0, ring_capacity=0, auto_reset=True, delta_scale=None,
-                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False, balance_every=0, use_cwnd=False):
+                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False, use_cwnd=False):
         if history_len is None:
             history_len = arg_or_default("--history-len", default=10)
         if features is None:
@@ -102,12 +102,6 @@ class BatchedNetworkEnv(object):
         self._params = None
         self._trace = None
         self._was_reset = False
-        # optional send-kernel load balancing: every `balance_every` steps the envs are re-dealt over
-        # the wavefronts by predicted packets (0 = never, the default: on the benchmark workload it
-        # shortens late-episode steps and lengthens early ones, a wash; needs n_envs % 64 == 0)
-        self.balance_every = int(balance_every) if self.n_envs % 64 == 0 and self.n_envs >= 128 else 0
-        self._order = None
-        self._since_balance = 0
         self._t = 0
         if link_params is not None:
             self.set_link_params(*(link_params.values() if isinstance(link_params, dict) else link_params))
@@ -169,27 +163,13 @@ class BatchedNetworkEnv(object):
         check(self._L.pcc_set_rng(self._h, native.PCC_RNG_TRACE, _ptr(t), t.shape[1]))
         self._trace = t
 
-    def set_tuning(self, heavy_packets=None, heavy_rho=None, round_packets=None, takeover_lanes=None,
-                   send_envs_per_wave=None, heavy_predict=None, fused_step=None, help_lanes=None, send_waves=None):
-        """Performance knobs of the step kernels (results do not depend on them)."""
-        if fused_step is not None:
-            check(self._L.pcc_set_tuning(self._h, 6, float(fused_step)))
-        if help_lanes is not None:
-            check(self._L.pcc_set_tuning(self._h, 7, float(help_lanes)))
-        if send_waves is not None:
-            check(self._L.pcc_set_tuning(self._h, 8, float(send_waves)))
-        if heavy_predict is not None:
-            check(self._L.pcc_set_tuning(self._h, 5, float(heavy_predict)))
-        if send_envs_per_wave is not None:
-            check(self._L.pcc_set_tuning(self._h, 4, float(send_envs_per_wave)))
-        if round_packets is not None:
-            check(self._L.pcc_set_tuning(self._h, 2, float(round_packets)))
-        if takeover_lanes is not None:
-            check(self._L.pcc_set_tuning(self._h, 3, float(takeover_lanes)))
-        if heavy_packets is not None:
-            check(self._L.pcc_set_tuning(self._h, 0, float(heavy_packets)))
-        if heavy_rho is not None:
-            check(self._L.pcc_set_tuning(self._h, 1, float(heavy_rho)))
+    def set_tuning(self, round_packets=None, takeover_lanes=None, send_envs_per_wave=None, heavy_predict=None,
+                   send_waves=None):
+        """Performance knobs of the send half (results do not depend on them); see pcc_set_tuning."""
+        for key, value in ((2, round_packets), (3, takeover_lanes), (4, send_envs_per_wave), (5, heavy_predict),
+                           (8, send_waves)):
+            if value is not None:
+                check(self._L.pcc_set_tuning(self._h, key, float(value)))
 
     def seed(self, seed=None):
         if seed is not None:
@@ -213,7 +193,6 @@ class BatchedNetworkEnv(object):
                 raise ValueError("mask must be [n_envs]")
         check(self._L.pcc_reset(self._h, _ptr(m), _ptr(self._obs), self._stream()))
         self._was_reset = True
-        self._since_balance = self.balance_every  # re-deal at the next step: the links are new
         if mask is None:
             self._t = 0
         return self._out(self._obs)
@@ -230,24 +209,8 @@ class BatchedNetworkEnv(object):
                              % (a.numel(), width, self.n_envs * width))
         return a.reshape(self.n_envs, width).contiguous()
 
-    def rebalance(self):
-        """Deal the envs over the send kernel's wavefronts by predicted packets in the next interval
-        (run_dur * rate, summed over senders): rank r goes to wavefront r % n_waves, so every
-        wavefront gets the same share of heavy envs.  A performance hint only."""
-        pred = self.state("run_dur") * self.state("rate").sum(0)
-        ranks = torch.argsort(pred, descending=True)
-        n_waves = self.n_envs // 64
-        r = torch.arange(self.n_envs, device=self.device)
-        slot = (r % n_waves) * 64 + r // n_waves
-        order = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
-        order[slot] = ranks.to(torch.int32)
-        check(self._L.pcc_set_send_order(self._h, _ptr(order)))
-        self._order = order     # keep alive: the library reads it at every step
-        self._since_balance = 0
-
     def step_send(self, actions):
         """First half of step(): apply the actions and transmit the coming monitor interval's packets."""
-        self._balance_tick()
         a = self._actions(actions)
         check(self._L.pcc_step_send(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, self._stream()))
 
@@ -257,16 +220,8 @@ class BatchedNetworkEnv(object):
                                       _ptr(self._steps), 1 if self.auto_reset else 0, self._stream()))
         return self._step_result()
 
-    def _balance_tick(self):
-        if self.balance_every:
-            self._since_balance += 1
-            if self._since_balance >= self.balance_every:
-                self.rebalance()
-
     def _step_result(self):
         self._t += 1
-        if self.auto_reset and self._t % self.max_steps == 0:
-            self._since_balance = self.balance_every  # the envs were just reset: re-deal at the next step
         info = {}
         if self._steps is not None:
             info["steps"] = self._out(self._steps)
@@ -274,8 +229,7 @@ class BatchedNetworkEnv(object):
 
     def step(self, actions):
         """One monitor interval for every env (ns:407-446 batched): obs, reward, done, info.  One
-        library call (pcc_step: by default one fused send + retire launch)."""
-        self._balance_tick()
+        library call (pcc_step: two launches, the send half and the retire half)."""
         a = self._actions(actions)
         check(self._L.pcc_step(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, _ptr(self._obs),
                                _ptr(self._reward), _ptr(self._done), _ptr(self._steps),
@@ -303,8 +257,6 @@ class BatchedNetworkEnv(object):
         if bad:
             over = int(((flags & native.PCC_FLAG_RING_OVERFLOW) != 0).sum().item())
             tr = int(((flags & native.PCC_FLAG_TRACE_OVERRUN) != 0).sum().item())
-            if int(((flags & native.PCC_FLAG_INTERNAL) != 0).sum().item()):
-                raise PccError(-6, "internal error: the fused step's retire queue timed out")
             pool = int(((flags & native.PCC_FLAG_POOL_EXHAUSTED) != 0).sum().item())
             raise PccError(-6, "%d envs overflowed the in-flight ring, %d ran past the loss trace, %d found the "
                                "ring pools empty (PCC_RING_POOLS)" % (over, tr, pool))
@@ -314,15 +266,27 @@ class BatchedNetworkEnv(object):
         return int(self._L.pcc_device_bytes(self._h))
 
     def debug_timeline(self):
-        """[send wavefronts, 8] uint64 of the last send launch (PCC_DEBUG_TIMELINE=1 at creation;
-        see pcc_debug_timeline in include/pcc_sim.h), or None when the timeline is off."""
+        """[send work items (8 words each) ..., retire workgroups (2 rows of 8 each)] uint64 of the last
+        step (PCC_DEBUG_TIMELINE=1 at creation; see pcc_debug_timeline in include/pcc_sim.h), or None
+        when the timeline is off."""
         import numpy as np
         n = int(self._L.pcc_debug_timeline(self._h, None, 0))
         if n <= 0:
             return None
         out = np.zeros(n, dtype=np.uint64)
         got = int(self._L.pcc_debug_timeline(self._h, out.ctypes.data, n))
-        return out[:got].reshape(-1, 8)   # 2 rows per env block (wavefronts), then 2 rows (16 words) per workgroup
+        return out[:got].reshape(-1, 8)
+
+    PASS_STAT_NAMES = ("pass_empty", "pass_scan", "pass_free", "pass_serial", "pk_empty", "pk_scan", "pk_free",
+                       "pk_serial", "scan_nothing_committed", "refused_time", "refused_queue", "envs_heavy_wave",
+                       "envs_taken_over", "cycles_committed", "cycles_serial", "items")
+
+    def debug_pass_stats(self, reset=True):
+        """Counters of the send half's wave passes (PCC_DEBUG_TIMELINE=1 at creation), as a dict."""
+        import numpy as np
+        out = np.zeros(16, dtype=np.uint64)
+        check(self._L.pcc_debug_pass_stats(self._h, out.ctypes.data, 1 if reset else 0))
+        return dict(zip(self.PASS_STAT_NAMES, [int(v) for v in out]))
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

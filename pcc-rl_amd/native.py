@@ -29,9 +29,9 @@ FIELDS = {
 
 # every symbol include/pcc_sim.h declares
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
-           "pcc_set_rng", "pcc_set_seed", "pcc_set_send_order", "pcc_set_tuning", "pcc_set_cwnd_mode", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
+           "pcc_set_rng", "pcc_set_seed", "pcc_set_tuning", "pcc_set_cwnd_mode", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
            "pcc_step_retire",
-           "pcc_get_state", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline"]
+           "pcc_get_state", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline", "pcc_debug_pass_stats"]
 
 
 class PccError(RuntimeError):
@@ -66,8 +66,6 @@ def lib():
     L.pcc_set_param_ranges.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     L.pcc_set_rng.argtypes = [vp, i32, vp, i64]
     L.pcc_set_seed.argtypes = [vp, u64]
-    L.pcc_set_send_order.argtypes = [vp, vp]
-    L.pcc_set_send_order.restype = i32
     L.pcc_set_tuning.argtypes = [vp, i32, dbl]
     L.pcc_set_tuning.restype = i32
     L.pcc_set_cwnd_mode.argtypes = [vp, i32]
@@ -84,6 +82,8 @@ def lib():
     L.pcc_device_bytes.argtypes = [vp]
     L.pcc_debug_timeline.restype = i64
     L.pcc_debug_timeline.argtypes = [vp, vp, i64]
+    L.pcc_debug_pass_stats.restype = i32
+    L.pcc_debug_pass_stats.argtypes = [vp, vp, i32]
     for fn in ("pcc_create", "pcc_set_link_params", "pcc_set_param_ranges", "pcc_set_rng", "pcc_set_seed",
                "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
                "pcc_step_retire", "pcc_get_state", "pcc_metric_info"):

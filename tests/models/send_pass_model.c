@@ -83,8 +83,12 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
     while (s->t < end) {
         const double t0 = s->t;
         const double t1s = t0 + gap, G = t1s - t0, t2s = t1s + gap;
+        /* positions whose send time leaves the binade of t0 are not part of the pass (their t0 + k G would
+         * not be exact); lim = min(end, top of the binade) */
+        const double ttop = ldexp(1.0, (int)exp_bits(t0) - 1022);
+        const double lim = end < ttop ? end : ttop;
         const double tend = t0 + (double)PASS * G;
-        const int ok_t = (t2s - t1s == G) && (G > 0.0) && (t0 >= 2.0 * PASS * gap) && (exp_bits(t0) == exp_bits(tend));
+        const int ok_t = (t2s - t1s == G) && (G > 0.0) && (t0 >= (PASS + 4.0) * gap) && (exp_bits(t0) == exp_bits(t2s));
         const uint32_t skip = s->sent & 3u;   /* packets of lane 0's Philox block that are already sent */
         int regime = 0;                        /* 0 = serial, 1 = A, 2 = B */
         int why = 0;
@@ -101,7 +105,7 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
             else {
                 e = exp_bits(s->q);
                 const uint32_t eb = exp_bits(ebw);
-                int ok = (s->q > 0.0) && e > 64 && e < 1100 && (s->tu >= maxq) && (s->tu + s->tu >= tend) && (x0 > 0.0) && (eb <= e) &&
+                int ok = (s->q > 0.0) && e > 64 && e < 1100 && (s->tu + s->tu >= tend) && (x0 > 0.0) && (eb <= e) &&
                          exp_bits(s->tu) >= e && exp_bits(maxq) >= e;
                 if (!ok) why = 2;
                 if (ok) {
@@ -128,6 +132,9 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
                         Mi = free_mode ? 0 : (int64_t)(maxq * inv_u);
                         if (tie && ((Q0i | D0i | Gi) & 1)) { ok = 0; why = 4; }
                         maxq_above = exp_bits(maxq) > e;
+                        /* the first packet would already take q out of the binade: no point in trying */
+                        const uint32_t es0 = exp_bits(x0 + R);
+                        if (ok && (es0 < e || (es0 > e && maxq_above))) { ok = 0; why = 6; }
                     }
                 }
                 if (ok) regime = 2;
@@ -141,7 +148,7 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
             for (uint32_t p = skip; p < PASS; p++) {
                 const uint32_t k = p - skip;
                 const double tk = t0 + (double)k * G;
-                if (!(tk < end)) break;
+                if (!(tk < lim)) break;
                 const int rnd = loss[s->sent + k];
                 rec_t r;
                 r.lat = dl + 0.0;
@@ -150,7 +157,7 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
                 n++;
             }
             if (any) { s->q = ebw + 0.0; s->tu = last_t; }
-            s->t = t0 + (double)n * G;
+            if (n) s->t = (t0 + (double)(n - 1) * G) + gap;
             s->sent += n;
             st->pass_a++; st->pk_a += n;
             serial_len = 8;
@@ -166,7 +173,7 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
             for (uint32_t p = 0; p < PASS; p++) {
                 const int32_t k = (int32_t)p - (int32_t)skip;
                 const double tk = t0 + (double)(k < 0 ? 0 : k) * G;
-                ex_k[p] = k >= 0 && tk < end;
+                ex_k[p] = k >= 0 && tk < lim;
                 m_k[p] = ex_k[p] && !loss[s->sent + (k < 0 ? 0 : k)];
             }
             /* phase 1 (overdriven only), per lane: tokens at the lane's first packet by one division
@@ -268,7 +275,7 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
             }
             if (ncommit) {
                 if (any) { s->q = last_q; s->tu = last_t; }
-                s->t = t0 + (double)ncommit * G;
+                s->t = (t0 + (double)(ncommit - 1) * G) + gap;
                 s->sent += ncommit;
                 st->pass_b++; st->pk_b += ncommit;
                 serial_len = 8;

@@ -148,24 +148,26 @@ def test_auto_reset_and_second_episode_match_oracle():
     assert np.array_equal(steps[:, :25], ref1["steps"])
     # after the auto-reset the observation row is the fresh-episode observation
     assert np.array_equal(obs[:, 24], ref1["obs0"].astype(np.float32))
-    ref2 = oracle.run_batch(np.concatenate([acts[:, 25:], acts[:, 25:]], 0)[:n_envs], rng_mode=oracle.RNG_PHILOX,
-                            seed=seed, n_episodes=2)
-    # episode index 1 of the same envs (run_batch returns the last episode)
+    # episode index 1 of the same envs (run_batch returns the last episode; with Philox uniforms an
+    # episode depends on its index and its actions only): every column and the observations
     ref2 = oracle.run_batch(acts[:, 25:], rng_mode=oracle.RNG_PHILOX, seed=seed, n_episodes=2)
     assert np.array_equal(steps[:, 25:, :3], ref2["steps"][..., :3])
+    assert np.array_equal(steps[:, 25:], ref2["steps"])
+    assert np.array_equal(obs[:, 25:49], ref2["obs"][:, :24].astype(np.float32))
     ret = env.episode_returns().cpu().numpy()
     assert np.allclose(ret, ref2["steps"][..., 6].sum(1), rtol=1e-12)
     env.close()
 
 
-@pytest.mark.parametrize("fused", [0, 1])
-def test_conservation_and_queue_bounds_at_full_size(fused):
+@pytest.mark.parametrize("knobs", [dict(), dict(heavy_predict=128.0, takeover_lanes=4)])
+def test_conservation_and_queue_bounds_at_full_size(knobs):
     """Size-independent properties at BASELINE's 65 536 envs: every packet sent is acked, lost
-    or still in flight; the queue never exceeds its limit; clocks only move forward.  Both as two
-    launches (the default) and as the one-launch step, which at this size fills the device."""
+    or still in flight; the queue never exceeds its limit; clocks only move forward.  And the
+    first 512 envs of the full batch -- wherever the work lists put them -- against the oracle,
+    bit for bit."""
     N = 65536
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=DEV, seed=0, record_steps=True, auto_reset=False)
-    env.set_tuning(fused_step=fused)
+    env.set_tuning(**knobs)
     env.reset()
     gen = torch.Generator(device=DEV).manual_seed(0)
     sent0 = (env.state("acc_tail") + env.state("drop_tail"))[0].clone().long()
@@ -173,10 +175,13 @@ def test_conservation_and_queue_bounds_at_full_size(fused):
     acked = torch.zeros(N, dtype=torch.float64, device=DEV)
     sent = torch.zeros_like(acked)
     now_prev = env.state("now").clone()
+    M, rows_m, acts_m = 512, [], []
     for t in range(40):
-        a = torch.rand((N,), generator=gen, device=DEV) * 2 - 1
+        a = torch.rand((N,), generator=gen, device=DEV, dtype=torch.float64) * 2 - 1
         o, r, d, info = env.step(a)
         s = info["steps"]
+        rows_m.append(s[:M].clone())
+        acts_m.append(a[:M].clone())
         sent += s[:, 0]
         acked += s[:, 1] + s[:, 2]
         now = env.state("now")
@@ -191,6 +196,8 @@ def test_conservation_and_queue_bounds_at_full_size(fused):
     assert bool(((head - head0).double() == acked).all())
     assert bool((env.state("acc_tail") >= env.state("acc_head")).all())
     assert bool((env.state("drop_tail") >= env.state("drop_head")).all())
+    ref = oracle.run_batch(torch.stack(acts_m, 1).cpu().numpy(), rng_mode=oracle.RNG_PHILOX, seed=0, want_obs=False)
+    assert np.array_equal(torch.stack(rows_m, 1).cpu().numpy(), ref["steps"])
     env.close()
 
 
@@ -223,15 +230,12 @@ def test_old_gym_adapter_drop_in():
     dict(takeover_lanes=64, round_packets=8),            # everything through the wave path after 8 packets
     dict(takeover_lanes=0, heavy_predict=1e18),          # lane-serial only
     dict(heavy_predict=0.0),                             # every env sent by the heavy wavefront from the start
-    dict(heavy_packets=16, heavy_rho=10.0),              # standing classification on for every regime
     dict(send_envs_per_wave=7, round_packets=64, takeover_lanes=3),
-    dict(help_lanes=64, takeover_lanes=0, heavy_predict=1e18),   # every round after the first with helper-drawn loss bits
-    dict(help_lanes=0),                                          # never
-    dict(fused_step=0),                                          # pcc_step as two launches
-    dict(send_waves=2, heavy_predict=64.0),                      # one heavy wavefront takes every flagged env
-    dict(send_waves=8, heavy_predict=64.0),                      # seven of them share the flagged envs
-    dict(fused_step=2),                                          # one launch: send + work-stealing retire
-    dict(fused_step=2, heavy_predict=64.0, takeover_lanes=1),    # ... with all three heavy wavefronts busy
+    dict(takeover_lanes=0, heavy_predict=1e18),                  # lane rounds only
+    dict(send_waves=1, heavy_predict=64.0),                      # few persistent wavefronts, many heavy items each
+    dict(send_waves=32, heavy_predict=64.0),                     # more wavefronts than items
+    dict(send_envs_per_wave=64, heavy_predict=256.0, takeover_lanes=8),
+    dict(heavy_predict=16.0, round_packets=16),                  # nearly everything by wave passes of every regime
 ])
 def test_send_paths_are_exact_whatever_the_tuning(knobs):
     """The tuning knobs only choose WHICH exact send path runs (lane-serial rounds, the wave-wide
@@ -255,8 +259,7 @@ def test_send_paths_are_exact_whatever_the_tuning(knobs):
     dict(takeover_lanes=0),                              # lane-serial only
     dict(takeover_lanes=64, round_packets=8),            # merge-path wave passes for almost everything
     dict(takeover_lanes=64, round_packets=4, heavy_predict=200.0),
-    dict(fused_step=2),
-    dict(fused_step=2, heavy_predict=100.0),
+    dict(heavy_predict=100.0, send_waves=2),
 ])
 def test_two_sender_philox_batches_match_oracle(knobs):
     """BASELINE.json configs[4] shape (two senders on one link) at a size the oracle finishes in
@@ -288,18 +291,6 @@ def test_two_sender_wave_path_on_golden_trace():
     steps, obs, _ = run_gpu(env, d["actions"], T)
     assert np.array_equal(steps, d["steps"])
     env.close()
-
-
-def test_fused_step_on_golden_traces():
-    """The one-launch step (send, then work-stealing retire) on reference traces."""
-    for name in ("default_pm1", "saturating_0_2", "fixed_deepq"):
-        d = load(name)
-        env = golden_env(d, history_len=int(d["history_len"]))
-        env.set_tuning(fused_step=2)
-        env.reset()
-        steps, obs, done = run_gpu(env, d["actions"], d["actions"].shape[1])
-        assert np.array_equal(steps, d["steps"]), name
-        env.close()
 
 
 def test_wave_path_on_golden_traces():

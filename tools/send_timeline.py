@@ -19,7 +19,6 @@ import pcc_rl_amd
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 dev = torch.device("cuda:0")
 env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
-env.set_tuning(fused_step=1 if os.environ.get("PCC_TL_FUSED", "1") != "0" else 0)
 for k, v in os.environ.items():
     if k.startswith("PCC_TUNE_"):
         env.set_tuning(**{k[9:].lower(): float(v)})
@@ -28,7 +27,7 @@ acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
 env.reset()
 out = []
 sample = {2, 10, 30, 60, 100, 150, 200, 250, 300, 350, 398}
-FUSED = os.environ.get("PCC_TL_FUSED", "1") != "0"
+FUSED = False
 for t in range(400):
     if FUSED:
         env.step(acts[t % 64])
@@ -36,10 +35,10 @@ for t in range(400):
         env.step_send(acts[t % 64])
     if t in sample:
         raw = env.debug_timeline().astype(np.int64)
-        nb = raw.shape[0] // 4
-        tl, bl = raw[:2 * nb], raw[2 * nb:].reshape(-1, 16)
+        n_items = int(env.debug_pass_stats(reset=False)["items"])
+        tl = raw[:n_items]
         tl = tl[tl[:, 0] > 0]
-        t0 = tl[:nb * 2:2, 0].min() if False else tl[tl[:, 0] >= np.median(tl[:, 0]) - 10**7][:, 0].min()
+        t0 = tl[:, 0].min()
         start, mid, fin = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0   # us
         heavy_wave = np.arange(len(tl))  # placeholder, the heavy wavefronts are the ones with 0 round time and w[3] > 0
         order = np.argsort(-fin)[:8]
@@ -53,6 +52,19 @@ for t in range(400):
                "slowest": [{"start": float(start[i]), "rounds_end": float(mid[i]), "finish": float(fin[i]),
                             "wave_path_envs": int(tl[i, 3]), "packets": int(tl[i, 4]), "largest_env": int(tl[i, 5]),
                             "wave_path_packets": int(tl[i, 6]), "live": int(tl[i, 7])} for i in order]}
+        if os.environ.get("PCC_TL_RAW") and t in (100, 300):
+            np.save(os.path.join(os.environ["PCC_TL_RAW"], "items_step%d.npy" % t), tl)
+        hv = tl[:, 3] > 0
+        lt_ = ~hv
+        dur = fin - start
+        rec["heavy_items"] = {"n": int(hv.sum()), "busy_us": float(dur[hv].sum()), "packets": int(tl[hv, 4].sum()),
+                              "ns_per_packet": float(1e3 * dur[hv].sum() / max(1, tl[hv, 4].sum())),
+                              "ns_per_packet_p10_p50_p90": [float(np.percentile(1e3 * dur[hv] / np.maximum(1, tl[hv, 4]), q)) for q in (10, 50, 90)] if hv.any() else None}
+        rec["light_items"] = {"n": int(lt_.sum()), "busy_us": float(dur[lt_].sum()), "packets": int(tl[lt_, 4].sum()),
+                              "lane_iterations": int(tl[lt_, 5].sum()),
+                              "ns_per_iteration": float(1e3 * dur[lt_].sum() / max(1, tl[lt_, 5].sum())),
+                              "lane_efficiency": float(tl[lt_, 4].sum() / max(1, 64 * tl[lt_, 5].sum())),
+                              "rounds_share": float((mid[lt_] - start[lt_]).sum() / max(1e-9, dur[lt_].sum()))}
         if FUSED:
             pub, ext = (bl[:, 0] - t0) / 100.0, (bl[:, 1] - t0) / 100.0
             rec["block_published_us"] = pct(pub)
