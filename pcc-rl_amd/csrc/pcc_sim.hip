@@ -965,9 +965,6 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
         const bool always = thr_d >= 4294967296.0;
         const uint32_t thr = always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
         char *base = rings[0].base;
-        // profiling only: the lanes write into the rings of 64 NEIGHBOURING envs instead of their own (wrong results;
-        // isolates what the placement of a sorted item's rings costs)
-        if (D.debug_skip & 16) base = D.tier_base[0] + (size_t)(((uint64_t)tl_slot * 64u + lane) % (uint64_t)D.n) * tier_slot_bytes(D, 0);
         if (D.use_cwnd) {
             // ---- USE_CWND (ns:54, 251-255, 158-160): a SEND goes out only while fewer than cwnd
             // packets are unacknowledged.  That couples the SEND stream to the notifications, so this
@@ -1063,7 +1060,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
                             bool dropped;
                             const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
                             const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                            if (!(D.debug_skip & 4)) st_rec(reinterpret_cast<double2 *>(base + ((D.debug_skip & 16) ? (off & 8176u) : off)), rec);
+                            if (!(D.debug_skip & 4)) st_rec(reinterpret_cast<double2 *>(base + off), rec);
                             a += dropped ? 0u : 1u;
                             d += dropped ? 1u : 0u;
                             t += gap[0];  // ns:161
@@ -1079,7 +1076,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
                             bool dropped;
                             const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
                             const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                            if (!(D.debug_skip & 4)) st_rec(reinterpret_cast<double2 *>(base + ((D.debug_skip & 16) ? (off & 8176u) : off)), rec);
+                            if (!(D.debug_skip & 4)) st_rec(reinterpret_cast<double2 *>(base + off), rec);
                             a += dropped ? 0u : 1u;
                             d += dropped ? 1u : 0u;
                             t += gap[0];  // ns:161
@@ -2446,7 +2443,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.takeover_lanes = 1;  // measured with three heavy wavefronts per block: 1 -> 0.487, 2 -> 0.516, 3 -> 0.595 ms/step
     d.send_waves = 16;  // persistent send wavefronts per compute unit (4 per SIMD at <= 128 VGPRs)
     d.send_envs_per_wave = 64;
-    d.heavy_predict = 1024.0;
+    d.heavy_predict = 512.0;
     d.send_wg_waves = getenv("PCC_SEND_WG_WAVES") ? (uint32_t)atoi(getenv("PCC_SEND_WG_WAVES")) : 4u;
     if (d.send_wg_waves < 1u || d.send_wg_waves > 4u) d.send_wg_waves = 4u;
     d.debug_skip = getenv("PCC_DEBUG_SKIP") ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;
