@@ -9,23 +9,26 @@ ranges, actions U(-1, 1) pre-generated on the device, Philox loss uniforms, auto
 400-step episode boundary.  One "step" = one `step()` of all envs = one monitor interval per
 env.  For N > 1 every rank owns its own 65 536 envs (weak scaling, env ids rank*65536+i, no
 collective inside the step; episode returns are all-gathered over RCCL when episodes end).
+`--gpus N` run directly (no torchrun) starts the N ranks itself.
+
+Protocol: W warm-up steps, then K timed steps between barrier +
+synchronize, repeated `--repeats` times back to back; the line reports the MEDIAN run, every run's
+ms/step, and which steps of the 400-step episode each run covered (`window`) -- the packet count per
+step grows over an episode, so a short window early in the episode is lighter than the average.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md section 6 for the fields).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import pcc_rl_amd  # noqa: E402
-from pcc_rl_amd import distributed as pdist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Algorithmic bytes per env-step (SURVEY.md section 8d): 450 B of fixed traffic + 32 B per packet
@@ -33,75 +36,106 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # timed apart with HIP events: send_kernel (dominant) reads the action (4), link parameters (32),
 # and reads+writes link state (2x16) and sender rate/next_send/cursors (2x26) = 120 B, and writes
 # the 16-B record; retire_kernel owns the remaining 330 B (state, history, obs/reward/done) and
-# reads the record.  With --fused the step is ONE launch (step_kernel: a workgroup sends for its
-# 64 envs, then retires envs of whichever blocks are done) and carries all 450 + 32 P bytes.
+# reads the record.
 B_FIXED_SEND, B_FIXED_RETIRE, B_PACKET_HALF = 120, 330, 16
+REFERENCE_STEPS_PER_S_PER_CORE = 800.0   # the unmodified reference, SURVEY.md section 6 (build container)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks (one per GPU) ourselves."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(args.port or port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def pmc_traffic():
-    """HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    separate passes over this same script; see profiles/README.md).  Counters cannot be read from
-    inside the process, so the figure is the profile's, labelled with its source."""
-    for name in ("r01_v9_pmc_hbm.json", "r01_v8_pmc_hbm.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            with open(path) as f:
-                return json.load(f), "profiles/" + name
+    """HBM bytes per launch from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate passes over this same script; see profiles/README.md).  Counters cannot be
+    read from inside the process, so the figure is the profile's, labelled with its source and window."""
+    pdir = os.path.join(ROOT, "profiles")
+    names = sorted((n for n in os.listdir(pdir) if n.endswith("_pmc_hbm.json")), reverse=True) if os.path.isdir(pdir) else []
+    for name in names:
+        with open(os.path.join(pdir, name)) as f:
+            return json.load(f), "profiles/" + name
     return None, None
 
 
-def cpu_baseline(seconds_budget=20.0, threads=1):
-    """The CPU oracle (oracle/pcc_oracle.c, the literal heap-based restatement of the
-    reference engine) timed on this host on a bounded sample of the same workload."""
+def cpu_baseline(seconds_budget=15.0):
+    """The CPU side of the same workload on this host's cores, a bounded sample each:
+    the C oracle (oracle/pcc_oracle.c, the literal heap-based restatement of the reference engine)
+    on one thread and on every core, and the same algorithm in the reference's own language
+    (oracle/pcc_oracle_py.py: heapq + numpy), one process per core."""
     import numpy as np
 
     import oracle
 
+    cores = os.cpu_count() or 1
     rs = np.random.RandomState(0)
     n_envs, n_steps = 64, 100
-    done_steps, done_pk, t_used = 0, 0.0, 0.0
-    base = 0
+    done_steps, done_pk, t_used, base = 0, 0.0, 0.0, 0
     while t_used < seconds_budget:
         acts = rs.uniform(-1, 1, (n_envs, n_steps))
         t0 = time.perf_counter()
-        out = oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=0, env_gid_base=base,
-                               n_threads=threads, want_obs=False)
+        out = oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=0, env_gid_base=base, n_threads=1, want_obs=False)
         t_used += time.perf_counter() - t0
         done_steps += n_envs * n_steps
         done_pk += float(out["steps"][..., 0].sum())
         base += n_envs
-    out = {"value": done_steps / t_used, "unit": "env steps/s", "cores": threads, "kind": "port",
+    res = {"value": done_steps / t_used, "unit": "env steps/s", "cores": 1, "kind": "port",
            "sample": "%d env-steps (%d-env x %d-step batches of the bench workload, Philox uniforms, "
-                     "%.1f packets/step) on the C oracle, %d thread(s), %.1f s; host has %d cores"
-                     % (done_steps, n_envs, n_steps, done_pk / done_steps, threads, t_used, os.cpu_count() or 1)}
-    # the same C oracle on every host core (envs are independent: one env batch per thread)
-    cores = os.cpu_count() or 1
-    if cores > 1:
+                     "%.1f packets/step) on the C oracle, 1 thread, %.1f s; host has %d cores"
+                     % (done_steps, n_envs, n_steps, done_pk / done_steps, t_used, cores)}
+    if cores > 1:   # the same C oracle on every host core (envs are independent: one env batch per thread)
         n_all, steps_all, t_all, base_all = 8 * cores, 0, 0.0, 1 << 20
         while t_all < 5.0:
             acts = rs.uniform(-1, 1, (n_all, n_steps))
             t0 = time.perf_counter()
-            oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=0, env_gid_base=base_all, n_threads=cores,
-                             want_obs=False)
+            oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=0, env_gid_base=base_all, n_threads=cores, want_obs=False)
             t_all += time.perf_counter() - t0
             steps_all += n_all * n_steps
             base_all += n_all
-        out["all_cores"] = {"value": steps_all / t_all, "unit": "env steps/s", "cores": cores,
+        res["all_cores"] = {"value": steps_all / t_all, "unit": "env steps/s", "cores": cores,
                             "sample": "%d env-steps on %d threads, %.1f s" % (steps_all, cores, t_all)}
-    # the same algorithm in the reference's own language (heapq + numpy), for scale: a few episodes
-    from oracle.pcc_oracle_py import time_episodes
-    py_steps, py_pk, py_s = time_episodes(1000, 2, n_steps=200)
-    out["python_port"] = {"value": py_steps / py_s, "unit": "env steps/s", "cores": 1,
-                          "sample": "%d env-steps, %.1f packets/step, %.1f s (oracle/pcc_oracle_py.py)"
-                                    % (py_steps, py_pk / py_steps, py_s)}
-    return out
+    # the reference's algorithm class in its own language, one process per host core, >= 10 s each
+    code = ("import sys, json; sys.path.insert(0, %r)\n"
+            "from oracle.pcc_oracle_py import time_episodes\n"
+            "tot_s = tot_p = tot_t = 0.0; k = 0\n"
+            "while tot_t < 10.0:\n"
+            "    s, p, t = time_episodes(int(sys.argv[1]) * 1000 + k, 1, n_steps=200); tot_s += s; tot_p += p; tot_t += t; k += 1\n"
+            "print(json.dumps([tot_s, tot_p, tot_t]))\n" % ROOT)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+             for r in range(cores)]
+    t0 = time.perf_counter()
+    outs = []
+    for p in procs:
+        try:
+            outs.append(json.loads(p.communicate()[0].decode() or "[0,0,1]"))
+        except ValueError:
+            outs.append([0, 0, 1])
+    wall = time.perf_counter() - t0
+    per_core = [o[0] / o[2] for o in outs if o[0] > 0]
+    if per_core:
+        agg = sum(o[0] for o in outs) / wall
+        res["python_port"] = {"value": agg, "unit": "env steps/s", "cores": len(per_core),
+                              "per_core": sum(per_core) / len(per_core),
+                              "vs_reference_per_core": (sum(per_core) / len(per_core)) / REFERENCE_STEPS_PER_S_PER_CORE,
+                              "sample": "one process per core, %d processes x >= 10 s of 200-step default-parameter episodes "
+                                        "(oracle/pcc_oracle_py.py: heapq + numpy, %.1f packets/step), %.1f s wall; the unmodified "
+                                        "reference measured %.0f steps/s/core in the build container (SURVEY.md section 6)"
+                                        % (len(per_core), sum(o[1] for o in outs) / max(1.0, sum(o[0] for o in outs)), wall,
+                                           REFERENCE_STEPS_PER_S_PER_CORE)}
+    return res
 
 
-def async_groups(N, dev, K, W, n_groups=4):
+def async_groups(pcc_rl_amd, torch, N, dev, K, W, n_groups=4):
     """Supplementary figure, NOT the headline: the same N envs as independent groups on their own
     streams, stepped without a per-step synchronization between the groups (double-buffered
-    sampling: the policy works on one group while the others simulate).  Same envs, same results,
-    same work; the bulk of one group's step fills the send tail of another's."""
+    sampling: the policy works on one group while the others simulate)."""
     K = min(K, 400)
     env = pcc_rl_amd.GroupedNetworkEnv(N, n_groups, device=dev, seed=0)
     acts = []
@@ -129,22 +163,38 @@ def async_groups(N, dev, K, W, n_groups=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1200)
+    ap.add_argument("--steps", type=int, default=2000, help="timed steps per run (5 episodes by default)")
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=3, help="timed runs, back to back; the line reports the median")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself")
     ap.add_argument("--ring-capacity", type=int, default=0, help="records per accepted ring (0 = library default)")
     ap.add_argument("--groups", type=int, default=0,
                     help="also measure the same envs as this many independent groups on their own streams "
-                         "(supplementary field async_groups; how well the groups overlap depends on how HIP maps "
-                         "the streams to hardware queues)")
+                         "(supplementary field async_groups)")
+    ap.add_argument("--stagger", action="store_true",
+                    help="spread the envs' episode phases uniformly over the 400 steps before timing (masked resets "
+                         "during an untimed pre-roll): every window then sees the episode-average load, and the "
+                         "auto-resets run on the device-gated path instead of the host-known lockstep boundary")
+    ap.add_argument("--max-steps", type=int, default=400, help="episode length (tests shorten it to see the all-gather)")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (lets the N > 1 path run on a 1-GPU box with gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+
+    import torch
+
+    import pcc_rl_amd
+    from pcc_rl_amd import distributed as pdist
+
     rank, world, local_rank = pdist.rank_info()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -154,14 +204,21 @@ def main():
         import torch.distributed as dist
         pdist.init_process_group(args.backend, device=dev)   # "nccl" is RCCL on ROCm
 
-    N, K, W = args.envs, args.steps, args.warmup
+    N, K, W, R = args.envs, args.steps, args.warmup, max(1, args.repeats)
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, env_gid_base=pdist.env_gid_base(rank, N),
-                                       auto_reset=True, ring_capacity=args.ring_capacity)
+                                       auto_reset=True, ring_capacity=args.ring_capacity, max_steps=args.max_steps)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = 64
     actions = torch.rand((pool, N), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
-    args.split = True
     env.reset()
+    max_steps = env.max_steps
+    if args.stagger:
+        # env i starts its episode at pre-roll step i % 400: after 400 steps the phases are uniform
+        phase = torch.arange(N, device=dev) % max_steps
+        for s in range(max_steps):
+            if s:
+                env.reset(phase == s)
+            env.step(actions[s % pool])
     returns_gathered = 0
     gather_buf = torch.empty((world * N,), dtype=torch.float32, device=dev) if world > 1 else None
 
@@ -169,16 +226,13 @@ def main():
         nonlocal returns_gathered
         if ev is not None:
             ev[0].record()
-        if args.split:
-            env.step_send(actions[t % pool])
-            if ev is not None:
-                ev[1].record()
-            env.step_retire()
-        else:
-            env.step(actions[t % pool])
+        env.step_send(actions[t % pool])
+        if ev is not None:
+            ev[1].record()
+        env.step_retire()
         if ev is not None:
             ev[2].record()
-        if world > 1 and (t + 1) % env.max_steps == 0:
+        if world > 1 and (t + 1) % max_steps == 0:
             # the only inter-GPU traffic on this path: episode returns, once per episode
             pdist.gather_episode_returns(env.episode_returns().to(torch.float32), out=gather_buf)
             returns_gathered += 1
@@ -187,81 +241,88 @@ def main():
     for _ in range(W):
         one_step(t_global)
         t_global += 1
-    sent0 = env.state("total_sent").sum()
 
-    # HIP events on the launch stream (torch's current stream IS the stream the library launches on)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(K):
-        one_step(t_global, ev[k])
-        t_global += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-
-    packets = float((env.state("total_sent").sum() - sent0).item())
+    runs = []
+    for r in range(R):
+        sent0 = env.state("total_sent").sum()
+        # HIP events on the launch stream (torch's current stream IS the stream the library launches on)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+        first = t_global
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(K):
+            one_step(t_global, ev[k])
+            t_global += 1
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)     # MAX over ranks (bench contract)
+        packets = float((env.state("total_sent").sum() - sent0).item())
+        # steps that also ran the episode-boundary reset kernels are kept out of the retire average
+        plain = [k for k in range(K) if (first + k + 1) % max_steps != 0] if not args.stagger else list(range(K))
+        runs.append({"elapsed": elapsed, "packets": packets, "first_step": first,
+                     "send_ms": sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K,
+                     "retire_ms": sum(ev[k][1].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))})
     if not os.environ.get("PCC_BENCH_IGNORE_FLAGS"):   # experiments only: an overflowed ring means invalid results
         env.check_flags()
-    plain = [k for k in range(K) if (W + k + 1) % env.max_steps != 0]
-    # steps that also ran the episode-boundary reset kernels are kept out of the kernel averages
-    if args.split:
-        send_ms = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
-        retire_ms = sum(ev[k][1].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))
-    else:
-        step_ms = sum(ev[k][0].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))
-
-    elapsed = pdist.max_over_ranks(elapsed, device=dev)     # MAX over ranks (bench contract)
-    max_steps = env.max_steps
     env.close()
 
     if rank == 0:
-        value = world * N * K / elapsed
-        pk_per_step = packets / (N * K)
+        order = sorted(range(R), key=lambda r: runs[r]["elapsed"])
+        med = runs[order[R // 2]]
+        value = world * N * K / med["elapsed"]
+        pk_per_step = med["packets"] / (N * K)
         send_bytes = N * (B_FIXED_SEND + B_PACKET_HALF * pk_per_step)
         retire_bytes = N * (B_FIXED_RETIRE + B_PACKET_HALF * pk_per_step)
+        send_ms, retire_ms = med["send_ms"], med["retire_ms"]
+        if args.stagger:
+            window = {"episode_steps": "all phases at once (--stagger): every step sees the episode-average load"}
+        else:
+            f = med["first_step"] % max_steps
+            window = {"episode_steps": [f, f + K - 1] if K < max_steps else "whole episodes",
+                      "first_step_of_episode": f, "steps": K,
+                      "covers_whole_episodes": K % max_steps == 0,
+                      "note": None if K >= max_steps else
+                      "steps < one 400-step episode: packets per step grow over an episode (about 120 early, 180 on "
+                      "average), so this window is lighter than the episode average"}
         out = {
             "metric": "env steps/sec (whole node) at 64k parallel envs",
             "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * med["elapsed"] / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "repeats": R, "runs_ms_per_step": [1e3 * r["elapsed"] / K for r in runs],
+            "spread": (max(r["elapsed"] for r in runs) - min(r["elapsed"] for r in runs)) / med["elapsed"],
+            "window": window,
             "config": {"workload": "%d envs/GPU, 1 sender, per-env randomized bw/latency/queue/loss "
-                                   "(ICML'19 ranges), U(-1,1) actions, 400-step episodes, auto-reset" % N,
+                                   "(ICML'19 ranges), U(-1,1) actions, 400-step episodes, auto-reset%s"
+                                   % (N, ", episode phases staggered" if args.stagger else ""),
                        "envs_per_gpu": N, "packets_per_env_step": pk_per_step,
                        "episode_return_allgathers": returns_gathered},
         }
-        if args.split:
-            send_gbps = send_bytes / (send_ms * 1e-3) / 1e9
-            retire_gbps = retire_bytes / (retire_ms * 1e-3) / 1e9
-            both = (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "send_kernel<1, false>", "achieved": send_gbps,
-                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": send_gbps / HBM_PEAK_GBPS,
-                               "traffic": None, "kernel_ms": send_ms, "algorithmic_bytes_per_launch": send_bytes,
-                               "other_kernels": [{"kernel": "retire_kernel<1>", "achieved": retire_gbps,
-                                                  "frac": retire_gbps / HBM_PEAK_GBPS, "kernel_ms": retire_ms,
-                                                  "algorithmic_bytes_per_launch": retire_bytes}],
-                               "whole_step": {"achieved": both, "frac": both / HBM_PEAK_GBPS}}
-        else:
-            # the step IS the dominant kernel: one launch per step
-            step_bytes = send_bytes + retire_bytes
-            gbps = step_bytes / (step_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "step_kernel<1, false>", "achieved": gbps,
-                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                               "traffic": None, "kernel_ms": step_ms, "algorithmic_bytes_per_launch": step_bytes,
-                               "algorithmic_bytes_per_env_step": B_FIXED_SEND + B_FIXED_RETIRE + 2 * B_PACKET_HALF * pk_per_step}
+        send_gbps = send_bytes / (send_ms * 1e-3) / 1e9
+        retire_gbps = retire_bytes / (retire_ms * 1e-3) / 1e9
+        both = (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "send_kernel<1, false>", "achieved": send_gbps,
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": send_gbps / HBM_PEAK_GBPS,
+                           "traffic": None, "kernel_ms": send_ms, "algorithmic_bytes_per_launch": send_bytes,
+                           "other_kernels": [{"kernel": "retire_kernel<1>", "achieved": retire_gbps,
+                                              "frac": retire_gbps / HBM_PEAK_GBPS, "kernel_ms": retire_ms,
+                                              "algorithmic_bytes_per_launch": retire_bytes}],
+                           "whole_step": {"achieved": both, "frac": both / HBM_PEAK_GBPS}}
         pmc, src = pmc_traffic()
         kname = out["roofline"]["kernel"]
         if pmc and N == 65536 and kname in pmc and pmc[kname].get("launches", 0) >= 50:
             out["roofline"]["traffic"] = pmc[kname]["hbm_bytes_per_launch_raw"]
-            out["roofline"]["traffic_source"] = src + " (raw FETCH_SIZE+WRITE_SIZE, KB units x 1024)"
+            out["roofline"]["traffic_source"] = (src + ": raw FETCH_SIZE + WRITE_SIZE (KB units x 1024) of a SEPARATE profiled run "
+                                                 "of this script over " + str(pmc.get("_window", "steps 20..120 of an episode")) +
+                                                 "; compare it with that window's algorithmic bytes (in the profile), not this run's")
             for other in out["roofline"].get("other_kernels", []):
                 if other["kernel"] in pmc and pmc[other["kernel"]].get("launches", 0) >= 50:
                     other["traffic"] = pmc[other["kernel"]]["hbm_bytes_per_launch_raw"]
         if world == 1 and args.groups > 1:
-            out["async_groups"] = async_groups(N, dev, K, W, args.groups)
+            out["async_groups"] = async_groups(pcc_rl_amd, torch, N, dev, K, W, args.groups)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         elif world == 1:

@@ -109,6 +109,7 @@ struct Dev {
     uint32_t *cls_count;  // [2][kClsStride] work lists of the send half (two buffers): envs per class, item cursor
     uint32_t *cls_list;   // [2][kClasses][N] env ids by class
     uint32_t *cursors;    // [3][kShards][kCursorStride] item cursors of the two list buffers (third block unused)
+    uint32_t *any_done;   // [1] set by the retire half when an env finished its episode; gates the auto-reset launches
     uint64_t *timeline;  // profiling only (PCC_DEBUG_TIMELINE env): 8 words per send wavefront, see pcc_debug_timeline
     unsigned long long *pass_stats;  // profiling only (same switch): counters of the wave passes, see pcc_debug_pass_stats
     int pass_counters;               // ... per-pass counters on (PCC_DEBUG_TIMELINE=2: contended atomics, they slow the passes down)
@@ -1304,11 +1305,15 @@ constexpr uint32_t kCursorStride = 32;  // words between shard cursors: one 128-
 
 template <int NS, bool TRACE>
 __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf, int zero_buf, int warm, uint32_t warm_mi,
-                                                         const void *actions, int actions_f64) {
+                                                         int gate, const void *actions, int actions_f64) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;  // every wavefront works on its own
     const uint32_t n_waves = gridDim.x * (blockDim.x / kWave);                      // a multiple of kShards
     const uint32_t E = D.send_envs_per_wave;
+    // auto-reset launches of a step in which no env finished have nothing to do (envs at different
+    // points of their episodes: the host cannot know)
+    if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (wave == 0 && lane == 0 && !warm) *D.any_done = 0u;  // consumed by the reset launches of the step before
     if (wave == 0 && zero_buf >= 0) {
         if (lane < (uint32_t)kClsStride) D.cls_count[zero_buf * kClsStride + lane] = 0u;
         if (lane < kShards) D.cursors[((uint32_t)zero_buf * kShards + lane) * kCursorStride] = 0u;
@@ -2124,6 +2129,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         D.steps[i] = steps + 1;
         const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
         D.done[i] = done;
+        if (done) *D.any_done = 1u;  // somebody needs the auto-reset launches of this step
         if (done_out) done_out[i] = done;
     }
     PCC_TL_STAMP(11)  // outputs
@@ -2135,8 +2141,9 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
 
 template <int NS>
 __global__ __launch_bounds__(kRetireBlock, 5) void retire_kernel(Dev D, int fill_buf, int warm, uint32_t warm_mi,
-                                                              int last_warm, float *obs_out, float *reward_out,
+                                                              int last_warm, int gate, float *obs_out, float *reward_out,
                                                               uint8_t *done_out, double *steps_out) {
+    if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const uint32_t tid = threadIdx.x;
     Group g;
     g.lane = tid & (kGroup - 1);
@@ -2165,7 +2172,8 @@ __global__ __launch_bounds__(kRetireBlock, 5) void retire_kernel(Dev D, int fill
 // MIs (ns:478-479) are run by send_kernel / retire_kernel in warm mode on the marked envs.
 // ======================================================================================
 template <int NS>
-__global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t *mask, int use_done, float *obs_out) {
+__global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t *mask, int use_done, int gate, float *obs_out) {
+    if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
     if (i >= D.n) return;
     const bool sel = (!mask || mask[i]) && (!use_done || D.done[i]);
@@ -2297,6 +2305,7 @@ size_t carve_state(Dev &d, char *base) {
     d.steps = c.take<uint32_t>(n); d.episode = c.take<uint32_t>(n); d.flags = c.take<uint32_t>(n);
     d.cls_count = c.take<uint32_t>(2 * kClsStride);
     d.cursors = c.take<uint32_t>(3 * 16 * 32);
+    d.any_done = c.take<uint32_t>(1);
     d.done = c.take<uint8_t>(n); d.resetting = c.take<uint8_t>(n);
     d.total_sent = c.take<unsigned long long>(n);
     d.rate = c.take<double>(sn); d.rate0 = c.take<double>(sn); d.next_send = c.take<double>(sn);
@@ -2322,7 +2331,7 @@ dim3 lane_grid(const Dev &d) { return dim3((unsigned)((d.n + kWave - 1) / kWave)
 // SEND half of one monitor interval: all envs (warm = 0) or the envs being reset (warm = 1).
 // Persistent single-wavefront workgroups, send_waves per compute unit, take work items off the class
 // lists the last retire launch filed (sim->read_buf) -- or the envs in index order when there are none.
-int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, const void *actions, int actions_f64, hipStream_t st) {
+int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64, hipStream_t st) {
     const Dev &d = sim->d;
     const bool tr = d.rng_mode == PCC_RNG_TRACE;
     const int read_buf = warm ? -1 : sim->read_buf;
@@ -2335,28 +2344,28 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, const void *actions,
     waves = (waves + unit - 1) / unit * unit;
     const dim3 sgrid((unsigned)(waves / d.send_wg_waves)), sblock(kWave * d.send_wg_waves);
     if (d.ns == 1) {
-        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<1, false>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, actions, actions_f64);
+        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<1, false>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, actions, actions_f64);
     } else {
-        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<2, false>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, actions, actions_f64);
+        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, actions, actions_f64);
+        else hipLaunchKernelGGL((send_kernel<2, false>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, actions, actions_f64);
     }
     return check_hip(hipGetLastError(), "send kernel launch");
 }
 
 // RETIRE half; a launch that is not a warm-up interval also files every env in the work lists of the
 // next send (buffer sim->fill_buf, cleared by the send launch before it)
-int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, float *obs_out, float *reward_out,
+int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, float *obs_out, float *reward_out,
                   uint8_t *done_out, double *steps_out, hipStream_t st) {
     const Dev &d = sim->d;
     const int64_t per_block = kRetireBlock / kGroup;
     const dim3 grid((unsigned)((d.n + per_block - 1) / per_block));
     const int fill = warm ? -1 : sim->fill_buf;
     if (d.ns == 1)
-        hipLaunchKernelGGL(retire_kernel<1>, grid, dim3(kRetireBlock), 0, st, d, fill, warm, warm_mi, last_warm, obs_out,
+        hipLaunchKernelGGL(retire_kernel<1>, grid, dim3(kRetireBlock), 0, st, d, fill, warm, warm_mi, last_warm, gate, obs_out,
                            reward_out, done_out, steps_out);
     else
-        hipLaunchKernelGGL(retire_kernel<2>, grid, dim3(kRetireBlock), 0, st, d, fill, warm, warm_mi, last_warm, obs_out,
+        hipLaunchKernelGGL(retire_kernel<2>, grid, dim3(kRetireBlock), 0, st, d, fill, warm, warm_mi, last_warm, gate, obs_out,
                            reward_out, done_out, steps_out);
     const int rc = check_hip(hipGetLastError(), "retire kernel launch");
     if (rc == PCC_OK && !warm) {
@@ -2366,21 +2375,23 @@ int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, flo
     return rc;
 }
 
-int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, const void *actions, int actions_f64,
+int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, const void *actions, int actions_f64,
               float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
-    const int rc = launch_send(sim, warm, warm_mi, actions, actions_f64, st);
+    const int rc = launch_send(sim, warm, warm_mi, gate, actions, actions_f64, st);
     if (rc != PCC_OK) return rc;
-    return launch_retire(sim, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out, st);
+    return launch_retire(sim, warm, warm_mi, last_warm, gate, obs_out, reward_out, done_out, steps_out, st);
 }
 
-// reset(): parameters + state, then the two unrecorded warm-up MIs (ns:469-484)
-int launch_reset(pcc_sim_t *sim, const uint8_t *mask, int use_done, float *obs_out, hipStream_t st) {
+// reset(): parameters + state, then the two unrecorded warm-up MIs (ns:469-484).  gate: the launches
+// do nothing unless the retire half flagged a finished env in this step (auto-reset of envs that are
+// not in lockstep)
+int launch_reset(pcc_sim_t *sim, const uint8_t *mask, int use_done, int gate, float *obs_out, hipStream_t st) {
     const Dev &d = sim->d;
-    if (d.ns == 1) hipLaunchKernelGGL(reset_init_kernel<1>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, obs_out);
-    else hipLaunchKernelGGL(reset_init_kernel<2>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, obs_out);
+    if (d.ns == 1) hipLaunchKernelGGL(reset_init_kernel<1>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, gate, obs_out);
+    else hipLaunchKernelGGL(reset_init_kernel<2>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, gate, obs_out);
     int rc = check_hip(hipGetLastError(), "reset kernel launch");
     for (uint32_t w = 0; w < 2 && rc == PCC_OK; w++)
-        rc = launch_mi(sim, 1, w, w == 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, st);
+        rc = launch_mi(sim, 1, w, w == 1, gate, nullptr, 0, nullptr, nullptr, nullptr, nullptr, st);
     return rc;
 }
 
@@ -2667,7 +2678,7 @@ int pcc_set_max_steps(pcc_sim_t *sim, int max_steps) {
 int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     DeviceGuard guard(sim->device);
-    const int rc = launch_reset(sim, mask, 0, obs_out, static_cast<hipStream_t>(stream));
+    const int rc = launch_reset(sim, mask, 0, 0, obs_out, static_cast<hipStream_t>(stream));
     if (rc != PCC_OK) return rc;
     sim->send_pending = false;
     if (!mask) {
@@ -2691,7 +2702,7 @@ int after_mi(pcc_sim_t *sim, float *obs_out, int auto_reset, hipStream_t st) {
         // skips the (otherwise no-op) masked reset launches
         const bool may_be_done = !sim->lockstep || sim->host_steps >= d.max_steps;
         if (may_be_done) {
-            const int rc = launch_reset(sim, nullptr, 1, obs_out, st);
+            const int rc = launch_reset(sim, nullptr, 1, sim->lockstep ? 0 : 1, obs_out, st);
             if (rc != PCC_OK) return rc;
             if (sim->lockstep) sim->host_steps = 0;
         }
@@ -2707,7 +2718,7 @@ int pcc_step_send(pcc_sim_t *sim, const void *actions, int actions_f64, void *st
     if (!sim->ever_reset) return fail(PCC_ESTATE, "pcc_step before pcc_reset (the reference raises TypeError: run_dur is None)");
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_step_send called twice without pcc_step_retire");
     DeviceGuard guard(sim->device);
-    const int rc = launch_send(sim, 0, 0, actions, actions_f64, static_cast<hipStream_t>(stream));
+    const int rc = launch_send(sim, 0, 0, 0, actions, actions_f64, static_cast<hipStream_t>(stream));
     if (rc == PCC_OK) sim->send_pending = true;
     return rc;
 }
@@ -2718,7 +2729,7 @@ int pcc_step_retire(pcc_sim_t *sim, float *obs_out, float *reward_out, uint8_t *
     if (!sim->send_pending) return fail(PCC_ESTATE, "pcc_step_retire without a preceding pcc_step_send");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rc = launch_retire(sim, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
+    const int rc = launch_retire(sim, 0, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
     sim->send_pending = false;
     return after_mi(sim, obs_out, auto_reset, st);
@@ -2731,8 +2742,8 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_step between pcc_step_send and pcc_step_retire");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = launch_send(sim, 0, 0, actions, actions_f64, st);
-    if (rc == PCC_OK) rc = launch_retire(sim, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
+    int rc = launch_send(sim, 0, 0, 0, actions, actions_f64, st);
+    if (rc == PCC_OK) rc = launch_retire(sim, 0, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
     return after_mi(sim, obs_out, auto_reset, st);
 }

@@ -382,6 +382,81 @@ def test_masked_reset_only_touches_selected_envs():
     env.close()
 
 
+def test_envs_out_of_lockstep_match_oracle():
+    """Masked resets at staggered steps, then auto-resets at each env's own episode end (the path where
+    the host cannot know which step finishes an episode: the reset launches are gated on the device).
+    Every env against its own oracle object driven through the same schedule -- all 19 columns and the
+    observations, bit for bit, across episode boundaries."""
+    n, seed, max_steps, T = 96, 11, 30, 85
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=seed, record_steps=True, auto_reset=True, max_steps=max_steps)
+    oenvs = []
+    for i in range(n):
+        o = oracle.OracleEnv()
+        o.rng_philox(seed, i)
+        oenvs.append(o)
+    obs = env.reset().cpu().numpy()
+    oobs = np.stack([o.reset() for o in oenvs])
+    assert np.array_equal(obs, oobs.astype(np.float32))
+    osteps = np.zeros(n, dtype=int)
+    rs = np.random.RandomState(5)
+    idx = np.arange(n)
+    for t in range(T):
+        if t % 7 == 3:
+            mask = (idx % 5) == ((t // 7) % 5)
+            got = env.reset(torch.as_tensor(mask)).cpu().numpy()
+            for i in idx[mask]:
+                want = oenvs[i].reset()
+                osteps[i] = 0
+                assert np.array_equal(got[i], want.astype(np.float32)), (t, i)
+        a = rs.uniform(-1, 1.5, n)
+        o_gpu, r_gpu, d_gpu, info = env.step(torch.as_tensor(a, device=DEV))
+        rows = info["steps"].cpu().numpy()
+        o_gpu, d_gpu = o_gpu.cpu().numpy(), d_gpu.cpu().numpy()
+        for i in range(n):
+            o_ref, r_ref, _, _ = oenvs[i].step(a[i])
+            osteps[i] += 1
+            done = osteps[i] >= max_steps
+            assert np.array_equal(rows[i], oenvs[i].last_row[0]), (t, i)
+            assert bool(d_gpu[i]) == done, (t, i)
+            if done:       # auto-reset: the row returned is the first observation of the next episode
+                o_ref = oenvs[i].reset()
+                osteps[i] = 0
+            assert np.array_equal(o_gpu[i], o_ref.astype(np.float32)), (t, i)
+    env.check_flags()
+    env.close()
+
+
+def test_two_senders_at_full_size():
+    """BASELINE.json configs[4] at its full size (32 768 envs x 2 senders): conservation per sender, the
+    queue bound, and the first 256 envs of the batch against the oracle, bit for bit."""
+    N, T, M = 32768, 30, 256
+    env = pcc_rl_amd.BatchedNetworkEnv(N, device=DEV, seed=4, n_senders=2, record_steps=True, auto_reset=False)
+    env.reset()
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    tail0 = (env.state("acc_tail") + env.state("drop_tail")).clone().long()
+    head0 = (env.state("acc_head") + env.state("drop_head")).clone().long()
+    sent = torch.zeros((2, N), dtype=torch.float64, device=DEV)
+    gone = torch.zeros_like(sent)
+    rows_m, acts_m = [], []
+    for t in range(T):
+        a = torch.rand((N, 2), generator=gen, device=DEV, dtype=torch.float64) * 2.5 - 1
+        o, r, d, info = env.step(a)
+        s = info["steps"]                      # [N, 2, 19]
+        sent += s[:, :, 0].t()
+        gone += (s[:, :, 1] + s[:, :, 2]).t()
+        rows_m.append(s[:M].clone())
+        acts_m.append(a[:M].clone())
+        assert bool((env.state("queue_delay") <= env.state("maxq")).all())
+    env.check_flags()
+    tail = (env.state("acc_tail") + env.state("drop_tail")).long()
+    head = (env.state("acc_head") + env.state("drop_head")).long()
+    assert bool(((tail - tail0).double() == sent).all())
+    assert bool(((head - head0).double() == gone).all())
+    ref = oracle.run_batch(torch.stack(acts_m, 1).cpu().numpy(), n_senders=2, rng_mode=oracle.RNG_PHILOX, seed=4, want_obs=False)
+    assert np.array_equal(torch.stack(rows_m, 2).cpu().numpy(), ref["steps"])
+    env.close()
+
+
 def test_ring_tiers_promote_and_come_back_at_reset(monkeypatch):
     """Rings start in the small tier, envs with many packets in flight are moved up (without
     changing a result: the goldens above cover that, fixed_deepq needs the top tier), reset gives the

@@ -63,3 +63,89 @@ def test_single_process_is_identity():
     x = torch.arange(4.0)
     assert D.gather_episode_returns(x) is x
     assert D.max_over_ranks(3.5) == 3.5 and D.sum_over_ranks(2.0) == 2.0
+
+
+# ---- the same path on a GPU box: two ranks of the SIMULATOR (sharing cuda:0, gloo between them) ----
+import json
+
+import pytest
+
+SHARD_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch
+    import pcc_rl_amd
+    from pcc_rl_amd import distributed as D
+    rank, world, local = D.init_process_group(backend="gloo")
+    dev = torch.device("cuda:0")
+    n, T = 320, 25
+    # rank r owns the global env ids [r*n, (r+1)*n): same seed, its own id base
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=dev, seed=9, env_gid_base=D.env_gid_base(rank, n), record_steps=True,
+                                       auto_reset=True, max_steps=10)
+    gen = torch.Generator().manual_seed(77)
+    acts = torch.rand((T, world * n), generator=gen, dtype=torch.float64) * 2 - 1   # actions by GLOBAL env id
+    env.reset()
+    rows = []
+    for t in range(T):
+        o, r, d, info = env.step(acts[t, rank * n:(rank + 1) * n].to(dev))
+        rows.append(info["steps"].clone())
+    mine = torch.stack(rows, 1).cpu()                              # [n, T, 19]
+    ret = D.gather_episode_returns(env.episode_returns().to(torch.float32).cpu())
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(gathered, mine)
+    if rank == 0:
+        # the same 2n envs as ONE batch on one handle: shard r must equal rows [r*n, (r+1)*n)
+        big = pcc_rl_amd.BatchedNetworkEnv(world * n, device=dev, seed=9, record_steps=True, auto_reset=True, max_steps=10)
+        big.reset()
+        rows = []
+        for t in range(T):
+            o, r, d, info = big.step(acts[t].to(dev))
+            rows.append(info["steps"].clone())
+        whole = torch.stack(rows, 1).cpu()
+        assert torch.equal(torch.cat(gathered, 0), whole), "sharded results differ from the single batch"
+        assert torch.equal(ret, big.episode_returns().to(torch.float32).cpu()), "gathered episode returns differ"
+        print("shards ok")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+""") % ROOT
+
+
+@pytest.mark.gpu
+def test_two_simulator_ranks_equal_one_batch(tmp_path):
+    """Rank r of a 2-rank job holds exactly the envs [r*n, (r+1)*n) of a single 2n-env batch (results
+    and gathered episode returns), i.e. sharding over GPUs never changes a result."""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out
+    assert "shards ok" in outs[0]
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` alone (no torchrun) runs two ranks and says so in its line; with short
+    episodes the per-episode all-gather of the returns shows up too."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo",
+           "--envs", "1024", "--steps", "30", "--warmup", "5", "--repeats", "1", "--max-steps", "10", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0, res.stdout
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["episode_return_allgathers"] >= 3
+    assert out["value"] > 0 and out["steps"] == 30
+
+
+def test_bench_refuses_a_rank_count_mismatch():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode != 0 and "--gpus 8" in res.stdout
