@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Where the retire half's time goes, by phase (PCC_DEBUG_TIMELINE=1; GPU box only): per-wavefront
+time in each phase of retire_env, averaged over all wavefronts, at a few steps of an episode."""
+import json, os, sys
+os.environ.setdefault("PCC_DEBUG_TIMELINE", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import pcc_rl_amd
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+dev = torch.device("cuda:0")
+env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
+gen = torch.Generator(device=dev).manual_seed(1234)
+acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
+env.reset()
+names = {3: "state loads", 4: "boundary search", 5: "candidates+repairs", 6: "ending event", 7: "write-back",
+         8: "rtt_means", 9: "metrics+batch loads", 10: "history+obs", 11: "outputs"}
+out = []
+for t in range(310):
+    env.step(acts[t % 64])
+    if t in (20, 100, 200, 300):
+        raw = env.debug_timeline().astype(np.int64)
+        n_items = int(env.debug_pass_stats(reset=False)["items"])
+        bl = raw[n_items:].reshape(-1, 16)          # one row per retire workgroup (4 wavefronts)
+        waves = bl.shape[0] * 4
+        rec = {"step": t, "us_per_wavefront": {v: float(bl[:, k].sum()) / 100.0 / waves for k, v in names.items()}}
+        rec["us_per_wavefront"]["total"] = sum(rec["us_per_wavefront"].values())
+        out.append(rec)
+print(json.dumps(out, indent=1))
