@@ -7,6 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "pcc_sim.hip")
+SRCS = [SRC, os.path.join(HERE, "csrc", "pcc_policy.hip")]
 INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libpcc_sim.so")
@@ -21,7 +22,7 @@ def library_path():
 def _stale():
     if not os.path.exists(LIB):
         return True
-    newest = max(os.path.getmtime(p) for p in (SRC, os.path.join(INCLUDE, "pcc_sim.h")))
+    newest = max(os.path.getmtime(p) for p in SRCS + [os.path.join(INCLUDE, "pcc_sim.h"), os.path.join(INCLUDE, "pcc_policy.h")])
     return os.path.getmtime(LIB) < newest
 
 
@@ -33,7 +34,7 @@ def build_library(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build %s" % LIB)
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, SRC, "-o", LIB]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE] + SRCS + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

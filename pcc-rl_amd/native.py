@@ -31,7 +31,8 @@ FIELDS = {
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
            "pcc_set_rng", "pcc_set_seed", "pcc_set_tuning", "pcc_set_cwnd_mode", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
            "pcc_step_retire",
-           "pcc_get_state", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline", "pcc_debug_pass_stats"]
+           "pcc_get_state", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline", "pcc_debug_pass_stats",
+           "pcc_policy_act"]
 
 
 class PccError(RuntimeError):
@@ -82,6 +83,8 @@ def lib():
     L.pcc_device_bytes.argtypes = [vp]
     L.pcc_debug_timeline.restype = i64
     L.pcc_debug_timeline.argtypes = [vp, vp, i64]
+    L.pcc_policy_act.restype = i32
+    L.pcc_policy_act.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.pcc_debug_pass_stats.restype = i32
     L.pcc_debug_pass_stats.argtypes = [vp, vp, i32]
     for fn in ("pcc_create", "pcc_set_link_params", "pcc_set_param_ranges", "pcc_set_rng", "pcc_set_seed",

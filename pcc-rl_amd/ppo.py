@@ -9,8 +9,9 @@ buffers, advantage estimation, updates -- lives on the GPU and the env never lea
 
 This is a caller of the hot path, not part of it: stable-baselines is not available in this
 image, so there is nothing to check agent-level parity against.  What is
-checked: the GAE recursion against a plain loop (CPU test) and that a short run on the GPU
-improves the return.
+checked: the GAE recursion and the clipped objective against plain loops (CPU tests), that a short
+run on the GPU improves the return, and what the whole loop costs next to the env alone
+(tools/ppo_throughput.py).
 """
 import math
 
@@ -49,6 +50,35 @@ class MlpPolicy(nn.Module):
         a = d.sample() if stochastic else d.mean
         return a, d.log_prob(a).sum(-1), self.value(obs)
 
+    def flat_params(self):
+        """The parameter block pcc_policy_act reads (include/pcc_policy.h): pi {W1, b1, W2, b2, W3, b3, log_std}, vf {...}."""
+        def net(seq):
+            return [p.detach().reshape(-1) for m in seq if isinstance(m, nn.Linear) for p in (m.weight, m.bias)]
+        return torch.cat(net(self.pi) + [self.log_std.detach().reshape(-1)] + net(self.vf)).float().contiguous()
+
+    @torch.no_grad()
+    def act_fused(self, obs, stochastic=True):
+        """act() as ONE kernel launch of the HIP library (two hidden layers, one action, fp32 observations
+        on the GPU); returns (action [N, 1], log-probability [N], value [N]) like act()."""
+        import ctypes
+
+        from .native import lib
+        linears = [m for m in self.pi if isinstance(m, nn.Linear)]
+        if len(linears) != 3 or linears[2].out_features != 1 or not obs.is_cuda or obs.dtype != torch.float32:
+            return self.act(obs, stochastic)
+        n, D = obs.shape
+        params = self.flat_params()
+        noise = torch.randn(n, device=obs.device) if stochastic else None
+        a = torch.empty(n, device=obs.device)
+        logp, v = torch.empty_like(a), torch.empty_like(a)
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        rc = lib().pcc_policy_act(ptr(obs.contiguous()), n, D, ptr(params), linears[0].out_features, linears[1].out_features,
+                                  ptr(noise), None, ptr(a), ptr(logp), ptr(v),
+                                  ctypes.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+        if rc != 0:
+            return self.act(obs, stochastic)          # e.g. an observation length without a kernel instantiation
+        return a.unsqueeze(-1), logp, v
+
 
 def gae(rewards, values, dones, last_value, gamma=0.99, lam=0.95):
     """Generalised advantage estimation over [T, N] tensors.  dones[t] marks that the env was reset
@@ -64,6 +94,18 @@ def gae(rewards, values, dones, last_value, gamma=0.99, lam=0.95):
         adv[t] = running
         next_value = values[t]
     return adv, adv + values
+
+
+def ppo_loss(policy, obs, act, logp_old, adv, ret, clip=0.2, ent_coef=0.01):
+    """PPO1's objective on one minibatch: clipped surrogate + 0.5 * value error - ent_coef * entropy.
+    Returns (loss, policy term, value term, entropy)."""
+    d = policy.dist(obs)
+    logp = d.log_prob(act).sum(-1)
+    ratio = (logp - logp_old).exp()
+    pg = -torch.min(ratio * adv, ratio.clamp(1 - clip, 1 + clip) * adv).mean()
+    vf = 0.5 * (policy.value(obs) - ret).pow(2).mean()
+    ent = d.entropy().sum(-1).mean()
+    return pg + vf - ent_coef * ent, pg, vf, ent
 
 
 class PPO(object):
@@ -87,7 +129,7 @@ class PPO(object):
         done_b = torch.empty((T, N), dtype=torch.bool, device=dev)
         obs = self.obs
         for t in range(T):
-            a, logp, v = self.policy.act(obs)
+            a, logp, v = self.policy.act_fused(obs)
             obs_b[t], act_b[t], logp_b[t], val_b[t] = obs, a, logp, v
             nobs, r, d, _ = env.step(a)           # tensors in, tensors out, no host round trip
             rew_b[t], done_b[t] = r, d
@@ -95,6 +137,9 @@ class PPO(object):
         self.obs = obs
         with torch.no_grad():
             last_v = self.policy.value(obs)
+        # never train on corrupted rollouts: an overflowed in-flight ring / an empty ring pool (a trained
+        # policy can push many deep-queue envs to MAX_RATE: PCC_RING_POOLS) is flagged, not silent
+        env.check_flags()
         adv, ret = gae(rew_b, val_b, done_b, last_v, self.gamma, self.lam)
         return obs_b, act_b, logp_b, adv, ret, rew_b
 
@@ -108,19 +153,13 @@ class PPO(object):
             perm = torch.randperm(n, device=obs_f.device)
             for i in range(0, n, self.minibatch):
                 idx = perm[i:i + self.minibatch]
-                d = self.policy.dist(obs_f[idx])
-                logp = d.log_prob(act_f[idx]).sum(-1)
-                ratio = (logp - logp_f[idx]).exp()
-                a = adv_f[idx]
-                pg = -torch.min(ratio * a, ratio.clamp(1 - self.clip, 1 + self.clip) * a).mean()
-                vf = 0.5 * (self.policy.value(obs_f[idx]) - ret_f[idx]).pow(2).mean()
-                ent = d.entropy().sum(-1).mean()
-                loss = pg + vf - self.ent_coef * ent
+                loss, pg, vf, ent = ppo_loss(self.policy, obs_f[idx], act_f[idx], logp_f[idx], adv_f[idx], ret_f[idx],
+                                             self.clip, self.ent_coef)
                 self.opt.zero_grad(set_to_none=True)
                 loss.backward()
                 self.opt.step()
-                stats = {"pg": float(pg), "vf": float(vf), "entropy": float(ent)}
-        return stats
+                stats = {"pg": pg.detach(), "vf": vf.detach(), "entropy": ent.detach()}
+        return {k: float(v) for k, v in stats.items()}
 
     def iterate(self):
         obs_b, act_b, logp_b, adv, ret, rew = self.collect()

@@ -21,9 +21,12 @@ def libpath():
 
 
 def declared_functions():
-    text = open(os.path.join(ROOT, "include", "pcc_sim.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pcc_[a-z_]+)\s*\(", text)))
+    names = set()
+    for header in ("pcc_sim.h", "pcc_policy.h"):     # every header under include/
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(pcc_[a-z_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_and_binding_agree():
