@@ -96,6 +96,8 @@ enum {
 #define PCC_FLAG_POOL_EXHAUSTED 8u /* a sender needed a bigger ring tier and every pool from that tier up was empty (it may
                                       then also overflow: RING_OVERFLOW); raise the pools with PCC_RING_POOLS */
 #define PCC_FLAG_INTERNAL 4u       /* reserved (a queue protocol of an earlier build; never set) */
+#define PCC_FLAG_BAD_PARAMS 16u    /* pcc_set_link_params gave this env a link outside what the exact formulation covers
+                                      (bw in (0, 1e8], latency > 0, queue >= 1, loss in [0, 1]): results invalid */
 
 /* last error text of the calling thread ("" if none) */
 const char *pcc_last_error(void);

@@ -2200,6 +2200,8 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
 #pragma unroll
         for (int s = 0; s < NS; s++) rate0[s] = (D.lo[4] + (D.hi[4] - D.lo[4]) * u32_to_unit(w1[s])) * bw;
     }
+    // caller-supplied parameters cannot be checked on the host (device arrays): never silent
+    if (!(bw > 0.0) || !(bw <= 1e8) || !(lat > 0.0) || !(queue >= 1.0) || !(loss >= 0.0) || !(loss <= 1.0)) D.flags[i] |= PCC_FLAG_BAD_PARAMS;
     D.bw[i] = bw; D.dl[i] = lat; D.lr[i] = loss;
     D.maxq[i] = queue / bw;   // ns:64
     D.ebw[i] = 1.0 / bw;      // ns:77
@@ -2602,10 +2604,16 @@ int pcc_set_link_params(pcc_sim_t *sim, const double *bw, const double *dl, cons
 
 int pcc_set_param_ranges(pcc_sim_t *sim, const double *lo, const double *hi) {
     if (!sim || !lo || !hi) return fail(PCC_EINVAL, "NULL argument");
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < 5; k++)
         if (!(lo[k] <= hi[k])) return fail(PCC_EINVAL, "range %d is empty", k);
-        sim->d.lo[k] = lo[k]; sim->d.hi[k] = hi[k];
-    }
+    // what the exact formulation rests on: a physical link -- positive one-way
+    // delay, 1/bw >= 1e-8 s -- a queue of at least one packet, a probability, a positive starting rate
+    if (!(lo[0] > 0.0) || !(hi[0] <= 1e8)) return fail(PCC_EINVAL, "bandwidth range must lie in (0, 1e8] packets/s");
+    if (!(lo[1] > 0.0) || !(hi[1] <= 1e6)) return fail(PCC_EINVAL, "latency range must lie in (0, 1e6] s");
+    if (!(lo[2] >= 0.0) || !(hi[2] <= 20.0)) return fail(PCC_EINVAL, "queue exponent range must lie in [0, 20] (queue = 1 + floor(e^x))");
+    if (!(lo[3] >= 0.0) || !(hi[3] <= 1.0)) return fail(PCC_EINVAL, "loss range must lie in [0, 1]");
+    if (!(lo[4] > 0.0)) return fail(PCC_EINVAL, "the starting-rate factor must be positive");
+    for (int k = 0; k < 5; k++) { sim->d.lo[k] = lo[k]; sim->d.hi[k] = hi[k]; }
     return PCC_OK;
 }
 

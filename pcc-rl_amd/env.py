@@ -46,7 +46,7 @@ class BatchedNetworkEnv(object):
     (S=1) or ``[N, S, H*F]`` float32, oldest monitor interval first; reward ``[N]`` or
     ``[N, S]`` float32; done ``[N]`` bool.  With ``auto_reset`` (default) an env that reaches
     ``max_steps`` is reset inside the same ``step`` call and its obs row is the first
-    observation of the next episode; ``info["episode_return"]`` then holds the finished return.
+    observation of the next episode; ``episode_returns()`` holds the finished return per env.
 
     The tensors returned by ``reset``/``step`` are the env's own output buffers: they are
     overwritten by the next call (pass ``new_tensors=True`` to get fresh ones each call).
@@ -225,7 +225,8 @@ class BatchedNetworkEnv(object):
         info = {}
         if self._steps is not None:
             info["steps"] = self._out(self._steps)
-        return self._out(self._obs), self._out(self._reward), self._done.view(torch.bool), info
+        done = self._done.clone() if self.new_tensors else self._done
+        return self._out(self._obs), self._out(self._reward), done.view(torch.bool), info
 
     def step(self, actions):
         """One monitor interval for every env (ns:407-446 batched): obs, reward, done, info.  One
@@ -251,15 +252,16 @@ class BatchedNetworkEnv(object):
         return r[0] if self.n_senders == 1 else r
 
     def check_flags(self):
-        """Raise if any env overflowed its in-flight ring or ran out of loss trace."""
+        """Raise if any env overflowed its in-flight ring, ran out of loss trace, found the ring pools empty
+        or was given link parameters outside what the simulator covers."""
         flags = self.state("flags")
         bad = int((flags != 0).sum().item())
         if bad:
-            over = int(((flags & native.PCC_FLAG_RING_OVERFLOW) != 0).sum().item())
-            tr = int(((flags & native.PCC_FLAG_TRACE_OVERRUN) != 0).sum().item())
-            pool = int(((flags & native.PCC_FLAG_POOL_EXHAUSTED) != 0).sum().item())
-            raise PccError(-6, "%d envs overflowed the in-flight ring, %d ran past the loss trace, %d found the "
-                               "ring pools empty (PCC_RING_POOLS)" % (over, tr, pool))
+            count = lambda bit: int(((flags & bit) != 0).sum().item())
+            raise PccError(-6, "%d envs overflowed the in-flight ring, %d ran past the loss trace, %d found the ring pools "
+                               "empty (PCC_RING_POOLS), %d have link parameters out of range"
+                           % (count(native.PCC_FLAG_RING_OVERFLOW), count(native.PCC_FLAG_TRACE_OVERRUN),
+                              count(native.PCC_FLAG_POOL_EXHAUSTED), count(native.PCC_FLAG_BAD_PARAMS)))
 
     @property
     def device_bytes(self):

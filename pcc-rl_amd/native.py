@@ -8,7 +8,7 @@ import os
 from .build import library_path
 
 PCC_RNG_PHILOX, PCC_RNG_TRACE = 0, 1
-PCC_FLAG_RING_OVERFLOW, PCC_FLAG_TRACE_OVERRUN, PCC_FLAG_INTERNAL, PCC_FLAG_POOL_EXHAUSTED = 1, 2, 4, 8
+PCC_FLAG_RING_OVERFLOW, PCC_FLAG_TRACE_OVERRUN, PCC_FLAG_INTERNAL, PCC_FLAG_POOL_EXHAUSTED, PCC_FLAG_BAD_PARAMS = 1, 2, 4, 8, 16
 PCC_STEP_COLS = 19
 STEP_COLUMNS = ["sent", "acked", "lost", "rate", "cur_time", "run_dur", "reward",
                 "send rate", "recv rate", "recv dur", "send dur", "avg latency", "loss ratio",

@@ -581,3 +581,27 @@ def test_grouped_env_is_the_same_envs_on_several_streams():
         assert torch.equal(torch.cat(got_obs[t], 0), ref_obs[t]), t
         assert torch.equal(torch.cat(got_rew[t], 0), ref_rew[t]), t
     one.close(); grp.close()
+
+
+def test_parameter_ranges_are_validated():
+    """What the exact formulation rests on (a physical link) is checked, not assumed: bad sampling ranges are
+    refused by the C ABI, bad caller-supplied link arrays are flagged per env at reset."""
+    env = pcc_rl_amd.BatchedNetworkEnv(64, device=DEV, seed=1)
+    for lo, hi in [((0.0, 0.05, 0, 0.0, 0.3), (500, 0.5, 8, 0.05, 1.5)),      # bandwidth may be 0
+                   ((100, 0.0, 0, 0.0, 0.3), (500, 0.5, 8, 0.05, 1.5)),       # latency may be 0
+                   ((100, 0.05, 0, 0.0, 0.3), (500, 0.5, 8, 1.5, 1.5)),       # loss probability > 1
+                   ((100, 0.05, 0, 0.0, 0.3), (2e8, 0.5, 8, 0.05, 1.5))]:     # 1/bw below 1e-8 s
+        with pytest.raises(pcc_rl_amd.PccError):
+            env.randomize_link_params((lo, hi))
+    env.randomize_link_params(((100, 0.05, 0, 0.0, 0.3), (500, 0.5, 8, 0.05, 1.5)))
+    env.reset()
+    env.check_flags()
+    bw = torch.full((64,), 200.0, dtype=torch.float64)
+    bw[5] = 0.0
+    env.set_link_params(bw, 0.03, 5.0, 0.0, 60.0)
+    env.reset()
+    flags = env.state("flags").cpu().numpy()
+    assert flags[5] & 16 and not (np.delete(flags, 5) & 16).any()
+    with pytest.raises(pcc_rl_amd.PccError):
+        env.check_flags()
+    env.close()
