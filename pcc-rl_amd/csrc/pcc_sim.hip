@@ -1318,25 +1318,38 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
         if (lane < (uint32_t)kClsStride) D.cls_count[zero_buf * kClsStride + lane] = 0u;
         if (lane < kShards) D.cursors[((uint32_t)zero_buf * kShards + lane) * kCursorStride] = 0u;
     }
-    // ---- item table: lane l < kClasses holds class kClasses-1-l (heaviest first)
+    // ---- item table, longest items first: lane l < kClasses looks after class kClasses-1-l and ranks it
+    // by how long one of its items runs -- an env on the wave path costs ~12 ns per packet, a light item
+    // lasts as long as its lanes, ~0.4 us per packet of the class -- so the giants and the long light
+    // items start at once and the short items fill in behind them.
     const bool listed = read_buf >= 0;
     const int cls_mine = kClasses - 1 - (int)lane;
     const int cls_heavy = D.use_cwnd ? kClasses : (D.heavy_predict >= 1e9 ? kClasses : class_of((float)D.heavy_predict));
     uint32_t n_mine = 0, items_mine = 0;
+    float est = -1.0f;  // lanes without a class sort last
     if (listed && lane < (uint32_t)kClasses) {
         n_mine = D.cls_count[read_buf * kClsStride + cls_mine];
-        items_mine = cls_mine >= cls_heavy ? n_mine : (n_mine + E - 1) / E;
+        const bool hv = cls_mine >= cls_heavy;
+        items_mine = hv ? n_mine : (n_mine + E - 1) / E;
+        const float pk = 8.0f * __expf(0.22314355f * ((float)cls_mine - 0.5f));  // 8 * 1.25^(c - 1/2)
+        est = pk * (hv ? 0.012f : 0.4f);
     }
-    uint32_t incl = items_mine;  // inclusive prefix over lanes 0..31
+    uint32_t rank = 0;  // classes that go before mine
+    for (uint32_t l = 0; l < (uint32_t)kClasses; l++) {
+        const float other = __shfl(est, (int)l);
+        rank += (other > est || (other == est && l < lane)) ? 1u : 0u;
+    }
+    // the table lives in LDS (one copy per wavefront: no barrier needed), indexed by rank
+    __shared__ uint32_t s_tab[4][4][kClasses];
+    uint32_t (*tab)[kClasses] = s_tab[threadIdx.x / kWave];
+    if (lane < (uint32_t)kClasses) { tab[1][rank] = items_mine; tab[2][rank] = n_mine; tab[3][rank] = (uint32_t)cls_mine; }
+    uint32_t incl = lane < (uint32_t)kClasses ? tab[1][lane] : 0u;  // inclusive prefix in rank order
     for (int o = 1; o < kClasses; o <<= 1) {
         const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
         if (lane >= (uint32_t)o) incl += up;
     }
+    if (lane < (uint32_t)kClasses) tab[0][lane] = incl;
     const uint32_t n_items = listed ? rl_u32(incl, kClasses - 1) : (uint32_t)((D.n + E - 1) / E);
-    // the table goes to LDS (one copy per wavefront: no barrier needed), not to registers the items need
-    __shared__ uint32_t s_tab[4][3][kClasses];
-    uint32_t (*tab)[kClasses] = s_tab[threadIdx.x / kWave];
-    if (lane < (uint32_t)kClasses) { tab[0][lane] = incl; tab[1][lane] = items_mine; tab[2][lane] = n_mine; }
     if (D.pass_stats && wave == 0 && lane == 0) D.pass_stats[15] = n_items;
     uint32_t *cursors = D.cursors + (uint32_t)(listed ? read_buf : 2) * kShards * kCursorStride;
     const uint32_t s_mine = wave % kShards, c0 = n_waves / kShards;
@@ -1362,7 +1375,7 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
         if (listed) {
             const uint64_t above = __ballot(lane < (uint32_t)kClasses && tab[0][lane & (kClasses - 1)] > t);
             const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
-            const int cls = kClasses - 1 - (int)L;
+            const int cls = (int)tab[3][L];
             const uint32_t off = t - (tab[0][L] - tab[1][L]);
             const uint32_t n_cls = tab[2][L];
             const uint32_t *list = D.cls_list + ((size_t)read_buf * kClasses + cls) * (size_t)D.n;

@@ -27,12 +27,8 @@ acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
 env.reset()
 out = []
 sample = {2, 10, 30, 60, 100, 150, 200, 250, 300, 350, 398}
-FUSED = False
 for t in range(400):
-    if FUSED:
-        env.step(acts[t % 64])
-    else:
-        env.step_send(acts[t % 64])
+    env.step_send(acts[t % 64])
     if t in sample:
         raw = env.debug_timeline().astype(np.int64)
         n_items = int(env.debug_pass_stats(reset=False)["items"])
@@ -65,19 +61,18 @@ for t in range(400):
                               "ns_per_iteration": float(1e3 * dur[lt_].sum() / max(1, tl[lt_, 5].sum())),
                               "lane_efficiency": float(tl[lt_, 4].sum() / max(1, 64 * tl[lt_, 5].sum())),
                               "rounds_share": float((mid[lt_] - start[lt_]).sum() / max(1e-9, dur[lt_].sum()))}
-        if FUSED:
-            pub, ext = (bl[:, 0] - t0) / 100.0, (bl[:, 1] - t0) / 100.0
-            rec["block_published_us"] = pct(pub)
-            rec["block_exit_us"] = pct(ext)
-            rec["kernel_span_us"] = float(ext.max())
-            rec["items_per_block_min_p50_max"] = [int(bl[:, 2].min()), int(np.median(bl[:, 2])), int(bl[:, 2].max())]
-            items = max(1, int(bl[:, 2].sum()))
-            names = {3: "state loads", 4: "boundary search", 5: "candidates+repairs", 6: "ending event", 7: "write-back",
-                     8: "rtt_means", 9: "metrics", 10: "history+obs", 11: "outputs"}
-            rec["retire_us_per_wave_item"] = {v: float(bl[:, k].sum()) / 100.0 / items for k, v in names.items()}
-            last = np.argsort(-pub)[:3]
-            rec["last_published"] = [{"published": float(pub[i]), "exit": float(ext[i]), "items": int(bl[i, 2])} for i in last]
+        # the critical path of the launch: its span against the longest single item of each kind
+        ih = int(np.argmax(np.where(hv, dur, -1.0))) if hv.any() else -1
+        il = int(np.argmax(np.where(lt_, dur, -1.0))) if lt_.any() else -1
+        rec["critical_path"] = {
+            "launch_span_us": float(fin.max()),
+            "longest_heavy_item": None if ih < 0 else {"us": float(dur[ih]), "start_us": float(start[ih]), "packets": int(tl[ih, 4]),
+                                                       "ns_per_packet": float(1e3 * dur[ih] / max(1, tl[ih, 4]))},
+            "heaviest_env": None if not hv.any() else {"packets": int(tl[hv, 4].max()),
+                                                       "us": float(dur[hv][int(np.argmax(tl[hv, 4]))])},
+            "longest_light_item": None if il < 0 else {"us": float(dur[il]), "start_us": float(start[il]),
+                                                       "lane_iterations": int(tl[il, 5]), "ns_per_iteration": float(1e3 * dur[il] / max(1, tl[il, 5]))},
+            "mean_busy_fraction_of_wavefronts": float(dur.sum() / (fin.max() * 256 * 16))}
         out.append(rec)
-    if not FUSED:
-        env.step_retire()
+    env.step_retire()
 print(json.dumps(out, indent=1))
