@@ -238,7 +238,8 @@ int64_t pcc_device_bytes(const pcc_sim_t *sim);
  * of its lane rounds, end (100 MHz device ticks), envs it sent with the wave path, packets it
  * sent, packets of its largest env, packets sent by the wave path, live lanes -- item t at word
  * 8 t, items in the order they were handed out (heaviest first).  After the items come 16 words per
- * retire workgroup (time by phase, summed over its wavefronts).  Synchronizes the device.  Returns
+ * retire workgroup (word 0 / 1: start / end of the workgroup in the last launch; words 3..11: time by
+ * phase, summed over its wavefronts and over the launches so far).  Synchronizes the device.  Returns
  * the number of words -- copied, or needed when out is NULL; 0 when the timeline is off, < 0 on
  * error. */
 int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words);

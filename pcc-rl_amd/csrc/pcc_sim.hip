@@ -42,6 +42,7 @@
 //                  its predicted packet count for the next send.
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 
 #include <cmath>
 #include <cstdarg>
@@ -62,6 +63,9 @@ constexpr int kMaxSenders = 2;
 constexpr int kWave = 64;
 constexpr int kGroup = 16;            // lanes per env in retire_kernel
 constexpr int kRetireBlock = 256;     // 16 envs per workgroup
+#ifndef PCC_RETIRE_OCC
+#define PCC_RETIRE_OCC 4  // retire workgroups per SIMD the register budget is cut for: 5 spills (48 B/lane) and is slower
+#endif
 constexpr double kMaxRate = 1000.0;      // ns:36
 constexpr double kMinRate = 40.0;        // ns:37
 constexpr double kRewardScale = 0.001;   // ns:39
@@ -87,6 +91,42 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr int kMaxTiers = 4;
 
+// State of an env and of a sender, one 128-byte line each: an env's fields share a line instead of
+// sharing it with the same field of 15 other envs -- both halves walk the envs in work-list order, so
+// neighbours in a wavefront are not neighbours in memory.
+// Fields are grouped in 16-byte pieces by who writes them, so that each half loads and writes an env
+// with a few wide instructions: many narrow stores to ONE line queue up behind each other in the L2
+// channel that owns it (measured: the same retire half ran 25 % slower with one 4/8-byte store per field).
+struct alignas(128) EnvBlk {
+    double bw, dl;    //   0  the episode's link (reset)
+    double lr, maxq;  //  16
+    double ebw;       //  32
+    uint32_t episode;
+    uint32_t cwnd;    //      the reference's dormant USE_CWND option (ns:54): window in packets (ns:227: 25 at reset)
+    double q, tu;     //  48  link queue: send half, and the retire half's MI-ending event
+    double now, run_dur;            //  64  retire half
+    unsigned long long total_sent;  //  80  retire half
+    uint32_t steps;
+    uint8_t done, resetting;
+    uint8_t pad0[2];
+    uint32_t mi_draws;  //  96  send half: link-entry draws of the MI (a SEND the window blocks still draws)
+    uint32_t ep_draws;  //      ... of the episode: the position in a replayed loss trace
+    uint32_t flags;
+    uint32_t pad1;
+};
+struct alignas(128) SndBlk {
+    double rate, rate0;          //  0  send half (rate)
+    double next_send, min_lat;   // 16  both halves / retire half
+    double ep_return, last_return;  // 32  retire half
+    char *ring_base;             // 48  accepted ring of the sender (the dropped ring follows it)
+    uint8_t ring_tier;
+    uint8_t pad0[7];
+    uint32_t ha, hd, ta, td;     // 64  accepted/dropped ring heads and tails
+    uint32_t mi_sent;            // 80
+    uint32_t ring_held[kMaxTiers];  // pool slot + 1 the sender holds in tier c (0 = none) until reset
+};
+static_assert(sizeof(EnvBlk) == 128 && sizeof(SndBlk) == 128, "one line per block");
+
 // Everything a kernel needs, passed by value.
 struct Dev {
     int64_t n;
@@ -100,9 +140,6 @@ struct Dev {
     char *tier_base[kMaxTiers];
     uint32_t *tier_free[kMaxTiers];  // [tier_slots[c]] free slot ids (a stack; c >= 1)
     int32_t *tier_top;               // [kMaxTiers] stack heights
-    char **ring_base;                // [S][N] accepted ring of the sender (dropped ring follows it)
-    uint8_t *ring_tier;              // [S][N]
-    uint32_t *ring_held;             // [S][N][kMaxTiers] pool slot + 1 the sender holds in tier c (0 = none) until reset
     uint32_t key0, key1, gid_base;
     double delta_scale;
     uint32_t max_steps;
@@ -114,6 +151,7 @@ struct Dev {
     unsigned long long *pass_stats;  // profiling only (same switch): counters of the wave passes, see pcc_debug_pass_stats
     int pass_counters;               // ... per-pass counters on (PCC_DEBUG_TIMELINE=2: contended atomics, they slow the passes down)
     uint32_t send_wg_waves;  // tuning: wavefronts per send workgroup (each works on its own)
+    uint32_t retire_sorted;  // debug: 0 = the retire launch walks the envs in index order even when there are lists
     int debug_skip;  // profiling only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs
     uint32_t round_packets, takeover_lanes, send_envs_per_wave, send_waves;
     double heavy_predict;  // predicted packets per MI above which an env goes to the heavy wave
@@ -122,19 +160,10 @@ struct Dev {
     const double *trace;
     int64_t trace_stride;
     const double *p_bw, *p_dl, *p_queue, *p_loss, *p_rate0;
-    // link + env state, [N]
-    double *bw, *dl, *lr, *maxq, *ebw, *q, *tu, *now, *run_dur;
-    uint32_t *steps, *episode, *flags;
-    uint8_t *done, *resetting;
-    unsigned long long *total_sent;
-    // per sender, [S][N]
-    double *rate, *rate0, *next_send, *min_lat, *ep_return, *last_return;
-    uint32_t *ha, *hd, *ta, *td, *mi_sent;  // accepted/dropped ring heads and tails
+    EnvBlk *env;  // [N] link + env state, one 128-byte block per env
+    SndBlk *snd;  // [S][N] per sender, one 128-byte block each
     // the reference's dormant USE_CWND engine option (ns:54), one sender only
     int use_cwnd;
-    uint32_t *cwnd;        // [N] congestion window, packets (ns:227: 25 for every new sender)
-    uint32_t *mi_draws;    // [N] link-entry draws of the MI made by the send half (a SEND the window blocks still draws)
-    uint32_t *ep_draws;    // [N] ... of the episode: the position in a replayed loss trace
     float *hist;    // [N][S][HF]
     double2 *ring;  // [N][S][2][cap]: accepted ring, dropped ring
 };
@@ -249,8 +278,8 @@ __device__ __forceinline__ size_t tier_slot_bytes(const Dev &D, uint32_t tier) {
 
 __device__ __forceinline__ RingRef ring_ref(const Dev &D, int64_t k /* s * n + i */) {
     RingRef r;
-    r.base = D.ring_base[k];
-    r.cap = tier_cap(D, D.ring_tier[k]);
+    r.base = D.snd[k].ring_base;
+    r.cap = tier_cap(D, D.snd[k].ring_tier);
     return r;
 }
 
@@ -307,9 +336,9 @@ __device__ __forceinline__ bool promote_rings(const Dev &D, uint32_t lane, uint3
     for (uint32_t j = lane; j < n_a; j += kWave) st_rec(to.accepted() + ((h_a + j) & to.mask()), ld_rec(from.accepted() + ((h_a + j) & from.mask())));
     for (uint32_t j = lane; j < n_d; j += kWave) st_rec(to.dropped() + ((h_d + j) & to.dmask()), ld_rec(from.dropped() + ((h_d + j) & from.dmask())));
     if (lane == l) {
-        D.ring_base[k] = to.base;
-        D.ring_tier[k] = (uint8_t)got;
-        D.ring_held[k * kMaxTiers + got] = slot + 1u;
+        D.snd[k].ring_base = to.base;
+        D.snd[k].ring_tier = (uint8_t)got;
+        D.snd[k].ring_held[got] = slot + 1u;
     }
     return true;
 }
@@ -898,18 +927,18 @@ template <int NS, bool TRACE>
 __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, const int64_t i, const bool in_range,
                                           const bool heavy_wave, const uint32_t tl_slot, int warm, uint32_t warm_mi,
                                           const void *actions, int actions_f64) {
-    const bool live = in_range && !(warm && !D.resetting[in_range ? i : 0]);
+    const bool live = in_range && !(warm && !D.env[in_range ? i : 0].resetting);
     if (!__ballot(live)) return;
     const int64_t ii = live ? i : 0;
     const uint64_t tl0 = D.timeline ? wall_clock64() : 0;
     uint64_t tl1 = 0, tl_heavy = 0, tl_heavy_pk = 0;
 
-    const double dl = D.dl[ii], lr = D.lr[ii], maxq = D.maxq[ii], ebw = D.ebw[ii];
-    double q = D.q[ii], tu = D.tu[ii];
-    const double now = D.now[ii];
-    const double end = now + D.run_dur[ii];  // ns:124
-    const uint32_t episode = D.episode[ii] - 1;
-    const uint32_t mi = warm ? warm_mi : D.steps[ii] + 2;
+    const double dl = D.env[ii].dl, lr = D.env[ii].lr, maxq = D.env[ii].maxq, ebw = D.env[ii].ebw;
+    double q = D.env[ii].q, tu = D.env[ii].tu;
+    const double now = D.env[ii].now;
+    const double end = now + D.env[ii].run_dur;  // ns:124
+    const uint32_t episode = D.env[ii].episode - 1;
+    const uint32_t mi = warm ? warm_mi : D.env[ii].steps + 2;
     const uint32_t gid = D.gid_base + (uint32_t)ii;
     uint32_t flags = 0;
 
@@ -918,7 +947,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + ii;
-        double rate = D.rate[k];
+        double rate = D.snd[k].rate;
         if (!warm && live) {
             const int64_t a = D.use_cwnd ? ii * 2 : ii * NS + s;  // USE_CWND: [rate action, cwnd action] per env
             double delta = actions_f64 ? ((const double *)actions)[a] : (double)((const float *)actions)[a];
@@ -926,12 +955,12 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
             rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
             if (rate > kMaxRate) rate = kMaxRate;
             if (rate < kMinRate) rate = kMinRate;
-            D.rate[k] = rate;
+            D.snd[k].rate = rate;
         }
         gap[s] = 1.0 / rate;  // ns:161
-        nsend[s] = D.next_send[k];
-        ta[s] = D.ta[k]; td[s] = D.td[k];
-        ha[s] = D.ha[k]; hd[s] = D.hd[k];
+        nsend[s] = D.snd[k].next_send;
+        ta[s] = D.snd[k].ta; td[s] = D.snd[k].td;
+        ha[s] = D.snd[k].ha; hd[s] = D.snd[k].hd;
         sent[s] = 0;
     }
     const double *trace = TRACE ? D.trace + ii * D.trace_stride : nullptr;
@@ -950,7 +979,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
             const uint32_t n_max = ahead < 1e9 ? (uint32_t)ahead : 1000000000u;
             want = tier_for(D, ta[s] - ha[s] + n_max, td[s] - hd[s] + n_max);
         }
-        uint64_t pm = __ballot(run && want > (uint32_t)D.ring_tier[k] && want < (uint32_t)D.n_tiers);
+        uint64_t pm = __ballot(run && want > (uint32_t)D.snd[k].ring_tier && want < (uint32_t)D.n_tiers);
         while (pm) {
             const uint32_t l = (uint32_t)__ffsll((unsigned long long)pm) - 1u;
             pm &= pm - 1ull;
@@ -974,20 +1003,20 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
             // time, ns:42-43) is no longer in flight.  A blocked SEND still passes through the link's
             // queue and takes its loss draw (ns:170-175 are outside the `if`): it updates (q, tu) and
             // the RNG position, but leaves no record and is not counted as sent.
-            uint32_t cw = D.cwnd[ii];
+            uint32_t cw = D.env[ii].cwnd;
             if (!warm && live) {  // apply_cwnd_delta + set_cwnd: ns:243-249, 283-289
                 const int64_t ai = ii * 2 + 1;
                 double delta = actions_f64 ? ((const double *)actions)[ai] : (double)((const float *)actions)[ai];
                 delta *= D.delta_scale;
                 const double c = delta >= 0.0 ? (double)cw * (1.0 + delta) : (double)cw / (1.0 - delta);
                 cw = c >= 5000.0 ? 5000u : (c < 4.0 ? 4u : (uint32_t)c);  // int(), then [MIN_CWND, MAX_CWND] (ns:33-34)
-                D.cwnd[ii] = cw;
+                D.env[ii].cwnd = cw;
             }
             const double2 *acc = rings[0].accepted(), *drp = rings[0].dropped();
             const uint32_t amask_r = rings[0].mask(), dmask_r = rings[0].dmask();
             double t = nsend[0];
             uint32_t a = ta[0], d = td[0], pa = ha[0], pd = hd[0], draws = 0, nsent = 0;
-            const uint32_t ep0 = D.ep_draws[ii];
+            const uint32_t ep0 = D.env[ii].ep_draws;
             while (run && t < end) {
                 while (pa != a && ld_t1(acc + (pa & amask_r)) + dl <= t) pa++;
                 while (pd != d && ld_t1(drp + (pd & dmask_r)) + dl <= t) pd++;
@@ -1025,8 +1054,8 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
                 t += gap[0];  // ns:161: the next SEND is scheduled either way
             }
             if (live) {
-                D.mi_draws[ii] = draws;
-                D.ep_draws[ii] = ep0 + draws;
+                D.env[ii].mi_draws = draws;
+                D.env[ii].ep_draws = ep0 + draws;
             }
             nsend[0] = t;
             sent[0] = nsent;
@@ -1261,17 +1290,17 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
         }
     }
     if (!live) return;
-    D.q[i] = q; D.tu[i] = tu;
+    D.env[i].q = q; D.env[i].tu = tu;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         // never silent: more packets in flight than a ring holds means records were overwritten
         if (ta[s] - ha[s] > rings[s].cap || td[s] - hd[s] > 2u * rings[s].cap) flags |= PCC_FLAG_RING_OVERFLOW;
         const int64_t k = (int64_t)s * D.n + i;
-        D.next_send[k] = nsend[s];
-        D.ta[k] = ta[s]; D.td[k] = td[s];
-        D.mi_sent[k] = sent[s];
+        D.snd[k].next_send = nsend[s];
+        D.snd[k].ta = ta[s]; D.snd[k].td = td[s];
+        D.snd[k].mi_sent = sent[s];
     }
-    if (flags) D.flags[i] |= flags;
+    if (flags) D.env[i].flags |= flags;
 }
 
 // ---- work lists ----------------------------------------------------------------------------
@@ -1859,12 +1888,13 @@ template <int NS>
 __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const Group g, int warm, uint32_t warm_mi,
                                             int last_warm, float *obs_out, float *reward_out, uint8_t *done_out,
                                             double *steps_out) {
-    if (warm && !D.resetting[i]) return -1.0f;
+    if (warm && !D.env[i].resetting) return -1.0f;
     const bool lead = g.lane == 0;
     // profiling only: where a wavefront's retire time goes (lane 0's view), summed per workgroup
     const bool tl = D.timeline != nullptr && (threadIdx.x & (kWave - 1)) == 0;
     uint64_t *tlw = D.timeline ? D.timeline + (int64_t)2 * D.n * 8 + (int64_t)blockIdx.x * 16 : nullptr;
     uint64_t tl_t = tl ? wall_clock64() : 0;
+    if (tl && threadIdx.x == 0) tlw[0] = tl_t;  // this launch's start of the workgroup (slot 1: its end)
 #define PCC_TL_STAMP(slot)                                                                               \
     if (tl) {                                                                                            \
         const uint64_t t_now = wall_clock64();                                                           \
@@ -1872,11 +1902,12 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         tl_t = t_now;                                                                                    \
     }
 
-    const double dl = D.dl[i];
-    const double start = D.now[i];
-    const double run_dur = D.run_dur[i];
+    const double dl = D.env[i].dl;
+    const double start = D.env[i].now;
+    const double run_dur = D.env[i].run_dur;
     const double end = start + run_dur;  // ns:124
-    const uint32_t steps = D.steps[i];
+    const uint32_t steps = D.env[i].steps;
+    const unsigned long long total_before = D.env[i].total_sent;
     double now = start;
 
     double nsend[NS];
@@ -1886,9 +1917,9 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
-        nsend[s] = D.next_send[k];
-        ha[s] = D.ha[k]; hd[s] = D.hd[k]; ta[s] = D.ta[k]; td[s] = D.td[k];
-        sent[s] = D.mi_sent[k];
+        nsend[s] = D.snd[k].next_send;
+        ha[s] = D.snd[k].ha; hd[s] = D.snd[k].hd; ta[s] = D.snd[k].ta; td[s] = D.snd[k].td;
+        sent[s] = D.snd[k].mi_sent;
         acked[s] = lost[s] = 0;
         from[s] = ha[s];
         const RingRef rr = ring_ref(D, k);
@@ -1985,7 +2016,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                 }
             } else if (best == 3 * s + 2) {  // SEND: one more packet leaves (ns:155-178)
                 const double t = nsend[s];
-                double q = D.q[i], tu = D.tu[i];
+                double q = D.env[i].q, tu = D.env[i].tu;
                 double u;
                 if (D.rng_mode == PCC_RNG_TRACE) {
                     uint64_t pos = 0;
@@ -1997,24 +2028,24 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                     uint32_t j = 0;
 #pragma unroll
                     for (int x = 0; x < NS; x++) j += sent[x];
-                    if (D.use_cwnd) j = D.mi_draws[i];  // draws, not packets: blocked SENDs drew too
-                    u = philox_packet_uniform(D, D.gid_base + (uint32_t)i, D.episode[i] - 1,
+                    if (D.use_cwnd) j = D.env[i].mi_draws;  // draws, not packets: blocked SENDs drew too
+                    u = philox_packet_uniform(D, D.gid_base + (uint32_t)i, D.env[i].episode - 1,
                                               warm ? warm_mi : steps + 2, j);
                 }
                 if (D.use_cwnd && D.rng_mode == PCC_RNG_TRACE) {
-                    const uint32_t pos = D.ep_draws[i];
+                    const uint32_t pos = D.env[i].ep_draws;
                     if ((int64_t)pos >= D.trace_stride) { flags |= PCC_FLAG_TRACE_OVERRUN; u = 1.0; }
                     else u = D.trace[i * D.trace_stride + pos];
                 }
                 // USE_CWND (ns:251-255): everything due before this event is retired, so what is in
                 // flight is exactly what the rings still hold
-                const bool can_send = !D.use_cwnd || (ta[s] - ha[s]) + (td[s] - hd[s]) < D.cwnd[i];
-                if (D.use_cwnd && lead) D.ep_draws[i] += 1u;
-                const double rate = D.rate[(int64_t)s * D.n + i];
+                const bool can_send = !D.use_cwnd || (ta[s] - ha[s]) + (td[s] - hd[s]) < D.env[i].cwnd;
+                if (D.use_cwnd && lead) D.env[i].ep_draws += 1u;
+                const double rate = D.snd[(int64_t)s * D.n + i].rate;
                 sent[s] += can_send ? 1u : 0u;
                 nsend[s] = t + 1.0 / rate;
                 bool dropped;
-                const double2 rec = link_send(t, u < D.lr[i], dl, D.maxq[i], D.ebw[i], q, tu, dropped);
+                const double2 rec = link_send(t, u < D.env[i].lr, dl, D.env[i].maxq, D.env[i].ebw, q, tu, dropped);
                 if (!can_send) {
                     // blocked by the window: the link saw it (queue, draw), nothing is in flight
                 } else if (dropped) {
@@ -2025,7 +2056,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                     ta[s]++;
                 }
                 if (ta[s] - ha[s] > amask[s] + 1u || td[s] - hd[s] > dmasks[s] + 1u) flags |= PCC_FLAG_RING_OVERFLOW;
-                if (lead) { D.q[i] = q; D.tu[i] = tu; }
+                if (lead) { D.env[i].q = q; D.env[i].tu = tu; }
             }
         }
         (void)l_h2;
@@ -2037,20 +2068,24 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
 #pragma unroll
     for (int s = 0; s < NS; s++) sent_total += sent[s];
     if (lead) {
-        D.now[i] = now;
-        if (flags) D.flags[i] |= flags;
-        atomicAdd(&D.total_sent[i], sent_total);  // no return value: nothing waits for the old count
+        if (flags) D.env[i].flags |= flags;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             const int64_t k = (int64_t)s * D.n + i;
-            D.next_send[k] = nsend[s];
-            D.ha[k] = ha[s]; D.hd[k] = hd[s]; D.ta[k] = ta[s]; D.td[k] = td[s];
+            D.snd[k].ha = ha[s]; D.snd[k].hd = hd[s]; D.snd[k].ta = ta[s]; D.snd[k].td = td[s];  // one 16-byte store
         }
     }
     if (warm) {  // reset(): the two warm-up MIs are not recorded (ns:478-479)
-        if (lead && last_warm) D.resetting[i] = 0;
+        if (lead) {
+            D.env[i].now = now;
+            D.env[i].total_sent = total_before + sent_total;
+#pragma unroll
+            for (int s = 0; s < NS; s++) D.snd[(int64_t)s * D.n + i].next_send = nsend[s];
+            if (last_warm) D.env[i].resetting = 0;
+        }
         return -1.0f;
     }
+    // (the rest of the env's state is written at the end, next to its neighbours in the block)
 
     // ---- metrics, history, observation, reward: ns:416-438 with so:44-73
     bool need_halves = steps_out != nullptr;
@@ -2080,9 +2115,9 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                 if (x < keep) old_row[b] = hist[x + D.F];
             }
         }
-        double min_lat = D.min_lat[k];
-        const double ep_before = D.ep_return[k];
-        const double rate_now = D.rate[k];
+        double min_lat = D.snd[k].min_lat;
+        const double ep_before = D.snd[k].ep_return;
+        const double rate_now = D.snd[k].rate;
         rate_sum += rate_now;
         double m[PCC_N_METRICS];
         mi_metrics(sent[s], acked[s], lost[s], dur, lat, inc, min_lat, m);
@@ -2117,11 +2152,11 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         }
         PCC_TL_STAMP(10)  // history + observation
         if (lead) {
-            D.min_lat[k] = min_lat;
-            if (reward_out) reward_out[i * NS + s] = (float)reward;
             const double ret = ep_before + reward;
-            D.ep_return[k] = ret;
-            if (steps + 1 >= D.max_steps) D.last_return[k] = ret;
+            D.snd[k].next_send = nsend[s]; D.snd[k].min_lat = min_lat;  // 16 bytes
+            D.snd[k].ep_return = ret;
+            if (steps + 1 >= D.max_steps) D.snd[k].last_return = ret;
+            if (reward_out) reward_out[i * NS + s] = (float)reward;
         }
         if (steps_out && g.lane < PCC_N_METRICS)
             steps_out[(i * NS + s) * PCC_STEP_COLS + PCC_COL_METRIC0 + g.lane] = select_metric(m, (int)g.lane);
@@ -2138,46 +2173,96 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
     if (lead) {
         if (steps_out)
             for (int s = 0; s < NS; s++) steps_out[(i * NS + s) * PCC_STEP_COLS + PCC_COL_RUN_DUR] = new_run_dur;
-        D.run_dur[i] = new_run_dur;
-        D.steps[i] = steps + 1;
         const uint8_t done = (steps + 1 >= D.max_steps) ? 1 : 0;  // ns:444
-        D.done[i] = done;
+        D.env[i].now = now; D.env[i].run_dur = new_run_dur;  // 16 bytes
+        D.env[i].total_sent = total_before + sent_total;     // 16 bytes with the two below
+        D.env[i].steps = steps + 1;
+        D.env[i].done = done;
         if (done) *D.any_done = 1u;  // somebody needs the auto-reset launches of this step
         if (done_out) done_out[i] = done;
     }
     PCC_TL_STAMP(11)  // outputs
+    if (tl) atomicMax(reinterpret_cast<unsigned long long *>(&tlw[1]), (unsigned long long)tl_t);
 #undef PCC_TL_STAMP
     // prediction for the next MI's send half: packets ~ MI length x current rate (the next action
     // moves the rate by at most a few percent)
     return (float)(new_run_dur * rate_sum);
 }
 
+// Order: with work lists (read_buf >= 0) the launch walks the classes the send half of this step
+// read, longest first -- the acks an env retires now are about the packets predicted for it -- so
+// that the four envs of a wavefront carry similar work and the launch ends with its shortest envs.
+// Without lists: index order.
+// Filing: every wavefront leaves its envs' classes in LDS and goes; the last one of the workgroup to
+// arrive files all 16 (one global atomic per class present) -- no barrier at the end, so a wavefront's
+// registers are free for the next workgroup as soon as ITS envs are done.
 template <int NS>
-__global__ __launch_bounds__(kRetireBlock, 5) void retire_kernel(Dev D, int fill_buf, int warm, uint32_t warm_mi,
-                                                              int last_warm, int gate, float *obs_out, float *reward_out,
-                                                              uint8_t *done_out, double *steps_out) {
+__global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(Dev D, int read_buf, int fill_buf, int warm,
+                                                              uint32_t warm_mi, int last_warm, int gate, float *obs_out,
+                                                              float *reward_out, uint8_t *done_out, double *steps_out) {
     if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    constexpr int kPerBlock = kRetireBlock / kGroup;
+    __shared__ uint32_t s_env[kPerBlock], s_cls[kPerBlock], s_arrived;
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    if (tid == 0) s_arrived = 0u;
+    __syncthreads();  // the workgroup's wavefronts start together: this one is free
     Group g;
     g.lane = tid & (kGroup - 1);
-    g.shift = (tid & (kWave - 1)) & ~(uint32_t)(kGroup - 1);
-    const int64_t i = (int64_t)blockIdx.x * (kRetireBlock / kGroup) + (tid / kGroup);
+    g.shift = lane & ~(uint32_t)(kGroup - 1);
+    const int64_t pos = (int64_t)blockIdx.x * kPerBlock + (tid / kGroup);
+    int64_t i = pos;
+    if (read_buf >= 0) {
+        // lane l < kClasses looks after class kClasses-1-l; inclusive prefix of the counts in that order
+        const uint32_t n_mine = lane < (uint32_t)kClasses ? D.cls_count[read_buf * kClsStride + (kClasses - 1 - (int)lane)] : 0u;
+        uint32_t incl = n_mine;
+        for (int o = 1; o < kClasses; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= (uint32_t)o) incl += up;
+        }
+        const uint32_t total = rl_u32(incl, kClasses - 1);
+        i = D.n;  // beyond the lists: nothing
+#pragma unroll
+        for (uint32_t grp = 0; grp < kWave / kGroup; grp++) {
+            const uint32_t p = (uint32_t)((int64_t)blockIdx.x * kPerBlock + (tid / kWave) * (kWave / kGroup) + grp);
+            const uint64_t above = __ballot(lane < (uint32_t)kClasses && incl > p);
+            if (p < total) {  // wave-uniform
+                const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
+                const uint32_t off = p - (rl_u32(incl, L) - rl_u32(n_mine, L));
+                const uint32_t e = D.cls_list[((size_t)read_buf * kClasses + (kClasses - 1 - L)) * (size_t)D.n + off];
+                if (lane / kGroup == grp) i = (int64_t)e;
+            }
+        }
+    }
     float pred = -1.0f;
     if (i < D.n) pred = retire_env<NS>(D, i, g, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out);
     if (fill_buf < 0) return;  // warm-up intervals do not file (kernel-uniform)
-    // ---- file the block's envs in the class lists of the next send (see "work lists"): ranks inside
-    // the block by LDS atomics, one global atomic per class the block holds
-    __shared__ uint32_t s_cnt[kClasses], s_base[kClasses];
-    if (tid < (uint32_t)kClasses) s_cnt[tid] = 0u;
-    __syncthreads();
-    const bool files = g.lane == 0 && pred >= 0.0f;
-    const int cls = class_of(pred);
-    uint32_t rank = 0;
-    if (files) rank = atomicAdd(&s_cnt[cls], 1u);
-    __syncthreads();
-    if (tid < (uint32_t)kClasses && s_cnt[tid]) s_base[tid] = atomicAdd(&D.cls_count[fill_buf * kClsStride + tid], s_cnt[tid]);
-    __syncthreads();
-    if (files) D.cls_list[((size_t)fill_buf * kClasses + cls) * (size_t)D.n + s_base[cls] + rank] = (uint32_t)i;
+    // ---- file the workgroup's envs in the class lists of the next send (see "work lists")
+    if (g.lane == 0) {
+        s_env[tid / kGroup] = pred >= 0.0f ? (uint32_t)i : 0xFFFFFFFFu;
+        s_cls[tid / kGroup] = (uint32_t)class_of(pred);
+    }
+    __threadfence_block();
+    uint32_t before = 0u;
+    if (lane == 0) before = atomicAdd(&s_arrived, 1u);
+    before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+    if (before != kRetireBlock / kWave - 1) return;
+    const uint32_t e = lane < (uint32_t)kPerBlock ? s_env[lane & (kPerBlock - 1)] : 0xFFFFFFFFu;
+    const uint32_t c = lane < (uint32_t)kPerBlock ? s_cls[lane & (kPerBlock - 1)] : 0xFFFFFFFFu;
+    const bool files = e != 0xFFFFFFFFu;
+    uint32_t rank = 0, same = 0, leader = lane;
+#pragma unroll
+    for (uint32_t l = 0; l < (uint32_t)kPerBlock; l++) {
+        const uint32_t oc = (uint32_t)__shfl((int)c, (int)l), oe = (uint32_t)__shfl((int)e, (int)l);
+        const bool match = oc == c && oe != 0xFFFFFFFFu;
+        same += match ? 1u : 0u;
+        rank += (match && l < lane) ? 1u : 0u;
+        if (match && l < leader) leader = l;
+    }
+    uint32_t base = 0u;
+    if (files && leader == lane) base = atomicAdd(&D.cls_count[fill_buf * kClsStride + c], same);
+    base = (uint32_t)__shfl((int)base, (int)leader);
+    if (files) D.cls_list[((size_t)fill_buf * kClasses + c) * (size_t)D.n + base + rank] = e;
 }
 
 // ======================================================================================
@@ -2189,12 +2274,12 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
     if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
     if (i >= D.n) return;
-    const bool sel = (!mask || mask[i]) && (!use_done || D.done[i]);
-    D.resetting[i] = sel ? 1 : 0;
+    const bool sel = (!mask || mask[i]) && (!use_done || D.env[i].done);
+    D.env[i].resetting = sel ? 1 : 0;
     if (!sel) return;
 
-    const uint32_t episode = D.episode[i];
-    D.episode[i] = episode + 1;
+    const uint32_t episode = D.env[i].episode;
+    D.env[i].episode = episode + 1;
 
     double bw, lat, queue, loss, rate0[NS];
     if (D.p_bw) {
@@ -2214,36 +2299,36 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
         for (int s = 0; s < NS; s++) rate0[s] = (D.lo[4] + (D.hi[4] - D.lo[4]) * u32_to_unit(w1[s])) * bw;
     }
     // caller-supplied parameters cannot be checked on the host (device arrays): never silent
-    if (!(bw > 0.0) || !(bw <= 1e8) || !(lat > 0.0) || !(queue >= 1.0) || !(loss >= 0.0) || !(loss <= 1.0)) D.flags[i] |= PCC_FLAG_BAD_PARAMS;
-    D.bw[i] = bw; D.dl[i] = lat; D.lr[i] = loss;
-    D.maxq[i] = queue / bw;   // ns:64
-    D.ebw[i] = 1.0 / bw;      // ns:77
-    D.q[i] = 0.0; D.tu[i] = 0.0; D.now[i] = 0.0;
-    D.run_dur[i] = 3 * lat;   // ns:467
-    D.steps[i] = 0;
-    D.done[i] = 0;
-    D.cwnd[i] = 25;       // ns:209, 227
-    D.mi_draws[i] = 0; D.ep_draws[i] = 0;
+    if (!(bw > 0.0) || !(bw <= 1e8) || !(lat > 0.0) || !(queue >= 1.0) || !(loss >= 0.0) || !(loss <= 1.0)) D.env[i].flags |= PCC_FLAG_BAD_PARAMS;
+    D.env[i].bw = bw; D.env[i].dl = lat; D.env[i].lr = loss;
+    D.env[i].maxq = queue / bw;   // ns:64
+    D.env[i].ebw = 1.0 / bw;      // ns:77
+    D.env[i].q = 0.0; D.env[i].tu = 0.0; D.env[i].now = 0.0;
+    D.env[i].run_dur = 3 * lat;   // ns:467
+    D.env[i].steps = 0;
+    D.env[i].done = 0;
+    D.env[i].cwnd = 25;       // ns:209, 227
+    D.env[i].mi_draws = 0; D.env[i].ep_draws = 0;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
-        D.rate[k] = rate0[s];
-        D.rate0[k] = rate0[s];
-        D.next_send[k] = 1.0 / rate0[s];  // ns:111
-        D.ha[k] = 0; D.hd[k] = 0; D.ta[k] = 0; D.td[k] = 0; D.mi_sent[k] = 0;
+        D.snd[k].rate = rate0[s];
+        D.snd[k].rate0 = rate0[s];
+        D.snd[k].next_send = 1.0 / rate0[s];  // ns:111
+        D.snd[k].ha = 0; D.snd[k].hd = 0; D.snd[k].ta = 0; D.snd[k].td = 0; D.snd[k].mi_sent = 0;
         // nothing is in flight any more: the pool slots go back (pushes only here, pops only in
         // send launches), the sender starts over in its own tier-0 rings
         for (int c = 1; c < D.n_tiers; c++) {
-            const uint32_t held = D.ring_held[k * kMaxTiers + c];
+            const uint32_t held = D.snd[k].ring_held[c];
             if (held) {
                 D.tier_free[c][atomicAdd(&D.tier_top[c], 1)] = held - 1u;
-                D.ring_held[k * kMaxTiers + c] = 0;
+                D.snd[k].ring_held[c] = 0;
             }
         }
-        D.ring_tier[k] = 0;
-        D.ring_base[k] = D.tier_base[0] + (size_t)((int64_t)i * NS + s) * tier_slot_bytes(D, 0);
-        D.min_lat[k] = 0.0;   // fresh sender id => no connection minimum yet (ns:229-233, so:158)
-        D.ep_return[k] = 0.0;
+        D.snd[k].ring_tier = 0;
+        D.snd[k].ring_base = D.tier_base[0] + (size_t)((int64_t)i * NS + s) * tier_slot_bytes(D, 0);
+        D.snd[k].min_lat = 0.0;   // fresh sender id => no connection minimum yet (ns:229-233, so:158)
+        D.snd[k].ep_return = 0.0;
         // all-empty history (so:57-62): every metric of an empty MI is 0 except the two ratios
         float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
         float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
@@ -2314,23 +2399,11 @@ struct Carver {
 size_t carve_state(Dev &d, char *base) {
     Carver c(base);
     const size_t n = (size_t)d.n, sn = n * d.ns;
-    d.bw = c.take<double>(n); d.dl = c.take<double>(n); d.lr = c.take<double>(n);
-    d.maxq = c.take<double>(n); d.ebw = c.take<double>(n); d.q = c.take<double>(n);
-    d.tu = c.take<double>(n); d.now = c.take<double>(n); d.run_dur = c.take<double>(n);
-    d.steps = c.take<uint32_t>(n); d.episode = c.take<uint32_t>(n); d.flags = c.take<uint32_t>(n);
+    d.env = c.take<EnvBlk>(n);
+    d.snd = c.take<SndBlk>(sn);
     d.cls_count = c.take<uint32_t>(2 * kClsStride);
     d.cursors = c.take<uint32_t>(3 * 16 * 32);
     d.any_done = c.take<uint32_t>(1);
-    d.done = c.take<uint8_t>(n); d.resetting = c.take<uint8_t>(n);
-    d.total_sent = c.take<unsigned long long>(n);
-    d.rate = c.take<double>(sn); d.rate0 = c.take<double>(sn); d.next_send = c.take<double>(sn);
-    d.min_lat = c.take<double>(sn); d.ep_return = c.take<double>(sn); d.last_return = c.take<double>(sn);
-    d.ha = c.take<uint32_t>(sn); d.hd = c.take<uint32_t>(sn); d.ta = c.take<uint32_t>(sn); d.td = c.take<uint32_t>(sn);
-    d.mi_sent = c.take<uint32_t>(sn);
-    d.cwnd = c.take<uint32_t>(n); d.mi_draws = c.take<uint32_t>(n); d.ep_draws = c.take<uint32_t>(n);
-    d.ring_base = c.take<char *>(sn);
-    d.ring_held = c.take<uint32_t>(sn * kMaxTiers);
-    d.ring_tier = c.take<uint8_t>(sn);
     d.tier_top = c.take<int32_t>(kMaxTiers);
     d.hist = c.take<float>(sn * d.HF);
     return (c.off + 255) & ~(size_t)255;
@@ -2376,12 +2449,13 @@ int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int
     const int64_t per_block = kRetireBlock / kGroup;
     const dim3 grid((unsigned)((d.n + per_block - 1) / per_block));
     const int fill = warm ? -1 : sim->fill_buf;
+    const int read = (warm || !d.retire_sorted) ? -1 : sim->read_buf;  // the lists this step's send launch read
     if (d.ns == 1)
-        hipLaunchKernelGGL(retire_kernel<1>, grid, dim3(kRetireBlock), 0, st, d, fill, warm, warm_mi, last_warm, gate, obs_out,
-                           reward_out, done_out, steps_out);
+        hipLaunchKernelGGL(retire_kernel<1>, grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm, gate,
+                           obs_out, reward_out, done_out, steps_out);
     else
-        hipLaunchKernelGGL(retire_kernel<2>, grid, dim3(kRetireBlock), 0, st, d, fill, warm, warm_mi, last_warm, gate, obs_out,
-                           reward_out, done_out, steps_out);
+        hipLaunchKernelGGL(retire_kernel<2>, grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm, gate,
+                           obs_out, reward_out, done_out, steps_out);
     const int rc = check_hip(hipGetLastError(), "retire kernel launch");
     if (rc == PCC_OK && !warm) {
         sim->read_buf = sim->fill_buf;
@@ -2472,6 +2546,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.heavy_predict = 512.0;
     d.send_wg_waves = getenv("PCC_SEND_WG_WAVES") ? (uint32_t)atoi(getenv("PCC_SEND_WG_WAVES")) : 4u;
     if (d.send_wg_waves < 1u || d.send_wg_waves > 4u) d.send_wg_waves = 4u;
+    d.retire_sorted = getenv("PCC_RETIRE_SORTED") ? (uint32_t)atoi(getenv("PCC_RETIRE_SORTED")) : 1u;
     d.debug_skip = getenv("PCC_DEBUG_SKIP") ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;
     const double lo[5] = {100, 0.05, 0, 0.0, 0.3}, hi[5] = {500, 0.5, 8, 0.05, 1.5};  // ns:355-358,466
     memcpy(d.lo, lo, sizeof lo); memcpy(d.hi, hi, sizeof hi);
@@ -2773,37 +2848,42 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {
     if (!sim || !out) return fail(PCC_EINVAL, "NULL argument");
     const Dev &d = sim->d;
     const size_t n = (size_t)d.n, sn = n * d.ns;
-    const void *src = nullptr;
-    size_t bytes = 0;
+    // the fields live in one 128-byte block per env / per sender: a strided 2-D copy gathers one
+    const char *src = nullptr;
+    size_t width = 0, rows = n;
+#define PCC_ENV_FIELD(f) src = reinterpret_cast<const char *>(d.env) + offsetof(EnvBlk, f); width = sizeof(EnvBlk::f); rows = n; break
+#define PCC_SND_FIELD(f) src = reinterpret_cast<const char *>(d.snd) + offsetof(SndBlk, f); width = sizeof(SndBlk::f); rows = sn; break
     switch (field) {
-        case PCC_F_BW: src = d.bw; bytes = n * 8; break;
-        case PCC_F_DL: src = d.dl; bytes = n * 8; break;
-        case PCC_F_LR: src = d.lr; bytes = n * 8; break;
-        case PCC_F_MAXQ: src = d.maxq; bytes = n * 8; break;
-        case PCC_F_QDELAY: src = d.q; bytes = n * 8; break;
-        case PCC_F_QTIME: src = d.tu; bytes = n * 8; break;
-        case PCC_F_NOW: src = d.now; bytes = n * 8; break;
-        case PCC_F_RUN_DUR: src = d.run_dur; bytes = n * 8; break;
-        case PCC_F_STEPS: src = d.steps; bytes = n * 4; break;
-        case PCC_F_EPISODE: src = d.episode; bytes = n * 4; break;
-        case PCC_F_FLAGS: src = d.flags; bytes = n * 4; break;
-        case PCC_F_RATE: src = d.rate; bytes = sn * 8; break;
-        case PCC_F_RATE0: src = d.rate0; bytes = sn * 8; break;
-        case PCC_F_NEXT_SEND: src = d.next_send; bytes = sn * 8; break;
-        case PCC_F_MIN_LAT: src = d.min_lat; bytes = sn * 8; break;
-        case PCC_F_ACC_HEAD: src = d.ha; bytes = sn * 4; break;
-        case PCC_F_ACC_TAIL: src = d.ta; bytes = sn * 4; break;
-        case PCC_F_DROP_HEAD: src = d.hd; bytes = sn * 4; break;
-        case PCC_F_DROP_TAIL: src = d.td; bytes = sn * 4; break;
-        case PCC_F_EP_RETURN: src = d.ep_return; bytes = sn * 8; break;
-        case PCC_F_LAST_RETURN: src = d.last_return; bytes = sn * 8; break;
-        case PCC_F_TOTAL_SENT: src = d.total_sent; bytes = n * 8; break;
-        case PCC_F_RING_TIER: src = d.ring_tier; bytes = sn; break;
-        case PCC_F_CWND: src = d.cwnd; bytes = n * 4; break;
+        case PCC_F_BW: PCC_ENV_FIELD(bw);
+        case PCC_F_DL: PCC_ENV_FIELD(dl);
+        case PCC_F_LR: PCC_ENV_FIELD(lr);
+        case PCC_F_MAXQ: PCC_ENV_FIELD(maxq);
+        case PCC_F_QDELAY: PCC_ENV_FIELD(q);
+        case PCC_F_QTIME: PCC_ENV_FIELD(tu);
+        case PCC_F_NOW: PCC_ENV_FIELD(now);
+        case PCC_F_RUN_DUR: PCC_ENV_FIELD(run_dur);
+        case PCC_F_STEPS: PCC_ENV_FIELD(steps);
+        case PCC_F_EPISODE: PCC_ENV_FIELD(episode);
+        case PCC_F_FLAGS: PCC_ENV_FIELD(flags);
+        case PCC_F_RATE: PCC_SND_FIELD(rate);
+        case PCC_F_RATE0: PCC_SND_FIELD(rate0);
+        case PCC_F_NEXT_SEND: PCC_SND_FIELD(next_send);
+        case PCC_F_MIN_LAT: PCC_SND_FIELD(min_lat);
+        case PCC_F_ACC_HEAD: PCC_SND_FIELD(ha);
+        case PCC_F_ACC_TAIL: PCC_SND_FIELD(ta);
+        case PCC_F_DROP_HEAD: PCC_SND_FIELD(hd);
+        case PCC_F_DROP_TAIL: PCC_SND_FIELD(td);
+        case PCC_F_EP_RETURN: PCC_SND_FIELD(ep_return);
+        case PCC_F_LAST_RETURN: PCC_SND_FIELD(last_return);
+        case PCC_F_TOTAL_SENT: PCC_ENV_FIELD(total_sent);
+        case PCC_F_RING_TIER: PCC_SND_FIELD(ring_tier);
+        case PCC_F_CWND: PCC_ENV_FIELD(cwnd);
         default: return fail(PCC_EINVAL, "unknown field %d", field);
     }
+#undef PCC_ENV_FIELD
+#undef PCC_SND_FIELD
     DeviceGuard guard(sim->device);
-    return check_hip(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)),
+    return check_hip(hipMemcpy2DAsync(out, width, src, 128, width, rows, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)),
                      "pcc_get_state copy");
 }
 
