@@ -314,13 +314,13 @@ def main():
         pmc, src = pmc_traffic()
         kname = out["roofline"]["kernel"]
         if pmc and N == 65536 and kname in pmc and pmc[kname].get("launches", 0) >= 50:
-            out["roofline"]["traffic"] = pmc[kname]["hbm_bytes_per_launch_raw"]
-            out["roofline"]["traffic_source"] = (src + ": raw FETCH_SIZE + WRITE_SIZE (KB units x 1024) of a SEPARATE profiled run "
+            out["roofline"]["traffic"] = pmc[kname].get("hbm_bytes_per_launch", pmc[kname]["hbm_bytes_per_launch_raw"])
+            out["roofline"]["traffic_source"] = (src + ": 2 x FETCH_SIZE + WRITE_SIZE (KB units x 1024; the factor 2 is this repo's calibration, profiles/r02_pmc_calibration.json) of a SEPARATE profiled run "
                                                  "of this script over " + str(pmc.get("_window", "steps 20..120 of an episode")) +
                                                  "; compare it with that window's algorithmic bytes (in the profile), not this run's")
             for other in out["roofline"].get("other_kernels", []):
                 if other["kernel"] in pmc and pmc[other["kernel"]].get("launches", 0) >= 50:
-                    other["traffic"] = pmc[other["kernel"]]["hbm_bytes_per_launch_raw"]
+                    other["traffic"] = pmc[other["kernel"]].get("hbm_bytes_per_launch", pmc[other["kernel"]]["hbm_bytes_per_launch_raw"])
         if world == 1 and args.groups > 1:
             out["async_groups"] = async_groups(pcc_rl_amd, torch, N, dev, K, W, args.groups)
         if not args.no_cpu_baseline and world == 1:

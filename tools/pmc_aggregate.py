@@ -31,9 +31,31 @@ for d in sys.argv[2:]:
 for k, e in out.items():
     if "FETCH_SIZE_KB_mean_per_launch" in e and "WRITE_SIZE_KB_mean_per_launch" in e:
         e["hbm_bytes_per_launch_raw"] = 1024.0 * (e["FETCH_SIZE_KB_mean_per_launch"] + e["WRITE_SIZE_KB_mean_per_launch"])
+        # calibration (profiles/r02_pmc_calibration.json): FETCH_SIZE counts every fetched 128-byte line as 64 bytes, for
+        # dense 16-byte reads, one 16-byte record per line and the 8-byte strided ring reads alike -> x 2;
+        # WRITE_SIZE is exact for dense writes and counts 32-byte sectors for lone 16-byte records (ring appends: 1.12 x)
+        e["hbm_bytes_per_launch"] = 1024.0 * (2.0 * e["FETCH_SIZE_KB_mean_per_launch"] + e["WRITE_SIZE_KB_mean_per_launch"])
+# the bench line of the profiled run (DIR.log, written by tools/profile_round.sh) names the window's algorithmic bytes
+import os
+for d in sys.argv[2:]:
+    log = d.rstrip("/") + ".log"
+    if not os.path.exists(log):
+        continue
+    lines = [l for l in open(log) if l.startswith("{")]
+    if not lines:
+        continue
+    r = json.loads(lines[-1]).get("roofline", {})
+    for k in [r] + r.get("other_kernels", []):
+        if k.get("kernel") in out and "algorithmic_bytes_per_launch" in k:
+            out[k["kernel"]]["algorithmic_bytes_per_launch"] = k["algorithmic_bytes_per_launch"]
+            if "hbm_bytes_per_launch" in out[k["kernel"]]:
+                out[k["kernel"]]["traffic_over_algorithmic"] = out[k["kernel"]]["hbm_bytes_per_launch"] / k["algorithmic_bytes_per_launch"]
+    break
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 100 --warmup 20 "
-                "--no-cpu-baseline` (steps 20..120 of an episode); counters are KB per dispatch.  MI355X_MICROARCH.md: on gfx950 "
-                "FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read and is uncalibrated for other widths; these kernels "
-                "touch 16-B records at scattered addresses, so the raw values are reported uncorrected.")
+                "--repeats 1 --no-cpu-baseline` (steps 20..120 of an episode); counters are KB per dispatch.  hbm_bytes_per_launch = "
+                "2 x FETCH_SIZE + WRITE_SIZE: tools/pmc_calibrate.sh (profiles/r02_pmc_calibration.json) measured FETCH_SIZE at "
+                "exactly half of the fetched 128-byte lines for every read pattern of these kernels and WRITE_SIZE at 1.0 x (dense) "
+                "to 1.12 x (ring appends) of the written bytes; hbm_bytes_per_launch_raw is the uncorrected sum.")
+out["_window"] = "steps 20..120 of an episode"
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out, indent=1))
