@@ -93,6 +93,12 @@ def lib():
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int,
             ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, _u64p,
             ctypes.c_long, _dp, ctypes.c_long, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, ctypes.c_int]
+        L.pcc_oracle_run_batch_opts.restype = ctypes.c_int
+        L.pcc_oracle_run_batch_opts.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int,
+            ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, _u64p,
+            ctypes.c_long, _dp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, ctypes.c_int]
+        L.pcc_oracle_use_latency_noise.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
         _lib = L
     return _lib
 
@@ -176,6 +182,11 @@ class OracleEnv(object):
         self._cwnd = bool(on)
         self.L.pcc_oracle_use_cwnd(self.h, 1 if on else 0)
 
+    def use_latency_noise(self, on=True, max_noise=1.1):
+        """The reference's dormant USE_LATENCY_NOISE engine option (ns:51-52, 150-151, 171-172): every
+        link latency is multiplied by random.uniform(1.0, MAX_LATENCY_NOISE), packets can overtake."""
+        self.L.pcc_oracle_use_latency_noise(self.h, 1 if on else 0, float(max_noise))
+
     def cwnd(self, sender=0):
         return int(self.L.pcc_oracle_cwnd(self.h, sender))
 
@@ -217,10 +228,12 @@ class OracleEnv(object):
 
 def run_batch(actions, n_senders=1, history_len=10, features=DEFAULT_FEATURES, mean_mode=MEAN_NUMPY,
               delta_scale=0.025, rng_mode=RNG_PHILOX, seed=0, env_gid_base=0, mt_seeds=None, mt_skip=5,
-              trace=None, params=None, n_episodes=1, n_threads=None, want_obs=True, cwnd_actions=None):
+              trace=None, params=None, n_episodes=1, n_threads=None, want_obs=True, cwnd_actions=None,
+              latency_noise=None):
     """Run B independent envs for T steps.  actions: [B, T] or [B, T, n_senders].
     cwnd_actions (same shape) switches the USE_CWND engine option on and supplies the second
-    action component.
+    action component; latency_noise (e.g. 1.1 = the reference's MAX_LATENCY_NOISE) switches
+    USE_LATENCY_NOISE on.
 
     Returns dict(steps [B, S, T, 19], obs [B, S, T, H*F], obs0 [B, S, H*F],
                  params [B, 5+S], warm [B, 2]); S axis squeezed when n_senders == 1.
@@ -242,11 +255,11 @@ def run_batch(actions, n_senders=1, history_len=10, features=DEFAULT_FEATURES, m
     ms = None if mt_seeds is None else np.ascontiguousarray(mt_seeds, dtype=np.uint64)
     nt = n_threads if n_threads else (os.cpu_count() or 1)
     ca = None if cwnd_actions is None else np.ascontiguousarray(cwnd_actions, dtype=np.float64).reshape(B, T, S)
-    bad = lib().pcc_oracle_run_batch_cwnd(
+    bad = lib().pcc_oracle_run_batch_opts(
         B, S, T, n_episodes, history_len, _ptr(fids, _ip), len(fids), mean_mode, delta_scale, rng_mode,
         int(seed), int(env_gid_base), _ptr(ms, _u64p), int(mt_skip), _ptr(tr),
-        0 if tr is None else tr.shape[1], _ptr(p), _ptr(a), _ptr(ca), _ptr(steps), _ptr(obs), _ptr(obs0),
-        _ptr(pout), _ptr(warm), nt)
+        0 if tr is None else tr.shape[1], _ptr(p), _ptr(a), _ptr(ca), float(latency_noise or 0.0), _ptr(steps),
+        _ptr(obs), _ptr(obs0), _ptr(pout), _ptr(warm), nt)
     if bad:
         raise RuntimeError("loss-uniform trace ran out for env %d" % (bad - 1))
     out = dict(steps=steps, obs=obs, obs0=obs0, params=pout, warm=warm)

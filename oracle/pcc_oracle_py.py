@@ -31,7 +31,8 @@ class PyOracleEnv(object):
     """Single env, 1 or 2 senders, reference life cycle: construct, reset(), step(a)..."""
 
     def __init__(self, seed=0, history_len=10, features=("sent latency inflation", "latency ratio", "send ratio"),
-                 n_senders=1, delta_scale=0.025, fixed=None, ctor_draws=5, use_cwnd=False):
+                 n_senders=1, delta_scale=0.025, fixed=None, ctor_draws=5, use_cwnd=False,
+                 latency_noise=None):
         self.rng = random.Random(seed)
         for _ in range(ctor_draws):           # the constructor's discarded parameter draws (ns:366)
             self.rng.random()
@@ -40,6 +41,7 @@ class PyOracleEnv(object):
         self.run_dur = None
         self.draws = ctor_draws
         self.use_cwnd = use_cwnd          # ns:54: window-limited sending, [rate action, cwnd action] per step
+        self.latency_noise = latency_noise  # ns:51-52: None = off, else MAX_LATENCY_NOISE (1.1 in the reference)
 
     # ---- parameters and reset: ns:454-484
     def _new_params(self):
@@ -105,6 +107,9 @@ class PyOracleEnv(object):
                     self.in_flight[s] -= 1    # ns:269, 273
                 else:   # return link: never queued on, so its latency is dl + max(0, 0 - t) (ns:66-70)
                     ll = dl + max(0.0, 0.0 - (t - 0.0))
+                    if self.latency_noise:        # ns:150-151
+                        ll *= self.rng.uniform(1.0, self.latency_noise)
+                        self.draws += 1
                     push(heap, (t + ll, s, ACK, hop + 1, lat + ll, dropped))
             else:
                 # ns:158-160, 251-255: a SEND the window blocks launches no packet, but the link lines
@@ -116,6 +121,9 @@ class PyOracleEnv(object):
                 push(heap, (t + (1.0 / self.rate[s]), s, SEND, 0, 0.0, False))
                 qd = max(0.0, self.q - (t - self.tq))
                 ll = dl + qd
+                if self.latency_noise:            # ns:171-172: drawn before the loss decision
+                    ll *= self.rng.uniform(1.0, self.latency_noise)
+                    self.draws += 1
                 self.draws += 1
                 if rnd() < self.lr:
                     ok = False

@@ -105,15 +105,17 @@ class Recorder(object):
 
 
 def run_env_episodes(ns, seed, n_steps, action_fn, history_len=10,
-                     features=DEFAULT_FEATURES, fixed=None, n_episodes=1, cwnd=False):
+                     features=DEFAULT_FEATURES, fixed=None, n_episodes=1, cwnd=False, noise=False):
     """One reference env object driven for n_episodes; returns dict of arrays.
 
     cwnd=True runs the engine with its dormant USE_CWND option on (ns:54; a module global the
     engine reads at call time, set here from outside -- the reference file is not modified):
-    actions are then [rate action, cwnd action] pairs (ns:376-377, 413-414)."""
+    actions are then [rate action, cwnd action] pairs (ns:376-377, 413-414).
+    noise=True does the same with USE_LATENCY_NOISE (ns:51; MAX_LATENCY_NOISE stays the reference's 1.1)."""
     rng = CountingRandom(seed)
     ns.random = rng
     ns.USE_CWND = bool(cwnd)
+    ns.USE_LATENCY_NOISE = bool(noise)
     env = ns.SimulatedNetworkEnv(history_len=history_len, features=features)
     offsets = []
     orig_create = env.create_new_links_and_senders
@@ -161,6 +163,7 @@ def run_env_episodes(ns, seed, n_steps, action_fn, history_len=10,
                         obs=np.array(rec.obs, dtype=np.float64),
                         done=np.array(dones, dtype=np.bool_)))
     ns.USE_CWND = False
+    ns.USE_LATENCY_NOISE = False
     return out
 
 
@@ -303,7 +306,17 @@ def gen_two_sender(ns, name, seeds, n_steps=200):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # optional: regenerate only the fixtures whose name starts with this
     ns = import_reference()
+    real_gen_single, real_gen_two = globals()["gen_single"], globals()["gen_two_sender"]
+
+    def gen_single(ns_, name, *a, **kw):
+        if name.startswith(only):
+            real_gen_single(ns_, name, *a, **kw)
+
+    def gen_two_sender(ns_, name, *a, **kw):
+        if name.startswith(only):
+            real_gen_two(ns_, name, *a, **kw)
     cwd = os.getcwd()
     tmp = tempfile.mkdtemp(prefix="pcc_golden_")
     os.chdir(tmp)   # the reference env dumps pcc_env_log_run_N.json into the CWD
@@ -323,6 +336,11 @@ def main():
         gen_single(ns, "cwnd_grow", range(520, 524), rate_pm1_cwnd_up, n_steps=200, cwnd=True)
         gen_single(ns, "cwnd_fixed_deepq", [5], rate_pm1_cwnd_up, fixed=(100, 0.05, 2981, 0.0, 150.0), n_steps=200,
                    cwnd=True)
+        gen_single(ns, "noise_pm1", range(600, 608), uniform_pm1, noise=True)
+        gen_single(ns, "noise_fixed_q1", [6], uniform_pm1, fixed=(150, 0.05, 1, 0.0, 300.0), n_steps=200, noise=True)
+        gen_single(ns, "noise_fixed_lossy", [7], uniform_pm1, fixed=(300, 0.1, 50, 0.5, 400.0), n_steps=200, noise=True)
+        gen_single(ns, "noise_fixed_deepq", [8], uniform_0_2, fixed=(100, 0.05, 2981, 0.0, 150.0), n_steps=200,
+                   noise=True)
     finally:
         os.chdir(cwd)
 

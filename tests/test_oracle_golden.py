@@ -141,6 +141,27 @@ def test_use_cwnd_engine_option_bit_exact(name):
         assert d["cwnd"].max() == 5000              # ... and the window can open up to MAX_CWND
 
 
+@pytest.mark.parametrize("name", ["noise_pm1", "noise_fixed_q1", "noise_fixed_lossy", "noise_fixed_deepq"])
+def test_use_latency_noise_engine_option_bit_exact(name):
+    """The reference's dormant USE_LATENCY_NOISE option (ns:51-52, 150-151, 171-172): every link latency is
+    multiplied by random.uniform(1.0, 1.1) -- one more draw of the shared stream per hop, taken before the
+    loss decision -- so packets overtake each other on both hops."""
+    d = load(name)
+    feats = [str(f) for f in d["features"]]
+    fixed = tuple(d["fixed"]) if "fixed" in d else None
+    for i in range(d["seed"].shape[0]):
+        env = run_case_mt(d, i, int(d["history_len"]), feats)
+        env.use_latency_noise(True, 1.1)
+        check_episode(env, d, i, fixed=fixed)
+        assert env.rng_draws == int(d["rng"][i][1])
+        env.close()
+    # the fixtures are not the noiseless engine's numbers with other seeds: three draws per packet
+    plain = load("fixed_q1" if "fixed" in d else "default_pm1")
+    per_packet = (d["rng"][:, 1] - d["rng"][:, 0]) / d["steps"][:, :, 0].sum(axis=1)
+    per_packet_plain = (plain["rng"][:, 1] - plain["rng"][:, 0]) / plain["steps"][:, :, 0].sum(axis=1)
+    assert (per_packet > 2.5).all() and (per_packet_plain < 1.5).all()
+
+
 def test_two_sender_engine_bit_exact():
     d = load("two_sender")
     for i in range(d["seed"].shape[0]):

@@ -68,3 +68,11 @@ def test_use_cwnd_option():
     env = PyOracleEnv(seed=int(d["seed"][0]), use_cwnd=True)
     check(env, d, 0)
     assert env.cwnd[0] == int(d["cwnd"][0, -1])
+
+
+def test_use_latency_noise_option():
+    d = load("noise_pm1")
+    for i in (0, 5):
+        check(PyOracleEnv(seed=int(d["seed"][i]), latency_noise=1.1), d, i)
+    d = load("noise_fixed_lossy")
+    check(PyOracleEnv(seed=int(d["seed"][0]), fixed=tuple(d["fixed"]), latency_noise=1.1), d, 0)
