@@ -182,6 +182,21 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
  * the others. */
 int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable);
 
+/* The reference's other dormant engine option, USE_LATENCY_NOISE / MAX_LATENCY_NOISE (ns:51-52; off /
+ * 1.1 in the reference): every link latency -- forward hop at the SEND (ns:171-172), return hop at the
+ * first ACK event (ns:150-151) -- is multiplied by random.uniform(1.0, max_noise), one more draw of the
+ * env's stream per hop (at a SEND it precedes the loss draw).  Packets overtake each other, so with the
+ * option on an env keeps the reference's own structure -- a binary heap of its events, ring_capacity
+ * events per env, allocated by this call (2 x 16 bytes x ring_capacity per env) -- and one lane runs the
+ * reference's event loop over it; the whole interval is one kernel launch (pcc_step; there is no
+ * pcc_step_send / pcc_step_retire split).  Exact like the other paths (golden sets noise_*), and slow:
+ * it exists for parity with the reference's flag, not for throughput.  Uniforms: PCC_RNG_TRACE replays
+ * the trace in draw order (three draws per packet); PCC_RNG_PHILOX numbers ALL draws of an interval
+ * 0, 1, 2, ... in event order (word index of the interval's Philox stream).  One sender per env, not
+ * together with pcc_set_cwnd_mode; pcc_reset must follow.  More events in flight than ring_capacity, or
+ * more acknowledgements in one interval, raise PCC_FLAG_RING_OVERFLOW. */
+int pcc_set_latency_noise(pcc_sim_t *sim, int enable, double max_noise);
+
 /* DELTA_SCALE (src/common/config.py:17, default 0.025) and MAX_STEPS (ns:41, default 400) */
 int pcc_set_delta_scale(pcc_sim_t *sim, double delta_scale);
 int pcc_set_max_steps(pcc_sim_t *sim, int max_steps);

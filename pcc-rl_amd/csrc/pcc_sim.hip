@@ -112,7 +112,7 @@ struct alignas(128) EnvBlk {
     uint32_t mi_draws;  //  96  send half: link-entry draws of the MI (a SEND the window blocks still draws)
     uint32_t ep_draws;  //      ... of the episode: the position in a replayed loss trace
     uint32_t flags;
-    uint32_t pad1;
+    uint32_t heap_n;    //      USE_LATENCY_NOISE option: events in the env's heap
 };
 struct alignas(128) SndBlk {
     double rate, rate0;          //  0  send half (rate)
@@ -164,6 +164,13 @@ struct Dev {
     SndBlk *snd;  // [S][N] per sender, one 128-byte block each
     // the reference's dormant USE_CWND engine option (ns:54), one sender only
     int use_cwnd;
+    // the reference's dormant USE_LATENCY_NOISE engine option (ns:51-52), one sender only: packets overtake each
+    // other, so the in-flight set is a real priority queue per env (see noise_engine)
+    int use_noise;
+    double noise_span;     // MAX_LATENCY_NOISE - 1.0: random.uniform(1.0, MAX) = 1.0 + span * random()
+    uint32_t noise_cap;    // events / RTT samples per env (a power of two)
+    double2 *noise_heap;   // [N][noise_cap] (+-t, +-latency): sign of t = hop 2, sign of latency = dropped
+    double2 *noise_rtt;    // [N][noise_cap] (-, rtt) of the packets acknowledged in the current MI, in ack order
     float *hist;    // [N][S][HF]
     double2 *ring;  // [N][S][2][cap]: accepted ring, dropped ring
 };
@@ -1883,11 +1890,141 @@ __device__ __forceinline__ double select_metric(const double (&m)[PCC_N_METRICS]
     return __longlong_as_double((long long)bits);
 }
 
+// --------------------------------------------------------------------------------------
+// USE_LATENCY_NOISE (ns:51-52, 150-151, 171-172): every link latency is multiplied by
+// random.uniform(1.0, MAX_LATENCY_NOISE), one more draw of the stream per hop.  Packets overtake each
+// other on both hops, so the two monotone rings cannot hold the in-flight set: with this option an
+// env keeps the reference's own structure, a binary heap of its events, in global memory, and ONE
+// lane runs the reference's event loop (ns:127-178) over it -- exactness, not speed, is the point of
+// a dormant option.  Only acknowledgement events live in the heap (hop 1: arrives at the return link,
+// hop 2: arrives at the sender); the sender's one pending SEND is next_send as everywhere else.  The
+// reference orders events as tuples (time, sender, type, hop, latency, dropped): 'A' < 'S' puts an
+// ACK before a SEND at equal times, the rest is heap_less.  Any priority queue pops the same order.
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sign_of(double x) { return __double_as_longlong(x) < 0; }
+__device__ __forceinline__ bool heap_less(const double2 a, const double2 b) {
+    const double ta = fabs(a.x), tb = fabs(b.x);
+    if (ta != tb) return ta < tb;
+    const bool ha = sign_of(a.x), hb = sign_of(b.x);  // hop 2
+    if (ha != hb) return hb;
+    const double la = fabs(a.y), lb = fabs(b.y);
+    if (la != lb) return la < lb;
+    return !sign_of(a.y) && sign_of(b.y);  // dropped: False < True
+}
+__device__ __forceinline__ void heap_push(double2 *H, uint32_t &n, const double2 v) {
+    uint32_t pos = n++;
+    while (pos > 0) {
+        const uint32_t parent = (pos - 1u) >> 1;
+        const double2 pv = ld_rec(H + parent);
+        if (!heap_less(v, pv)) break;
+        st_rec(H + pos, pv);
+        pos = parent;
+    }
+    st_rec(H + pos, v);
+}
+__device__ __forceinline__ double2 heap_pop(double2 *H, uint32_t &n) {
+    const double2 top = ld_rec(H);
+    const double2 last = ld_rec(H + (--n));
+    uint32_t pos = 0;
+    for (;;) {
+        uint32_t c = 2u * pos + 1u;
+        if (c >= n) break;
+        double2 cv = ld_rec(H + c);
+        if (c + 1u < n) {
+            const double2 rv = ld_rec(H + c + 1u);
+            if (heap_less(rv, cv)) { cv = rv; c++; }
+        }
+        if (!heap_less(cv, last)) break;
+        st_rec(H + pos, cv);
+        pos = c;
+    }
+    if (n) st_rec(H + pos, last);
+    return top;
+}
+
+struct NoiseOut {
+    double now, nsend, q, tu;
+    uint32_t sent, acked, lost, flags;
+};
+
+// one monitor interval of env i, by one lane: ns:123-178 with the option on
+__device__ __noinline__ NoiseOut noise_engine(const Dev &D, int64_t i, double start, double end, double rate, double nsend,
+                                              uint32_t mi) {
+    const double dl = D.env[i].dl, lr = D.env[i].lr, maxq = D.env[i].maxq, ebw = D.env[i].ebw;
+    double q = D.env[i].q, tu = D.env[i].tu;
+    const uint32_t episode = D.env[i].episode - 1;
+    uint32_t hn = D.env[i].heap_n, mi_draws = 0, ep_draws = D.env[i].ep_draws;
+    double2 *H = D.noise_heap + (size_t)i * D.noise_cap;
+    double2 *R = D.noise_rtt + (size_t)i * D.noise_cap;
+    NoiseOut o;
+    o.sent = o.acked = o.lost = o.flags = 0;
+    double now = start;
+    auto draw = [&]() -> double {
+        if (D.rng_mode == PCC_RNG_TRACE) {
+            const uint32_t pos = ep_draws++;
+            if ((int64_t)pos >= D.trace_stride) { o.flags |= PCC_FLAG_TRACE_OVERRUN; return 1.0; }
+            return D.trace[i * D.trace_stride + pos];
+        }
+        ep_draws++;
+        return philox_packet_uniform(D, D.gid_base + (uint32_t)i, episode, mi, mi_draws++);
+    };
+    while (now < end) {  // ns:128
+        const bool from_heap = hn > 0 && fabs(ld_rec(H).x) <= nsend;  // equal times: the ACK goes first ('A' < 'S')
+        if (from_heap) {
+            const double2 ev = heap_pop(H, hn);
+            now = fabs(ev.x);
+            const double lat = fabs(ev.y);
+            if (sign_of(ev.x)) {  // hop 2 == len(path): the sender hears of it (ns:139-146)
+                if (sign_of(ev.y)) o.lost++;
+                else {
+                    if (o.acked < D.noise_cap) { double2 r; r.x = 0.0; r.y = lat; st_rec(R + o.acked, r); }
+                    else o.flags |= PCC_FLAG_RING_OVERFLOW;
+                    o.acked++;
+                }
+            } else {  // hop 1: over the return link, which never queues (ns:147-153)
+                double ll = dl + max0(0.0 - (now - 0.0));
+                ll *= 1.0 + D.noise_span * draw();
+                double2 nv;
+                nv.x = -(now + ll);
+                nv.y = sign_of(ev.y) ? -(lat + ll) : lat + ll;
+                if (hn < D.noise_cap) heap_push(H, hn, nv);
+                else o.flags |= PCC_FLAG_RING_OVERFLOW;
+            }
+        } else {  // SEND (ns:155-175)
+            now = nsend;
+            o.sent++;
+            nsend = now + 1.0 / rate;  // ns:161
+            const double qd = max0(q - (now - tu));
+            double ll = dl + qd;
+            ll *= 1.0 + D.noise_span * draw();  // drawn before the loss decision (ns:171-175)
+            const double lat = 0.0 + ll;
+            bool dropped;
+            if (draw() < lr) dropped = true;  // ns:73-74
+            else {
+                q = qd; tu = now;            // ns:75-76
+                if (ebw + q > maxq) dropped = true;  // ns:78-79
+                else { q += ebw; dropped = false; }
+            }
+            double2 nv;
+            nv.x = now + ll;
+            nv.y = dropped ? -lat : lat;
+            if (hn < D.noise_cap) heap_push(H, hn, nv);
+            else o.flags |= PCC_FLAG_RING_OVERFLOW;
+        }
+    }
+    D.env[i].heap_n = hn;
+    D.env[i].ep_draws = ep_draws;
+    D.env[i].mi_draws = mi_draws;
+    o.now = now; o.nsend = nsend; o.q = q; o.tu = tu;
+    return o;
+}
+
 // Returns the env's predicted packet count for the next monitor interval (< 0: nothing to report).
-template <int NS>
+template <int NS, bool NOISE>
 __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const Group g, int warm, uint32_t warm_mi,
                                             int last_warm, float *obs_out, float *reward_out, uint8_t *done_out,
-                                            double *steps_out) {
+                                            double *steps_out, const void *actions, int actions_f64) {
+    static_assert(!NOISE || NS == 1, "the latency-noise option is built for one sender");
     if (warm && !D.env[i].resetting) return -1.0f;
     const bool lead = g.lane == 0;
     // profiling only: where a wavefront's retire time goes (lane 0's view), summed per workgroup
@@ -1927,8 +2064,34 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         amask[s] = rr.mask(); dmasks[s] = rr.dmask();
     }
     uint32_t flags = 0;
+    double noise_rate = 0.0;
 
-    if (start < end) {  // ns:128: otherwise the loop body never runs
+    if constexpr (NOISE) {
+        // the whole interval in the lead lane: rate action (ns:235-241; there is no send half with this option), event loop
+        double rate = D.snd[i].rate;
+        if (!warm) {
+            double delta = actions_f64 ? ((const double *)actions)[i] : (double)((const float *)actions)[i];
+            delta *= D.delta_scale;
+            rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
+            if (rate > kMaxRate) rate = kMaxRate;
+            if (rate < kMinRate) rate = kMinRate;
+        }
+        noise_rate = rate;
+        NoiseOut o;
+        o.now = start; o.nsend = nsend[0]; o.q = 0.0; o.tu = 0.0; o.sent = o.acked = o.lost = o.flags = 0;
+        if (lead) {
+            o = noise_engine(D, i, start, end, rate, nsend[0], warm ? warm_mi : steps + 2);
+            D.snd[i].rate = rate;
+            D.env[i].q = o.q; D.env[i].tu = o.tu;
+        }
+        __threadfence();  // the RTT samples the lead lane stored are read by all 16 lanes below
+        now = gbcast(o.now, 0); nsend[0] = gbcast(o.nsend, 0);
+        sent[0] = gbcast(o.sent, 0); acked[0] = gbcast(o.acked, 0); lost[0] = gbcast(o.lost, 0);
+        flags |= gbcast(o.flags, 0);
+        ra[0] = D.noise_rtt + (size_t)i * D.noise_cap;
+        amask[0] = D.noise_cap - 1u;
+        from[0] = 0;
+    } else if (start < end) {  // ns:128: otherwise the loop body never runs
         // candidates for the MI-ending event per sender: hop-1, hop-2 (with the ring it sits in)
         double t_h1[NS], t_h2[NS], l_h2[NS];
         uint32_t k_h2[NS];
@@ -2101,7 +2264,8 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         const int64_t k = (int64_t)s * D.n + i;
         double lat = 0.0, inc = 0.0;
         PCC_TL_STAMP(7)  // state write-back
-        if (acked[s] > 0 && !(D.debug_skip & 1)) rtt_means(g, ra[s], amask[s], from[s], acked[s], dl, need_halves, lat, inc);
+        if (acked[s] > 0 && !(D.debug_skip & 1))
+            rtt_means(g, ra[s], amask[s], from[s], acked[s], NOISE ? 0.0 : dl, need_halves, lat, inc);  // noise: the samples are whole RTTs
         PCC_TL_STAMP(8)  // RTT means
         // everything the rest of the MI reads, in one batch of loads (one round trip, not five)
         float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
@@ -2117,7 +2281,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         }
         double min_lat = D.snd[k].min_lat;
         const double ep_before = D.snd[k].ep_return;
-        const double rate_now = D.snd[k].rate;
+        const double rate_now = NOISE ? noise_rate : D.snd[k].rate;
         rate_sum += rate_now;
         double m[PCC_N_METRICS];
         mi_metrics(sent[s], acked[s], lost[s], dur, lat, inc, min_lat, m);
@@ -2196,10 +2360,11 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
 // Filing: every wavefront leaves its envs' classes in LDS and goes; the last one of the workgroup to
 // arrive files all 16 (one global atomic per class present) -- no barrier at the end, so a wavefront's
 // registers are free for the next workgroup as soon as ITS envs are done.
-template <int NS>
+template <int NS, bool NOISE>
 __global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(Dev D, int read_buf, int fill_buf, int warm,
                                                               uint32_t warm_mi, int last_warm, int gate, float *obs_out,
-                                                              float *reward_out, uint8_t *done_out, double *steps_out) {
+                                                              float *reward_out, uint8_t *done_out, double *steps_out,
+                                                              const void *actions, int actions_f64) {
     if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     constexpr int kPerBlock = kRetireBlock / kGroup;
     __shared__ uint32_t s_env[kPerBlock], s_cls[kPerBlock], s_arrived;
@@ -2235,7 +2400,9 @@ __global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(De
         }
     }
     float pred = -1.0f;
-    if (i < D.n) pred = retire_env<NS>(D, i, g, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out);
+    if (i < D.n)
+        pred = retire_env<NS, NOISE>(D, i, g, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out, actions,
+                                     actions_f64);
     if (fill_buf < 0) return;  // warm-up intervals do not file (kernel-uniform)
     // ---- file the workgroup's envs in the class lists of the next send (see "work lists")
     if (g.lane == 0) {
@@ -2309,6 +2476,7 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
     D.env[i].done = 0;
     D.env[i].cwnd = 25;       // ns:209, 227
     D.env[i].mi_draws = 0; D.env[i].ep_draws = 0;
+    D.env[i].heap_n = 0;      // latency-noise option: nothing in flight (the first SEND is next_send)
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
@@ -2368,6 +2536,9 @@ struct pcc_sim {
     int cu_count;       // compute units of the device
     void *list_blob;    // the class lists (Dev::cls_list)
     size_t list_bytes;
+    void *noise_blob;   // heap + RTT samples of the latency-noise option (allocated when it is switched on)
+    size_t noise_bytes;
+    uint32_t ring_capacity;
 };
 
 namespace {
@@ -2451,11 +2622,11 @@ int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int
     const int fill = warm ? -1 : sim->fill_buf;
     const int read = (warm || !d.retire_sorted) ? -1 : sim->read_buf;  // the lists this step's send launch read
     if (d.ns == 1)
-        hipLaunchKernelGGL(retire_kernel<1>, grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm, gate,
-                           obs_out, reward_out, done_out, steps_out);
+        hipLaunchKernelGGL((retire_kernel<1, false>), grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm,
+                           gate, obs_out, reward_out, done_out, steps_out, nullptr, 0);
     else
-        hipLaunchKernelGGL(retire_kernel<2>, grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm, gate,
-                           obs_out, reward_out, done_out, steps_out);
+        hipLaunchKernelGGL((retire_kernel<2, false>), grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm,
+                           gate, obs_out, reward_out, done_out, steps_out, nullptr, 0);
     const int rc = check_hip(hipGetLastError(), "retire kernel launch");
     if (rc == PCC_OK && !warm) {
         sim->read_buf = sim->fill_buf;
@@ -2466,6 +2637,16 @@ int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int
 
 int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, const void *actions, int actions_f64,
               float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
+    if (sim->d.use_noise) {
+        // the latency-noise option: the whole interval is one launch of the retire kernel's NOISE build (no send half,
+        // no work lists)
+        const Dev &d = sim->d;
+        const int64_t per_block = kRetireBlock / kGroup;
+        const dim3 grid((unsigned)((d.n + per_block - 1) / per_block));
+        hipLaunchKernelGGL((retire_kernel<1, true>), grid, dim3(kRetireBlock), 0, st, d, -1, -1, warm, warm_mi, last_warm, gate,
+                           obs_out, reward_out, done_out, steps_out, actions, actions_f64);
+        return check_hip(hipGetLastError(), "noise kernel launch");
+    }
     const int rc = launch_send(sim, warm, warm_mi, gate, actions, actions_f64, st);
     if (rc != PCC_OK) return rc;
     return launch_retire(sim, warm, warm_mi, last_warm, gate, obs_out, reward_out, done_out, steps_out, st);
@@ -2534,6 +2715,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.n = n_envs; d.ns = n_senders; d.H = history_len; d.F = n_features; d.HF = history_len * n_features;
     for (int f = 0; f < n_features; f++) d.fid[f] = feature_ids[f];
     // tiers: cap0 * 4^c records, the top tier = ring_capacity; as many tiers (<= 4) as keep cap0 >= 256
+    sim->ring_capacity = ring_capacity;
     d.n_tiers = 1; d.cap0 = ring_capacity;
     while (d.n_tiers < kMaxTiers && d.cap0 >= 4u * 256u) { d.cap0 >>= 2; d.n_tiers++; }
     d.key0 = (uint32_t)seed; d.key1 = (uint32_t)(seed >> 32); d.gid_base = env_gid_base;
@@ -2670,6 +2852,7 @@ void pcc_destroy(pcc_sim_t *sim) {
     DeviceGuard guard(sim->device);
     if (sim->timeline_blob) (void)hipFree(sim->timeline_blob);
     if (sim->list_blob) (void)hipFree(sim->list_blob);
+    if (sim->noise_blob) (void)hipFree(sim->noise_blob);
 
     if (sim->state_blob) (void)hipFree(sim->state_blob);
     for (int c = 0; c < kMaxTiers; c++) {
@@ -2679,7 +2862,7 @@ void pcc_destroy(pcc_sim_t *sim) {
     delete sim;
 }
 
-int64_t pcc_device_bytes(const pcc_sim_t *sim) { return sim ? (int64_t)(sim->state_bytes + sim->ring_bytes + sim->list_bytes) : 0; }
+int64_t pcc_device_bytes(const pcc_sim_t *sim) { return sim ? (int64_t)(sim->state_bytes + sim->ring_bytes + sim->list_bytes + sim->noise_bytes) : 0; }
 
 int pcc_set_link_params(pcc_sim_t *sim, const double *bw, const double *dl, const double *queue, const double *loss,
                         const double *rate0) {
@@ -2753,9 +2936,37 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
 int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     if (enable && sim->d.ns != 1) return fail(PCC_EINVAL, "the congestion-window option supports one sender per env");
+    if (enable && sim->d.use_noise) return fail(PCC_EINVAL, "the latency-noise and congestion-window options cannot be combined");
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_cwnd_mode between pcc_step_send and pcc_step_retire");
     sim->d.use_cwnd = enable ? 1 : 0;
     sim->ever_reset = false;  // in-flight accounting differs: a reset must follow
+    return PCC_OK;
+}
+
+int pcc_set_latency_noise(pcc_sim_t *sim, int enable, double max_noise) {
+    if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_latency_noise between pcc_step_send and pcc_step_retire");
+    if (enable) {
+        if (sim->d.ns != 1) return fail(PCC_EINVAL, "the latency-noise option supports one sender per env");
+        if (sim->d.use_cwnd) return fail(PCC_EINVAL, "the latency-noise and congestion-window options cannot be combined");
+        if (!(max_noise >= 1.0) || !(max_noise <= 16.0)) return fail(PCC_EINVAL, "max_noise must be in [1, 16] (the reference: 1.1)");
+        if (!sim->noise_blob) {
+            DeviceGuard guard(sim->device);
+            const size_t per = (size_t)sim->d.n * sim->ring_capacity * sizeof(double2);
+            void *p = nullptr;
+            if (hipMalloc(&p, 2 * per) != hipSuccess)
+                return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the latency-noise event heaps failed", 2 * per);
+            sim->noise_blob = p;
+            sim->noise_bytes = 2 * per;
+            sim->d.noise_heap = static_cast<double2 *>(p);
+            sim->d.noise_rtt = sim->d.noise_heap + (size_t)sim->d.n * sim->ring_capacity;
+            sim->d.noise_cap = sim->ring_capacity;
+        }
+        sim->d.noise_span = max_noise - 1.0;  // random.uniform(a, b) = a + (b - a) * random()
+    }
+    sim->d.use_noise = enable ? 1 : 0;
+    sim->ever_reset = false;  // the in-flight packets live in another structure: a reset must follow
+    sim->read_buf = -1;
     return PCC_OK;
 }
 
@@ -2813,6 +3024,7 @@ int pcc_step_send(pcc_sim_t *sim, const void *actions, int actions_f64, void *st
     if (!sim || !actions) return fail(PCC_EINVAL, "NULL argument");
     if (!sim->ever_reset) return fail(PCC_ESTATE, "pcc_step before pcc_reset (the reference raises TypeError: run_dur is None)");
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_step_send called twice without pcc_step_retire");
+    if (sim->d.use_noise) return fail(PCC_ESTATE, "the latency-noise option has no separate send half: use pcc_step");
     DeviceGuard guard(sim->device);
     const int rc = launch_send(sim, 0, 0, 0, actions, actions_f64, static_cast<hipStream_t>(stream));
     if (rc == PCC_OK) sim->send_pending = true;
@@ -2838,8 +3050,7 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_step between pcc_step_send and pcc_step_retire");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = launch_send(sim, 0, 0, 0, actions, actions_f64, st);
-    if (rc == PCC_OK) rc = launch_retire(sim, 0, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
+    const int rc = launch_mi(sim, 0, 0, 0, 0, actions, actions_f64, obs_out, reward_out, done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
     return after_mi(sim, obs_out, auto_reset, st);
 }

@@ -54,7 +54,7 @@ class BatchedNetworkEnv(object):
 
     def __init__(self, n_envs, device="cuda", history_len=None, features=None, seed=0, n_senders=1,
                  link_params=None, env_gid_base=0, ring_capacity=0, auto_reset=True, delta_scale=None,
-                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False, use_cwnd=False):
+                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False, use_cwnd=False, latency_noise=None):
         if history_len is None:
             history_len = arg_or_default("--history-len", default=10)
         if features is None:
@@ -91,6 +91,10 @@ class BatchedNetworkEnv(object):
         self.action_dim = 2 if self.use_cwnd else 1
         if self.use_cwnd:
             check(L.pcc_set_cwnd_mode(self._h, 1))
+        # ... and USE_LATENCY_NOISE (ns:51-52): latency_noise = MAX_LATENCY_NOISE (the reference: 1.1), None = off
+        self.latency_noise = None if not latency_noise else float(latency_noise)
+        if self.latency_noise:
+            check(L.pcc_set_latency_noise(self._h, 1, self.latency_noise))
 
         N, S, D = self.n_envs, self.n_senders, self.obs_dim
         with torch.cuda.device(self.device):
@@ -380,10 +384,11 @@ class SimulatedNetworkEnv(object):
 
     metadata = {"render.modes": []}
 
-    def __init__(self, history_len=None, features=None, device="cuda", seed=0, link_params=None, use_cwnd=False):
+    def __init__(self, history_len=None, features=None, device="cuda", seed=0, link_params=None, use_cwnd=False,
+                 latency_noise=None):
         self._env = BatchedNetworkEnv(1, device=device, history_len=history_len, features=features, seed=seed,
                                       link_params=link_params, auto_reset=False, record_steps=True,
-                                      use_cwnd=use_cwnd)
+                                      use_cwnd=use_cwnd, latency_noise=latency_noise)
         self.history_len = self._env.history_len
         self.features = self._env.features
         self.observation_space = self._env.single_observation_space

@@ -553,6 +553,83 @@ def test_use_cwnd_philox_batch_matches_oracle():
     env.close()
 
 
+@pytest.mark.parametrize("name", ["noise_pm1", "noise_fixed_q1", "noise_fixed_lossy", "noise_fixed_deepq"])
+def test_use_latency_noise_goldens_bit_exact(name):
+    """The reference's dormant USE_LATENCY_NOISE engine option (every link latency x random.uniform(1.0, 1.1):
+    packets overtake each other on both hops) on traces of the unmodified reference run with the flag set."""
+    d = load(name)
+    n = d["seed"].shape[0]
+    feats = [str(f) for f in d["features"]]
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, history_len=int(d["history_len"]), features=feats,
+                                       record_steps=True, auto_reset=False, latency_noise=1.1)
+    p = d["params"]
+    env.set_link_params(p[:, 0], p[:, 1], np.round(p[:, 2]), p[:, 3], p[:, 4])
+    k = int((d["rng"][:, 1] - d["rng"][:, 0]).max())
+    trace = np.stack([oracle.mt_uniforms(int(s), k, skip=int(o)) for s, o in zip(d["seed"], d["rng"][:, 0])])
+    env.set_loss_trace(trace)
+    obs0 = env.reset().cpu().numpy()
+    assert np.array_equal(obs0, d["obs0"].astype(np.float32))
+    assert np.array_equal(env.state("now").cpu().numpy(), d["warm"][:, 0])
+    rows, obs = [], []
+    for t in range(d["actions"].shape[1]):
+        o, r, dn, info = env.step(d["actions"][:, t])
+        rows.append(info["steps"].clone()); obs.append(o.clone())
+    env.check_flags()
+    steps = torch.stack(rows, 1).cpu().numpy()
+    assert np.array_equal(steps[..., :3], d["steps"][..., :3])
+    assert np.array_equal(steps, d["steps"])
+    nf = d["obs_tail"].shape[2]
+    assert np.array_equal(torch.stack(obs, 1).cpu().numpy()[..., -nf:], d["obs_tail"].astype(np.float32))
+    env.close()
+
+
+def test_use_latency_noise_philox_batch_matches_oracle():
+    """... and on its own counter-based streams against the oracle with the option on: 200 envs with random links,
+    two episodes back to back (auto-reset), every column and the observations."""
+    n_envs, n_steps, seed = 200, 60, 91
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=True,
+                                       latency_noise=1.1, max_steps=n_steps // 2)
+    env.reset()
+    acts = np.random.RandomState(seed).uniform(-1, 1, (n_envs, n_steps))
+    rows, obs = [], []
+    for t in range(n_steps):
+        o, r, dn, info = env.step(acts[:, t])
+        rows.append(info["steps"].clone()); obs.append(o.clone())
+    env.check_flags()
+    steps = torch.stack(rows, 1).cpu().numpy()
+    half = n_steps // 2
+    obs = torch.stack(obs, 1).cpu().numpy()
+    ref1 = oracle.run_batch(acts[:, :half], rng_mode=oracle.RNG_PHILOX, seed=seed, latency_noise=1.1)
+    assert np.array_equal(steps[:, :half, :3], ref1["steps"][..., :3])
+    assert np.array_equal(steps[:, :half], ref1["steps"])
+    assert np.array_equal(obs[:, :half - 1], ref1["obs"].astype(np.float32)[:, :half - 1])
+    assert np.array_equal(obs[:, half - 1], ref1["obs0"].astype(np.float32))     # the auto-reset's observation
+    # episode index 1 of the same envs (run_batch reports the last of its episodes)
+    ref2 = oracle.run_batch(acts[:, half:], rng_mode=oracle.RNG_PHILOX, seed=seed, latency_noise=1.1, n_episodes=2)
+    assert np.array_equal(steps[:, half:], ref2["steps"])
+    assert np.array_equal(obs[:, half:-1], ref2["obs"].astype(np.float32)[:, :half - 1])
+    # the noiseless engine gives other numbers on the same streams (the option really is on)
+    plain = oracle.run_batch(acts[:, :half], rng_mode=oracle.RNG_PHILOX, seed=seed)
+    assert not np.array_equal(plain["steps"], ref1["steps"])
+    env.close()
+
+
+def test_latency_noise_refuses_what_it_does_not_cover():
+    env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, n_senders=2, auto_reset=False)
+    with pytest.raises(pcc_rl_amd.PccError):
+        pcc_rl_amd.native.check(env._L.pcc_set_latency_noise(env._h, 1, 1.1))
+    env.close()
+    env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, use_cwnd=True, auto_reset=False)
+    with pytest.raises(pcc_rl_amd.PccError):
+        pcc_rl_amd.native.check(env._L.pcc_set_latency_noise(env._h, 1, 1.1))
+    env.close()
+    env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, latency_noise=1.1, auto_reset=False)
+    env.reset()
+    with pytest.raises(pcc_rl_amd.PccError):
+        env.step_send(torch.zeros(8, device=DEV))
+    env.close()
+
+
 def test_grouped_env_is_the_same_envs_on_several_streams():
     """GroupedNetworkEnv: groups stepped on their own streams give the numbers of one batch."""
     n, T, seed = 512, 80, 9
