@@ -22,8 +22,8 @@ for t in range(310):
     if t in (20, 100, 200, 300):
         raw = env.debug_timeline().astype(np.int64)
         n_items = int(env.debug_pass_stats(reset=False)["items"])
-        bl = raw[n_items:].reshape(-1, 16)          # one row per retire workgroup (4 wavefronts)
-        waves = bl.shape[0] * 4
+        bl = raw[n_items:].reshape(-1, 16)          # one row per retire workgroup
+        waves = (N + 3) // 4                        # 16 lanes per env
         rec = {"step": t, "us_per_wavefront": {v: float(bl[:, k].sum()) / 100.0 / waves for k, v in names.items()}}
         rec["us_per_wavefront"]["total"] = sum(rec["us_per_wavefront"].values())
         out.append(rec)
