@@ -1322,7 +1322,14 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
 // neighbour.  The lists are a permutation of the envs whatever the predictions say (a reset in
 // between leaves stale predictions: harmless).
 constexpr int kClasses = 32;
-constexpr int kClsStride = kClasses + 2;  // per buffer: kClasses counts, the item cursor, spare
+constexpr int kCntStride = 32;            // words between two counters: every class count has its own 128-byte line.  The
+                                          // retire launch reads one buffer's counts while it files into the other with
+                                          // atomics; a load from a line that atomics are queueing on waits behind them (a
+                                          // shared line made the launch 45 % slower), and atomics on one line serialize
+constexpr int kClsStride = (kClasses + 1) * kCntStride;  // words per buffer: kClasses counts + the count of the restart list
+constexpr int kRestart = kClasses;        // row of the envs that finished their episode in the filing retire launch:
+                                          // the next send launch runs their reset's two warm-up intervals first
+constexpr int kListRows = kClasses + 1;
 
 __device__ __forceinline__ int class_of(float pred) {
     if (!(pred >= 8.0f)) return 0;
@@ -1340,94 +1347,7 @@ __device__ __forceinline__ int class_of(float pred) {
 constexpr uint32_t kShards = 16;
 constexpr uint32_t kCursorStride = 32;  // words between shard cursors: one 128-byte line each
 
-template <int NS, bool TRACE>
-__global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf, int zero_buf, int warm, uint32_t warm_mi,
-                                                         int gate, const void *actions, int actions_f64) {
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;  // every wavefront works on its own
-    const uint32_t n_waves = gridDim.x * (blockDim.x / kWave);                      // a multiple of kShards
-    const uint32_t E = D.send_envs_per_wave;
-    // auto-reset launches of a step in which no env finished have nothing to do (envs at different
-    // points of their episodes: the host cannot know)
-    if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-    if (wave == 0 && lane == 0 && !warm) *D.any_done = 0u;  // consumed by the reset launches of the step before
-    if (wave == 0 && zero_buf >= 0) {
-        if (lane < (uint32_t)kClsStride) D.cls_count[zero_buf * kClsStride + lane] = 0u;
-        if (lane < kShards) D.cursors[((uint32_t)zero_buf * kShards + lane) * kCursorStride] = 0u;
-    }
-    // ---- item table, longest items first: lane l < kClasses looks after class kClasses-1-l and ranks it
-    // by how long one of its items runs -- an env on the wave path costs ~12 ns per packet, a light item
-    // lasts as long as its lanes, ~0.4 us per packet of the class -- so the giants and the long light
-    // items start at once and the short items fill in behind them.
-    const bool listed = read_buf >= 0;
-    const int cls_mine = kClasses - 1 - (int)lane;
-    const int cls_heavy = D.use_cwnd ? kClasses : (D.heavy_predict >= 1e9 ? kClasses : class_of((float)D.heavy_predict));
-    uint32_t n_mine = 0, items_mine = 0;
-    float est = -1.0f;  // lanes without a class sort last
-    if (listed && lane < (uint32_t)kClasses) {
-        n_mine = D.cls_count[read_buf * kClsStride + cls_mine];
-        const bool hv = cls_mine >= cls_heavy;
-        items_mine = hv ? n_mine : (n_mine + E - 1) / E;
-        const float pk = 8.0f * __expf(0.22314355f * ((float)cls_mine - 0.5f));  // 8 * 1.25^(c - 1/2)
-        est = pk * (hv ? 0.012f : 0.4f);
-    }
-    uint32_t rank = 0;  // classes that go before mine
-    for (uint32_t l = 0; l < (uint32_t)kClasses; l++) {
-        const float other = __shfl(est, (int)l);
-        rank += (other > est || (other == est && l < lane)) ? 1u : 0u;
-    }
-    // the table lives in LDS (one copy per wavefront: no barrier needed), indexed by rank
-    __shared__ uint32_t s_tab[4][4][kClasses];
-    uint32_t (*tab)[kClasses] = s_tab[threadIdx.x / kWave];
-    if (lane < (uint32_t)kClasses) { tab[1][rank] = items_mine; tab[2][rank] = n_mine; tab[3][rank] = (uint32_t)cls_mine; }
-    uint32_t incl = lane < (uint32_t)kClasses ? tab[1][lane] : 0u;  // inclusive prefix in rank order
-    for (int o = 1; o < kClasses; o <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-        if (lane >= (uint32_t)o) incl += up;
-    }
-    if (lane < (uint32_t)kClasses) tab[0][lane] = incl;
-    const uint32_t n_items = listed ? rl_u32(incl, kClasses - 1) : (uint32_t)((D.n + E - 1) / E);
-    if (D.pass_stats && wave == 0 && lane == 0) D.pass_stats[15] = n_items;
-    uint32_t *cursors = D.cursors + (uint32_t)(listed ? read_buf : 2) * kShards * kCursorStride;
-    const uint32_t s_mine = wave % kShards, c0 = n_waves / kShards;
-    uint32_t t = wave;  // the first item: no claim
-    for (;;) {
-        if (t >= n_items) {
-            t = 0xFFFFFFFFu;
-            if (lane == 0 && listed) {
-                for (uint32_t k = 0; k < kShards && t == 0xFFFFFFFFu; k++) {
-                    const uint32_t sh = (s_mine + k) % kShards;
-                    uint32_t *cur = cursors + sh * kCursorStride;
-                    const uint32_t seen = __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint64_t)(seen + c0) * kShards + sh >= n_items) continue;  // looks empty: no atomic
-                    const uint64_t cand = (uint64_t)(atomicAdd(cur, 1u) + c0) * kShards + sh;
-                    if (cand < n_items) t = (uint32_t)cand;
-                }
-            }
-            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-            if (t == 0xFFFFFFFFu) break;
-        }
-        int64_t i;
-        bool has, heavy = false;
-        if (listed) {
-            const uint64_t above = __ballot(lane < (uint32_t)kClasses && tab[0][lane & (kClasses - 1)] > t);
-            const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
-            const int cls = (int)tab[3][L];
-            const uint32_t off = t - (tab[0][L] - tab[1][L]);
-            const uint32_t n_cls = tab[2][L];
-            const uint32_t *list = D.cls_list + ((size_t)read_buf * kClasses + cls) * (size_t)D.n;
-            heavy = cls >= cls_heavy;
-            const uint32_t idx = heavy ? off : off * E + lane;
-            has = heavy ? lane == 0 : (lane < E && idx < n_cls);
-            i = has ? (int64_t)list[idx] : 0;
-        } else {
-            i = (int64_t)t * E + lane;
-            has = lane < E && i < D.n;
-        }
-        send_item<NS, TRACE>(D, lane, i, has, heavy, t, warm, warm_mi, actions, actions_f64);
-        t = listed ? n_items /* forces a claim */ : t + n_waves /* without lists the items are dealt statically */;
-    }
-}
+// (send_kernel itself follows retire_env below: a restart item runs the env's warm-up intervals through both halves)
 
 // ======================================================================================
 // retire_kernel: 16 lanes per env
@@ -2020,10 +1940,90 @@ __device__ __noinline__ NoiseOut noise_engine(const Dev &D, int64_t i, double st
     return o;
 }
 
-// Returns the env's predicted packet count for the next monitor interval (< 0: nothing to report).
+// ns:454-477 for one env, by one lane: parameters, fresh link/sender/history state (the two warm-up MIs,
+// ns:478-479, are run by the send and retire halves in warm mode).  The caller sets D.env[i].resetting.
+// The senders' ring-pool slots go back to their free stacks here (nothing is in flight any more) -- pushes
+// happen only in reset and retire launches, pops only in send launches: no stack races.
+template <int NS>
+__device__ __forceinline__ void release_ring_slots(const Dev &D, const int64_t i) {
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int64_t k = (int64_t)s * D.n + i;
+        for (int c = 1; c < D.n_tiers; c++) {
+            const uint32_t held = D.snd[k].ring_held[c];
+            if (held) {
+                D.tier_free[c][atomicAdd(&D.tier_top[c], 1)] = held - 1u;
+                D.snd[k].ring_held[c] = 0;
+            }
+        }
+        D.snd[k].ring_tier = 0;  // the sender starts over in its own tier-0 rings
+        D.snd[k].ring_base = D.tier_base[0] + (size_t)((int64_t)i * NS + s) * tier_slot_bytes(D, 0);
+    }
+}
+
+// (the caller has released the ring-pool slots)
+template <int NS>
+__device__ __forceinline__ void reset_env(const Dev &D, const int64_t i, float *obs_out) {
+    const uint32_t episode = D.env[i].episode;
+    D.env[i].episode = episode + 1;
+
+    double bw, lat, queue, loss, rate0[NS];
+    if (D.p_bw) {
+        bw = D.p_bw[i]; lat = D.p_dl[i]; queue = D.p_queue[i]; loss = D.p_loss[i];
+#pragma unroll
+        for (int s = 0; s < NS; s++) rate0[s] = D.p_rate0[(int64_t)s * D.n + i];
+    } else {  // ns:455-466
+        uint32_t w0[4], w1[4];
+        const uint32_t gid = D.gid_base + (uint32_t)i;
+        philox4x32_10(0u, kParamTag, episode, gid, D.key0, D.key1, w0);
+        philox4x32_10(1u, kParamTag, episode, gid, D.key0, D.key1, w1);
+        bw = D.lo[0] + (D.hi[0] - D.lo[0]) * u32_to_unit(w0[0]);
+        lat = D.lo[1] + (D.hi[1] - D.lo[1]) * u32_to_unit(w0[1]);
+        queue = (double)(1 + (long long)exp(D.lo[2] + (D.hi[2] - D.lo[2]) * u32_to_unit(w0[2])));
+        loss = D.lo[3] + (D.hi[3] - D.lo[3]) * u32_to_unit(w0[3]);
+#pragma unroll
+        for (int s = 0; s < NS; s++) rate0[s] = (D.lo[4] + (D.hi[4] - D.lo[4]) * u32_to_unit(w1[s])) * bw;
+    }
+    // caller-supplied parameters cannot be checked on the host (device arrays): never silent
+    if (!(bw > 0.0) || !(bw <= 1e8) || !(lat > 0.0) || !(queue >= 1.0) || !(loss >= 0.0) || !(loss <= 1.0)) D.env[i].flags |= PCC_FLAG_BAD_PARAMS;
+    D.env[i].bw = bw; D.env[i].dl = lat; D.env[i].lr = loss;
+    D.env[i].maxq = queue / bw;   // ns:64
+    D.env[i].ebw = 1.0 / bw;      // ns:77
+    D.env[i].q = 0.0; D.env[i].tu = 0.0; D.env[i].now = 0.0;
+    D.env[i].run_dur = 3 * lat;   // ns:467
+    D.env[i].steps = 0;
+    D.env[i].done = 0;
+    D.env[i].cwnd = 25;       // ns:209, 227
+    D.env[i].mi_draws = 0; D.env[i].ep_draws = 0;
+    D.env[i].heap_n = 0;      // latency-noise option: nothing in flight (the first SEND is next_send)
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int64_t k = (int64_t)s * D.n + i;
+        D.snd[k].rate = rate0[s];
+        D.snd[k].rate0 = rate0[s];
+        D.snd[k].next_send = 1.0 / rate0[s];  // ns:111
+        D.snd[k].ha = 0; D.snd[k].hd = 0; D.snd[k].ta = 0; D.snd[k].td = 0; D.snd[k].mi_sent = 0;
+        D.snd[k].min_lat = 0.0;   // fresh sender id => no connection minimum yet (ns:229-233, so:158)
+        D.snd[k].ep_return = 0.0;
+        // all-empty history (so:57-62): every metric of an empty MI is 0 except the two ratios
+        float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
+        float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
+        for (int h = 0; h < D.H; h++)
+            for (int f = 0; f < D.F; f++) {
+                const int id = D.fid[f];
+                const double v = (id == PCC_M_SEND_RATIO || id == PCC_M_LATENCY_RATIO) ? 1.0 : 0.0;
+                const float x = (float)(v / c_metric_scale[id]);
+                hist[h * D.F + f] = x;
+                if (obs) obs[h * D.F + f] = x;
+            }
+    }
+}
+
+// Returns the env's predicted packet count for the next monitor interval (-1: nothing to report; -2: the env finished its
+// episode and was reset here -- restart = 1 -- its warm-up intervals are due in the next send launch).
 template <int NS, bool NOISE>
 __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const Group g, int warm, uint32_t warm_mi,
-                                            int last_warm, float *obs_out, float *reward_out, uint8_t *done_out,
+                                            int last_warm, int restart, float *obs_out, float *reward_out, uint8_t *done_out,
                                             double *steps_out, const void *actions, int actions_f64) {
     static_assert(!NOISE || NS == 1, "the latency-noise option is built for one sender");
     if (warm && !D.env[i].resetting) return -1.0f;
@@ -2085,7 +2085,9 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             D.snd[i].rate = rate;
             D.env[i].q = o.q; D.env[i].tu = o.tu;
         }
-        __threadfence();  // the RTT samples the lead lane stored are read by all 16 lanes below
+        // the RTT samples the lead lane stored are read by all 16 lanes below: same wavefront, same L1 -- a workgroup-scope
+        // fence orders them (an agent-scope one writes back and invalidates the XCD's whole L2)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         now = gbcast(o.now, 0); nsend[0] = gbcast(o.nsend, 0);
         sent[0] = gbcast(o.sent, 0); acked[0] = gbcast(o.acked, 0); lost[0] = gbcast(o.lost, 0);
         flags |= gbcast(o.flags, 0);
@@ -2306,12 +2308,19 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             if (id == PCC_M_SEND_RATE || id == PCC_M_RECV_RATE) val = val / 1e7;
             if (((keep + f) & (kGroup - 1)) == (int)g.lane) new_feat = (float)val;
         }
+        // an env that finishes its episode here and restarts (see the end of this function) shows the first observation
+        // of its next episode: the all-empty history (so:57-62; every metric of an empty MI is 0 but the two ratios)
+        const bool restarts = restart && steps + 1 >= D.max_steps;
         for (int base = 0; base < D.HF && !(D.debug_skip & 2); base += kGroup) {
             const int x = base + (int)g.lane;
             float v = new_feat;  // x in [keep, HF): F <= 16, so a lane owns at most one feature entry
             if (x < keep) v = small_hist ? (base ? old_row[1] : old_row[0]) : hist[x + D.F];
             if (x < D.HF) {
                 hist[x] = v;
+                if (restarts) {
+                    const int id = D.fid[x % D.F];
+                    v = (float)(((id == PCC_M_SEND_RATIO || id == PCC_M_LATENCY_RATIO) ? 1.0 : 0.0) / c_metric_scale[id]);
+                }
                 if (obs) obs[x] = v;
             }
         }
@@ -2346,12 +2355,145 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         if (done) *D.any_done = 1u;  // somebody needs the auto-reset launches of this step
         if (done_out) done_out[i] = done;
     }
+    if (restart && steps + 1 >= D.max_steps) {
+        // auto-reset of envs that are not in lockstep, without extra launches: the env is marked and filed in the restart
+        // list, and the send launch of the next step gives it new links (ns:469-477) and runs the two warm-up
+        // intervals (ns:478-479) right before its first interval -- nothing in between reads any of that (the first
+        // observation of an episode is the empty history, written above)
+        if (lead) {
+            D.env[i].resetting = 2;
+            release_ring_slots<NS>(D, i);  // here, not in the send launch: see release_ring_slots
+        }
+        return -2.0f;
+    }
     PCC_TL_STAMP(11)  // outputs
     if (tl) atomicMax(reinterpret_cast<unsigned long long *>(&tlw[1]), (unsigned long long)tl_t);
 #undef PCC_TL_STAMP
     // prediction for the next MI's send half: packets ~ MI length x current rate (the next action
     // moves the rate by at most a few percent)
     return (float)(new_run_dur * rate_sum);
+}
+
+template <int NS, bool TRACE>
+__global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf, int zero_buf, int warm, uint32_t warm_mi,
+                                                         int gate, const void *actions, int actions_f64) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;  // every wavefront works on its own
+    const uint32_t n_waves = gridDim.x * (blockDim.x / kWave);                      // a multiple of kShards
+    const uint32_t E = D.send_envs_per_wave;
+    // auto-reset launches of a step in which no env finished have nothing to do (envs at different
+    // points of their episodes: the host cannot know)
+    if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (wave == 0 && lane == 0 && !warm) *D.any_done = 0u;  // consumed by the reset launches of the step before
+    if (wave == 0 && zero_buf >= 0) {
+        if (lane <= (uint32_t)kClasses) D.cls_count[zero_buf * kClsStride + lane * kCntStride] = 0u;
+        if (lane < kShards) D.cursors[((uint32_t)zero_buf * kShards + lane) * kCursorStride] = 0u;
+    }
+    // ---- item table, longest items first: lane l < kClasses looks after class kClasses-1-l and ranks it
+    // by how long one of its items runs -- an env on the wave path costs ~12 ns per packet, a light item
+    // lasts as long as its lanes, ~0.4 us per packet of the class -- so the giants and the long light
+    // items start at once and the short items fill in behind them.
+    const bool listed = read_buf >= 0;
+    const int cls_mine = kClasses - 1 - (int)lane;
+    const int cls_heavy = D.use_cwnd ? kClasses : (D.heavy_predict >= 1e9 ? kClasses : class_of((float)D.heavy_predict));
+    uint32_t n_mine = 0, items_mine = 0;
+    float est = -1.0f;  // lanes without a class sort last
+    if (listed && lane < (uint32_t)kClasses) {
+        n_mine = D.cls_count[read_buf * kClsStride + cls_mine * kCntStride];
+        const bool hv = cls_mine >= cls_heavy;
+        items_mine = hv ? n_mine : (n_mine + E - 1) / E;
+        const float pk = 8.0f * __expf(0.22314355f * ((float)cls_mine - 0.5f));  // 8 * 1.25^(c - 1/2)
+        est = pk * (hv ? 0.012f : 0.4f);
+    }
+    uint32_t rank = 0;  // classes that go before mine
+    for (uint32_t l = 0; l < (uint32_t)kClasses; l++) {
+        const float other = __shfl(est, (int)l);
+        rank += (other > est || (other == est && l < lane)) ? 1u : 0u;
+    }
+    // the table lives in LDS (one copy per wavefront: no barrier needed), indexed by rank
+    __shared__ uint32_t s_tab[4][4][kClasses];
+    uint32_t (*tab)[kClasses] = s_tab[threadIdx.x / kWave];
+    if (lane < (uint32_t)kClasses) { tab[1][rank] = items_mine; tab[2][rank] = n_mine; tab[3][rank] = (uint32_t)cls_mine; }
+    uint32_t incl = lane < (uint32_t)kClasses ? tab[1][lane] : 0u;  // inclusive prefix in rank order
+    for (int o = 1; o < kClasses; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o) incl += up;
+    }
+    if (lane < (uint32_t)kClasses) tab[0][lane] = incl;
+    // the restart list (envs the last retire launch reset: warm-up intervals first) goes in front, one env per item
+    const uint32_t n_restart = listed ? D.cls_count[read_buf * kClsStride + kRestart * kCntStride] : 0u;
+    const uint32_t n_items = listed ? n_restart + rl_u32(incl, kClasses - 1) : (uint32_t)((D.n + E - 1) / E);
+    if (D.pass_stats && wave == 0 && lane == 0) D.pass_stats[15] = n_items;
+    uint32_t *cursors = D.cursors + (uint32_t)(listed ? read_buf : 2) * kShards * kCursorStride;
+    const uint32_t s_mine = wave % kShards, c0 = n_waves / kShards;
+    uint32_t t = wave;  // the first item: no claim
+    for (;;) {
+        if (t >= n_items) {
+            t = 0xFFFFFFFFu;
+            if (lane == 0 && listed) {
+                for (uint32_t k = 0; k < kShards && t == 0xFFFFFFFFu; k++) {
+                    const uint32_t sh = (s_mine + k) % kShards;
+                    uint32_t *cur = cursors + sh * kCursorStride;
+                    const uint32_t seen = __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint64_t)(seen + c0) * kShards + sh >= n_items) continue;  // looks empty: no atomic
+                    const uint64_t cand = (uint64_t)(atomicAdd(cur, 1u) + c0) * kShards + sh;
+                    if (cand < n_items) t = (uint32_t)cand;
+                }
+            }
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            if (t == 0xFFFFFFFFu) break;
+        }
+        int64_t i;
+        bool has, heavy = false;
+        const bool restart_item = t < n_restart;
+        if (restart_item) {
+            heavy = true;
+            has = lane == 0;
+            i = has ? (int64_t)D.cls_list[((size_t)read_buf * kListRows + kRestart) * (size_t)D.n + t] : 0;
+        } else if (listed) {
+            const uint32_t tc = t - n_restart;
+            const uint64_t above = __ballot(lane < (uint32_t)kClasses && tab[0][lane & (kClasses - 1)] > tc);
+            const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
+            const int cls = (int)tab[3][L];
+            const uint32_t off = tc - (tab[0][L] - tab[1][L]);
+            const uint32_t n_cls = tab[2][L];
+            const uint32_t *list = D.cls_list + ((size_t)read_buf * kListRows + cls) * (size_t)D.n;
+            heavy = cls >= cls_heavy;
+            const uint32_t idx = heavy ? off : off * E + lane;
+            has = heavy ? lane == 0 : (lane < E && idx < n_cls);
+            i = has ? (int64_t)list[idx] : 0;
+        } else {
+            i = (int64_t)t * E + lane;
+            has = lane < E && i < D.n;
+        }
+        // a restart item: warm-up interval 0, warm-up interval 1 (send + retire each, ns:478-479), then the env's
+        // first interval like everybody's; any other item: that last pass only
+        if (restart_item) {
+            // new links and fresh state (ns:469-477) unless a flush already did all of it (pcc_get_state, a masked reset)
+            if (has && D.env[i].resetting == 2) reset_env<NS>(D, i, nullptr);
+            // what one lane wrote is read by the others of this wavefront: a workgroup-scope fence is enough, and an
+            // agent-scope one (__threadfence) writes back and invalidates the XCD's whole L2 under everybody's feet --
+            // with ~160 restart items per launch that made every other item 2.5 x slower
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        for (int pass = restart_item ? 0 : 2; pass < 3; pass++) {
+            const bool wu = pass < 2;
+            send_item<NS, TRACE>(D, lane, i, has, heavy, t, wu ? 1 : warm, wu ? (uint32_t)pass : warm_mi, actions, actions_f64);
+            if (wu) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // records and state just written are read by other lanes
+                const int64_t i0 = (int64_t)__builtin_amdgcn_readfirstlane((int)i) |
+                                   ((int64_t)__builtin_amdgcn_readfirstlane((int)(i >> 32)) << 32);
+                if (lane < (uint32_t)kGroup) {
+                    Group g;
+                    g.lane = lane; g.shift = 0;
+                    (void)retire_env<NS, false>(D, i0, g, 1, (uint32_t)pass, pass == 1, 0, nullptr, nullptr, nullptr, nullptr,
+                                                nullptr, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+        }
+        t = listed ? n_items /* forces a claim */ : t + n_waves /* without lists the items are dealt statically */;
+    }
 }
 
 // Order: with work lists (read_buf >= 0) the launch walks the classes the send half of this step
@@ -2363,7 +2505,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
 // registers are free for the next workgroup as soon as ITS envs are done.
 template <int NS, bool NOISE>
 __global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(Dev D, int read_buf, int fill_buf, int warm,
-                                                              uint32_t warm_mi, int last_warm, int gate, float *obs_out,
+                                                              uint32_t warm_mi, int last_warm, int gate, int restart, float *obs_out,
                                                               float *reward_out, uint8_t *done_out, double *steps_out,
                                                               const void *actions, int actions_f64) {
     if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
@@ -2379,36 +2521,40 @@ __global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(De
     const int64_t pos = (int64_t)blockIdx.x * kPerBlock + (tid / kGroup);
     int64_t i = pos;
     if (read_buf >= 0) {
-        // lane l < kClasses looks after class kClasses-1-l; inclusive prefix of the counts in that order
-        const uint32_t n_mine = lane < (uint32_t)kClasses ? D.cls_count[read_buf * kClsStride + (kClasses - 1 - (int)lane)] : 0u;
+        // lane l < kClasses looks after class kClasses-1-l, lane kClasses after the restart list (envs that were reset
+        // by the retire launch before this one: last); inclusive prefix of the counts in that order
+        const uint32_t row_mine = lane < (uint32_t)kClasses ? (uint32_t)(kClasses - 1) - lane : (uint32_t)kRestart;
+        const uint32_t n_mine = lane <= (uint32_t)kClasses ? D.cls_count[read_buf * kClsStride + row_mine * kCntStride] : 0u;
         uint32_t incl = n_mine;
-        for (int o = 1; o < kClasses; o <<= 1) {
+        for (int o = 1; o <= kClasses; o <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
             if (lane >= (uint32_t)o) incl += up;
         }
-        const uint32_t total = rl_u32(incl, kClasses - 1);
+        const uint32_t total = rl_u32(incl, kClasses);
         i = D.n;  // beyond the lists: nothing
 #pragma unroll
         for (uint32_t grp = 0; grp < kWave / kGroup; grp++) {
             const uint32_t p = (uint32_t)((int64_t)blockIdx.x * kPerBlock + (tid / kWave) * (kWave / kGroup) + grp);
-            const uint64_t above = __ballot(lane < (uint32_t)kClasses && incl > p);
+            const uint64_t above = __ballot(lane <= (uint32_t)kClasses && incl > p);
             if (p < total) {  // wave-uniform
                 const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
+                const uint32_t row = L < (uint32_t)kClasses ? (uint32_t)(kClasses - 1) - L : (uint32_t)kRestart;
                 const uint32_t off = p - (rl_u32(incl, L) - rl_u32(n_mine, L));
-                const uint32_t e = D.cls_list[((size_t)read_buf * kClasses + (kClasses - 1 - L)) * (size_t)D.n + off];
+                const uint32_t e = D.cls_list[((size_t)read_buf * kListRows + row) * (size_t)D.n + off];
                 if (lane / kGroup == grp) i = (int64_t)e;
             }
         }
     }
     float pred = -1.0f;
     if (i < D.n)
-        pred = retire_env<NS, NOISE>(D, i, g, warm, warm_mi, last_warm, obs_out, reward_out, done_out, steps_out, actions,
-                                     actions_f64);
+        pred = retire_env<NS, NOISE>(D, i, g, warm, warm_mi, last_warm, restart, obs_out, reward_out, done_out, steps_out,
+                                     actions, actions_f64);
     if (fill_buf < 0) return;  // warm-up intervals do not file (kernel-uniform)
     // ---- file the workgroup's envs in the class lists of the next send (see "work lists")
     if (g.lane == 0) {
-        s_env[tid / kGroup] = pred >= 0.0f ? (uint32_t)i : 0xFFFFFFFFu;
-        s_cls[tid / kGroup] = (uint32_t)class_of(pred);
+        const bool restart = pred == -2.0f;  // reset inside retire_env: its warm-up intervals come first in the next send
+        s_env[tid / kGroup] = (pred >= 0.0f || restart) ? (uint32_t)i : 0xFFFFFFFFu;
+        s_cls[tid / kGroup] = restart ? (uint32_t)kRestart : (uint32_t)class_of(pred);
     }
     __threadfence_block();
     uint32_t before = 0u;
@@ -2428,9 +2574,9 @@ __global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(De
         if (match && l < leader) leader = l;
     }
     uint32_t base = 0u;
-    if (files && leader == lane) base = atomicAdd(&D.cls_count[fill_buf * kClsStride + c], same);
+    if (files && leader == lane) base = atomicAdd(&D.cls_count[fill_buf * kClsStride + c * kCntStride], same);
     base = (uint32_t)__shfl((int)base, (int)leader);
-    if (files) D.cls_list[((size_t)fill_buf * kClasses + c) * (size_t)D.n + base + rank] = e;
+    if (files) D.cls_list[((size_t)fill_buf * kListRows + c) * (size_t)D.n + base + rank] = e;
 }
 
 // ======================================================================================
@@ -2442,73 +2588,12 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
     if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
     if (i >= D.n) return;
-    const bool sel = (!mask || mask[i]) && (!use_done || D.env[i].done);
+    // use_done 1: the envs that finished their episode; 2: the envs a retire launch marked for a restart
+    const bool sel = use_done == 2 ? D.env[i].resetting == 2 : (!mask || mask[i]) && (!use_done || D.env[i].done);
     D.env[i].resetting = sel ? 1 : 0;
-    if (!sel) return;
-
-    const uint32_t episode = D.env[i].episode;
-    D.env[i].episode = episode + 1;
-
-    double bw, lat, queue, loss, rate0[NS];
-    if (D.p_bw) {
-        bw = D.p_bw[i]; lat = D.p_dl[i]; queue = D.p_queue[i]; loss = D.p_loss[i];
-#pragma unroll
-        for (int s = 0; s < NS; s++) rate0[s] = D.p_rate0[(int64_t)s * D.n + i];
-    } else {  // ns:455-466
-        uint32_t w0[4], w1[4];
-        const uint32_t gid = D.gid_base + (uint32_t)i;
-        philox4x32_10(0u, kParamTag, episode, gid, D.key0, D.key1, w0);
-        philox4x32_10(1u, kParamTag, episode, gid, D.key0, D.key1, w1);
-        bw = D.lo[0] + (D.hi[0] - D.lo[0]) * u32_to_unit(w0[0]);
-        lat = D.lo[1] + (D.hi[1] - D.lo[1]) * u32_to_unit(w0[1]);
-        queue = (double)(1 + (long long)exp(D.lo[2] + (D.hi[2] - D.lo[2]) * u32_to_unit(w0[2])));
-        loss = D.lo[3] + (D.hi[3] - D.lo[3]) * u32_to_unit(w0[3]);
-#pragma unroll
-        for (int s = 0; s < NS; s++) rate0[s] = (D.lo[4] + (D.hi[4] - D.lo[4]) * u32_to_unit(w1[s])) * bw;
-    }
-    // caller-supplied parameters cannot be checked on the host (device arrays): never silent
-    if (!(bw > 0.0) || !(bw <= 1e8) || !(lat > 0.0) || !(queue >= 1.0) || !(loss >= 0.0) || !(loss <= 1.0)) D.env[i].flags |= PCC_FLAG_BAD_PARAMS;
-    D.env[i].bw = bw; D.env[i].dl = lat; D.env[i].lr = loss;
-    D.env[i].maxq = queue / bw;   // ns:64
-    D.env[i].ebw = 1.0 / bw;      // ns:77
-    D.env[i].q = 0.0; D.env[i].tu = 0.0; D.env[i].now = 0.0;
-    D.env[i].run_dur = 3 * lat;   // ns:467
-    D.env[i].steps = 0;
-    D.env[i].done = 0;
-    D.env[i].cwnd = 25;       // ns:209, 227
-    D.env[i].mi_draws = 0; D.env[i].ep_draws = 0;
-    D.env[i].heap_n = 0;      // latency-noise option: nothing in flight (the first SEND is next_send)
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + i;
-        D.snd[k].rate = rate0[s];
-        D.snd[k].rate0 = rate0[s];
-        D.snd[k].next_send = 1.0 / rate0[s];  // ns:111
-        D.snd[k].ha = 0; D.snd[k].hd = 0; D.snd[k].ta = 0; D.snd[k].td = 0; D.snd[k].mi_sent = 0;
-        // nothing is in flight any more: the pool slots go back (pushes only here, pops only in
-        // send launches), the sender starts over in its own tier-0 rings
-        for (int c = 1; c < D.n_tiers; c++) {
-            const uint32_t held = D.snd[k].ring_held[c];
-            if (held) {
-                D.tier_free[c][atomicAdd(&D.tier_top[c], 1)] = held - 1u;
-                D.snd[k].ring_held[c] = 0;
-            }
-        }
-        D.snd[k].ring_tier = 0;
-        D.snd[k].ring_base = D.tier_base[0] + (size_t)((int64_t)i * NS + s) * tier_slot_bytes(D, 0);
-        D.snd[k].min_lat = 0.0;   // fresh sender id => no connection minimum yet (ns:229-233, so:158)
-        D.snd[k].ep_return = 0.0;
-        // all-empty history (so:57-62): every metric of an empty MI is 0 except the two ratios
-        float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
-        float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
-        for (int h = 0; h < D.H; h++)
-            for (int f = 0; f < D.F; f++) {
-                const int id = D.fid[f];
-                const double v = (id == PCC_M_SEND_RATIO || id == PCC_M_LATENCY_RATIO) ? 1.0 : 0.0;
-                const float x = (float)(v / c_metric_scale[id]);
-                hist[h * D.F + f] = x;
-                if (obs) obs[h * D.F + f] = x;
-            }
+    if (sel) {
+        release_ring_slots<NS>(D, i);
+        reset_env<NS>(D, i, obs_out);
     }
 }
 
@@ -2540,6 +2625,7 @@ struct pcc_sim {
     void *noise_blob;   // heap + RTT samples of the latency-noise option (allocated when it is switched on)
     size_t noise_bytes;
     uint32_t ring_capacity;
+    bool restarts_pending;  // a retire launch may have left envs in the restart list (their warm-up intervals are due)
 };
 
 namespace {
@@ -2615,8 +2701,9 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
 
 // RETIRE half; a launch that is not a warm-up interval also files every env in the work lists of the
 // next send (buffer sim->fill_buf, cleared by the send launch before it)
-int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, float *obs_out, float *reward_out,
-                  uint8_t *done_out, double *steps_out, hipStream_t st) {
+// restart: envs that finish their episode in this launch are reset inside it and filed in the restart list
+int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, int restart, float *obs_out,
+                  float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
     const Dev &d = sim->d;
     const int64_t per_block = kRetireBlock / kGroup;
     const dim3 grid((unsigned)((d.n + per_block - 1) / per_block));
@@ -2624,20 +2711,21 @@ int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int
     const int read = (warm || !d.retire_sorted) ? -1 : sim->read_buf;  // the lists this step's send launch read
     if (d.ns == 1)
         hipLaunchKernelGGL((retire_kernel<1, false>), grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm,
-                           gate, obs_out, reward_out, done_out, steps_out, nullptr, 0);
+                           gate, restart, obs_out, reward_out, done_out, steps_out, nullptr, 0);
     else
         hipLaunchKernelGGL((retire_kernel<2, false>), grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm,
-                           gate, obs_out, reward_out, done_out, steps_out, nullptr, 0);
+                           gate, restart, obs_out, reward_out, done_out, steps_out, nullptr, 0);
     const int rc = check_hip(hipGetLastError(), "retire kernel launch");
     if (rc == PCC_OK && !warm) {
         sim->read_buf = sim->fill_buf;
         sim->fill_buf ^= 1;
+        if (restart) sim->restarts_pending = true;
     }
     return rc;
 }
 
-int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, const void *actions, int actions_f64,
-              float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
+int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, int restart, const void *actions,
+              int actions_f64, float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
     if (sim->d.use_noise) {
         // the latency-noise option: the whole interval is one launch of the retire kernel's NOISE build (no send half,
         // no work lists)
@@ -2645,12 +2733,12 @@ int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gat
         const int64_t per_block = kRetireBlock / kGroup;
         const dim3 grid((unsigned)((d.n + per_block - 1) / per_block));
         hipLaunchKernelGGL((retire_kernel<1, true>), grid, dim3(kRetireBlock), 0, st, d, -1, -1, warm, warm_mi, last_warm, gate,
-                           obs_out, reward_out, done_out, steps_out, actions, actions_f64);
+                           0, obs_out, reward_out, done_out, steps_out, actions, actions_f64);
         return check_hip(hipGetLastError(), "noise kernel launch");
     }
     const int rc = launch_send(sim, warm, warm_mi, gate, actions, actions_f64, st);
     if (rc != PCC_OK) return rc;
-    return launch_retire(sim, warm, warm_mi, last_warm, gate, obs_out, reward_out, done_out, steps_out, st);
+    return launch_retire(sim, warm, warm_mi, last_warm, gate, restart, obs_out, reward_out, done_out, steps_out, st);
 }
 
 // reset(): parameters + state, then the two unrecorded warm-up MIs (ns:469-484).  gate: the launches
@@ -2662,8 +2750,24 @@ int launch_reset(pcc_sim_t *sim, const uint8_t *mask, int use_done, int gate, fl
     else hipLaunchKernelGGL(reset_init_kernel<2>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, gate, obs_out);
     int rc = check_hip(hipGetLastError(), "reset kernel launch");
     for (uint32_t w = 0; w < 2 && rc == PCC_OK; w++)
-        rc = launch_mi(sim, 1, w, w == 1, gate, nullptr, 0, nullptr, nullptr, nullptr, nullptr, st);
+        rc = launch_mi(sim, 1, w, w == 1, gate, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, st);
     return rc;
+}
+
+// Auto-reset of envs that are not in lockstep happens inside the step's own launches (the retire half resets a
+// finished env and files it in the restart list, the next send half runs its warm-up intervals) whenever the
+// send half can take such items: not with the congestion-window option (no wave path) or the latency-noise
+// option (no send half) -- those keep the gated reset launches after the step.
+bool restarts_in_step(const pcc_sim_t *sim, int auto_reset) {
+    return auto_reset && !sim->lockstep && !sim->d.use_cwnd && !sim->d.use_noise;
+}
+
+// What is still owed to the envs of the restart list -- new links, fresh state, the two warm-up intervals -- is
+// done now (before the state is read or the lists are dropped), by the ordinary reset launches over the marked envs.
+int flush_restarts(pcc_sim_t *sim, hipStream_t st) {
+    if (!sim->restarts_pending) return PCC_OK;
+    sim->restarts_pending = false;
+    return launch_reset(sim, nullptr, 2, 0, nullptr, st);
 }
 
 }  // namespace
@@ -2805,7 +2909,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         d.pass_counters = atoi(getenv("PCC_DEBUG_TIMELINE")) >= 2;
     }
     // the send half's work lists: two buffers of kClasses lists, each able to hold every env
-    sim->list_bytes = (size_t)2 * kClasses * (size_t)n_envs * sizeof(uint32_t);
+    sim->list_bytes = (size_t)2 * kListRows * (size_t)n_envs * sizeof(uint32_t);
     if (hipMalloc(&sim->list_blob, sim->list_bytes) != hipSuccess) {
         pcc_destroy(sim);
         return fail(PCC_ENOMEM, "hipMalloc(%zu) for the send work lists failed", sim->list_bytes);
@@ -2986,7 +3090,9 @@ int pcc_set_max_steps(pcc_sim_t *sim, int max_steps) {
 int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     DeviceGuard guard(sim->device);
-    const int rc = launch_reset(sim, mask, 0, 0, obs_out, static_cast<hipStream_t>(stream));
+    if (!mask) sim->restarts_pending = false;  // everything starts over
+    int rc = flush_restarts(sim, static_cast<hipStream_t>(stream));
+    if (rc == PCC_OK) rc = launch_reset(sim, mask, 0, 0, obs_out, static_cast<hipStream_t>(stream));
     if (rc != PCC_OK) return rc;
     sim->send_pending = false;
     if (!mask) {
@@ -3009,7 +3115,7 @@ int after_mi(pcc_sim_t *sim, float *obs_out, int auto_reset, hipStream_t st) {
         // when every env is in lockstep the host knows which step finishes the episode and
         // skips the (otherwise no-op) masked reset launches
         const bool may_be_done = !sim->lockstep || sim->host_steps >= d.max_steps;
-        if (may_be_done) {
+        if (may_be_done && !restarts_in_step(sim, auto_reset)) {
             const int rc = launch_reset(sim, nullptr, 1, sim->lockstep ? 0 : 1, obs_out, st);
             if (rc != PCC_OK) return rc;
             if (sim->lockstep) sim->host_steps = 0;
@@ -3038,7 +3144,8 @@ int pcc_step_retire(pcc_sim_t *sim, float *obs_out, float *reward_out, uint8_t *
     if (!sim->send_pending) return fail(PCC_ESTATE, "pcc_step_retire without a preceding pcc_step_send");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rc = launch_retire(sim, 0, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
+    const int rc = launch_retire(sim, 0, 0, 0, 0, restarts_in_step(sim, auto_reset) ? 1 : 0, obs_out, reward_out, done_out,
+                                 steps_out, st);
     if (rc != PCC_OK) return rc;
     sim->send_pending = false;
     return after_mi(sim, obs_out, auto_reset, st);
@@ -3051,7 +3158,8 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_step between pcc_step_send and pcc_step_retire");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rc = launch_mi(sim, 0, 0, 0, 0, actions, actions_f64, obs_out, reward_out, done_out, steps_out, st);
+    const int rc = launch_mi(sim, 0, 0, 0, 0, restarts_in_step(sim, auto_reset) ? 1 : 0, actions, actions_f64, obs_out, reward_out,
+                             done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
     return after_mi(sim, obs_out, auto_reset, st);
 }
@@ -3095,6 +3203,11 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {
 #undef PCC_ENV_FIELD
 #undef PCC_SND_FIELD
     DeviceGuard guard(sim->device);
+    // envs that restarted in the last step show the state after their warm-up intervals, like after any reset
+    if (!sim->send_pending) {
+        const int rc = flush_restarts(sim, static_cast<hipStream_t>(stream));
+        if (rc != PCC_OK) return rc;
+    }
     return check_hip(hipMemcpy2DAsync(out, width, src, 128, width, rows, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)),
                      "pcc_get_state copy");
 }
