@@ -2374,7 +2374,9 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
     return (float)(new_run_dur * rate_sum);
 }
 
-template <int NS, bool TRACE>
+// RESTART: the build that knows restart items (launched when the last retire launch may have filed some); the plain
+// build carries none of that code (the reset and the warm-up retire inlined here cost ~5 % of the launch otherwise)
+template <int NS, bool TRACE, bool RESTART>
 __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf, int zero_buf, int warm, uint32_t warm_mi,
                                                          int gate, const void *actions, int actions_f64) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -2421,7 +2423,7 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
     }
     if (lane < (uint32_t)kClasses) tab[0][lane] = incl;
     // the restart list (envs the last retire launch reset: warm-up intervals first) goes in front, one env per item
-    const uint32_t n_restart = listed ? D.cls_count[read_buf * kClsStride + kRestart * kCntStride] : 0u;
+    const uint32_t n_restart = (RESTART && listed) ? D.cls_count[read_buf * kClsStride + kRestart * kCntStride] : 0u;
     const uint32_t n_items = listed ? n_restart + rl_u32(incl, kClasses - 1) : (uint32_t)((D.n + E - 1) / E);
     if (D.pass_stats && wave == 0 && lane == 0) D.pass_stats[15] = n_items;
     uint32_t *cursors = D.cursors + (uint32_t)(listed ? read_buf : 2) * kShards * kCursorStride;
@@ -2468,29 +2470,33 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
         }
         // a restart item: warm-up interval 0, warm-up interval 1 (send + retire each, ns:478-479), then the env's
         // first interval like everybody's; any other item: that last pass only
-        if (restart_item) {
-            // new links and fresh state (ns:469-477) unless a flush already did all of it (pcc_get_state, a masked reset)
-            if (has && D.env[i].resetting == 2) reset_env<NS>(D, i, nullptr);
-            // what one lane wrote is read by the others of this wavefront: a workgroup-scope fence is enough, and an
-            // agent-scope one (__threadfence) writes back and invalidates the XCD's whole L2 under everybody's feet --
-            // with ~160 restart items per launch that made every other item 2.5 x slower
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        }
-        for (int pass = restart_item ? 0 : 2; pass < 3; pass++) {
-            const bool wu = pass < 2;
-            send_item<NS, TRACE>(D, lane, i, has, heavy, t, wu ? 1 : warm, wu ? (uint32_t)pass : warm_mi, actions, actions_f64);
-            if (wu) {
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // records and state just written are read by other lanes
-                const int64_t i0 = (int64_t)__builtin_amdgcn_readfirstlane((int)i) |
-                                   ((int64_t)__builtin_amdgcn_readfirstlane((int)(i >> 32)) << 32);
-                if (lane < (uint32_t)kGroup) {
-                    Group g;
-                    g.lane = lane; g.shift = 0;
-                    (void)retire_env<NS, false>(D, i0, g, 1, (uint32_t)pass, pass == 1, 0, nullptr, nullptr, nullptr, nullptr,
-                                                nullptr, 0);
-                }
+        if constexpr (RESTART) {
+            if (restart_item) {
+                // new links and fresh state (ns:469-477) unless a flush already did all of it (pcc_get_state, a masked reset)
+                if (has && D.env[i].resetting == 2) reset_env<NS>(D, i, nullptr);
+                // what one lane wrote is read by the others of this wavefront: a workgroup-scope fence is enough, and an
+                // agent-scope one (__threadfence) writes back and invalidates the XCD's whole L2 under everybody's feet --
+                // with ~160 restart items per launch that made every other item 2.5 x slower
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
+            for (int pass = restart_item ? 0 : 2; pass < 3; pass++) {
+                const bool wu = pass < 2;
+                send_item<NS, TRACE>(D, lane, i, has, heavy, t, wu ? 1 : warm, wu ? (uint32_t)pass : warm_mi, actions, actions_f64);
+                if (wu) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // records and state just written are read by other lanes
+                    const int64_t i0 = (int64_t)__builtin_amdgcn_readfirstlane((int)i) |
+                                       ((int64_t)__builtin_amdgcn_readfirstlane((int)(i >> 32)) << 32);
+                    if (lane < (uint32_t)kGroup) {
+                        Group g;
+                        g.lane = lane; g.shift = 0;
+                        (void)retire_env<NS, false>(D, i0, g, 1, (uint32_t)pass, pass == 1, 0, nullptr, nullptr, nullptr, nullptr,
+                                                    nullptr, 0);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+            }
+        } else {
+            send_item<NS, TRACE>(D, lane, i, has, heavy, t, warm, warm_mi, actions, actions_f64);
         }
         t = listed ? n_items /* forces a claim */ : t + n_waves /* without lists the items are dealt statically */;
     }
@@ -2626,6 +2632,7 @@ struct pcc_sim {
     size_t noise_bytes;
     uint32_t ring_capacity;
     bool restarts_pending;  // a retire launch may have left envs in the restart list (their warm-up intervals are due)
+    bool read_has_restarts; // the list buffer read_buf was filed by a retire launch that resets finished envs (restart list)
 };
 
 namespace {
@@ -2689,13 +2696,19 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
     const int64_t unit = (int64_t)kShards * d.send_wg_waves;  // whole workgroups, a multiple of kShards wavefronts
     waves = (waves + unit - 1) / unit * unit;
     const dim3 sgrid((unsigned)(waves / d.send_wg_waves)), sblock(kWave * d.send_wg_waves);
+    // restart items can only be in lists that a retire launch with `restart` filed
+    const bool rs = sim->read_has_restarts && read_buf >= 0;
+#define PCC_LAUNCH_SEND(NS_, TR_, RS_)                                                                                      \
+    hipLaunchKernelGGL((send_kernel<NS_, TR_, RS_>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, \
+                       actions, actions_f64)
     if (d.ns == 1) {
-        if (tr) hipLaunchKernelGGL((send_kernel<1, true>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<1, false>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, actions, actions_f64);
+        if (tr) { if (rs) PCC_LAUNCH_SEND(1, true, true); else PCC_LAUNCH_SEND(1, true, false); }
+        else { if (rs) PCC_LAUNCH_SEND(1, false, true); else PCC_LAUNCH_SEND(1, false, false); }
     } else {
-        if (tr) hipLaunchKernelGGL((send_kernel<2, true>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, actions, actions_f64);
-        else hipLaunchKernelGGL((send_kernel<2, false>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, actions, actions_f64);
+        if (tr) { if (rs) PCC_LAUNCH_SEND(2, true, true); else PCC_LAUNCH_SEND(2, true, false); }
+        else { if (rs) PCC_LAUNCH_SEND(2, false, true); else PCC_LAUNCH_SEND(2, false, false); }
     }
+#undef PCC_LAUNCH_SEND
     return check_hip(hipGetLastError(), "send kernel launch");
 }
 
@@ -2719,6 +2732,7 @@ int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int
     if (rc == PCC_OK && !warm) {
         sim->read_buf = sim->fill_buf;
         sim->fill_buf ^= 1;
+        sim->read_has_restarts = restart != 0;  // the buffer just filed may hold a restart list
         if (restart) sim->restarts_pending = true;
     }
     return rc;

@@ -384,7 +384,8 @@ def test_masked_reset_only_touches_selected_envs():
 
 def test_envs_out_of_lockstep_match_oracle():
     """Masked resets at staggered steps, then auto-resets at each env's own episode end (the path where
-    the host cannot know which step finishes an episode: the reset launches are gated on the device).
+    the host cannot know which step finishes an episode: the retire half marks a finished env, the next send
+    half gives it new links and runs its warm-up intervals as a restart item).
     Every env against its own oracle object driven through the same schedule -- all 19 columns and the
     observations, bit for bit, across episode boundaries."""
     n, seed, max_steps, T = 96, 11, 30, 85
@@ -422,6 +423,11 @@ def test_envs_out_of_lockstep_match_oracle():
                 o_ref = oenvs[i].reset()
                 osteps[i] = 0
             assert np.array_equal(o_gpu[i], o_ref.astype(np.float32)), (t, i)
+        if t % 9 == 4 or t in (29, 30):
+            # reading the state in between (t = 29: right after the envs that were never masked finished) shows every
+            # env after its reset and warm-up intervals, whether or not the library has run them yet
+            assert np.array_equal(env.state("steps").cpu().numpy(), osteps), t
+            assert np.array_equal(env.state("now").cpu().numpy(), np.array([o.cur_time for o in oenvs])), t
     env.check_flags()
     env.close()
 
