@@ -304,10 +304,10 @@ def main():
         send_gbps = send_bytes / (send_ms * 1e-3) / 1e9
         retire_gbps = retire_bytes / (retire_ms * 1e-3) / 1e9
         both = (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "send_kernel<1, false>", "achieved": send_gbps,
+        out["roofline"] = {"bound": "hbm", "kernel": "send_kernel<1, false, false>", "achieved": send_gbps,
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": send_gbps / HBM_PEAK_GBPS,
                            "traffic": None, "kernel_ms": send_ms, "algorithmic_bytes_per_launch": send_bytes,
-                           "other_kernels": [{"kernel": "retire_kernel<1>", "achieved": retire_gbps,
+                           "other_kernels": [{"kernel": "retire_kernel<1, false>", "achieved": retire_gbps,
                                               "frac": retire_gbps / HBM_PEAK_GBPS, "kernel_ms": retire_ms,
                                               "algorithmic_bytes_per_launch": retire_bytes}],
                            "whole_step": {"achieved": both, "frac": both / HBM_PEAK_GBPS}}

@@ -1,0 +1,42 @@
+"""The closed-form wave pass of the send half (pcc_sim.hip: heavy_mi), as a CPU model with the kernel's own
+integer / floating-point operations, against the plain per-packet recurrence (ns:66-84): fuzzed link states
+and the interval-start states of real episodes.  Any mismatch is a counter-example for the kernel's
+preconditions, found without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "models", "send_pass_model.c")
+LIB = os.path.join(HERE, "models", "libsend_pass_model.so")
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", SRC, "-o", LIB, "-lm"])
+    L = ctypes.CDLL(LIB)
+    L.pcc_model_fuzz.restype = ctypes.c_long
+    L.pcc_model_fuzz.argtypes = [ctypes.c_long, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    L.pcc_model_episodes.restype = ctypes.c_long
+    return L
+
+
+def test_fuzzed_link_states(model):
+    stats = (ctypes.c_uint64 * 16)()
+    bad = model.pcc_model_fuzz(20000, 12345, stats)
+    assert bad == 0
+    s = np.array(list(stats), dtype=np.uint64)
+    assert s[:3].sum() > 0          # the closed-form regimes were exercised, not only the serial pass
+
+
+def test_interval_starts_of_real_episodes(model):
+    model.pcc_model_episodes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    stats, hist = (ctypes.c_uint64 * 16)(), (ctypes.c_uint64 * 32)()
+    bad = model.pcc_model_episodes(48, 120, 7, 0, 64, stats, hist)
+    assert bad == 0
+    assert sum(hist) > 0

@@ -46,10 +46,12 @@ for d in sys.argv[2:]:
         continue
     r = json.loads(lines[-1]).get("roofline", {})
     for k in [r] + r.get("other_kernels", []):
-        if k.get("kernel") in out and "algorithmic_bytes_per_launch" in k:
-            out[k["kernel"]]["algorithmic_bytes_per_launch"] = k["algorithmic_bytes_per_launch"]
-            if "hbm_bytes_per_launch" in out[k["kernel"]]:
-                out[k["kernel"]]["traffic_over_algorithmic"] = out[k["kernel"]]["hbm_bytes_per_launch"] / k["algorithmic_bytes_per_launch"]
+        # (match on the kernel's base name: the template arguments in the bench line may lag the code)
+        name = next((n for n in out if n.split("<")[0] == str(k.get("kernel", "")).split("<")[0] and n.split("<")[1][:1] == "1"), None)
+        if name and "algorithmic_bytes_per_launch" in k:
+            out[name]["algorithmic_bytes_per_launch"] = k["algorithmic_bytes_per_launch"]
+            if "hbm_bytes_per_launch" in out[name]:
+                out[name]["traffic_over_algorithmic"] = out[name]["hbm_bytes_per_launch"] / k["algorithmic_bytes_per_launch"]
     break
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 100 --warmup 20 "
                 "--repeats 1 --no-cpu-baseline` (steps 20..120 of an episode); counters are KB per dispatch.  hbm_bytes_per_launch = "

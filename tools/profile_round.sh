@@ -16,5 +16,7 @@ timeout 200 python $R/bench.py --no-cpu-baseline --stagger --steps 800 --repeats
 cd $R
 timeout 200 python tools/send_timeline.py > $O/send_critical_path.json 2> $O/tl.err
 timeout 200 python tools/retire_phases.py > $O/retire_phases.json 2>> $O/tl.err
+timeout 200 python tools/retire_timeline.py > $O/retire_timeline.json 2>> $O/tl.err
+timeout 300 python tools/restart_items.py > $O/restart_items.json 2>> $O/tl.err
 find $O -name "*kernel_stats.csv" | head -3
 tail -c 2500 $O/bench.log
