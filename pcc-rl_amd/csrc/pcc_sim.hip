@@ -317,6 +317,28 @@ __device__ __forceinline__ uint64_t rl_u64(uint64_t v, uint32_t l) {
     const uint32_t lo = rl_u32((uint32_t)v, l), hi = rl_u32((uint32_t)(v >> 32), l);
     return ((uint64_t)hi << 32) | lo;
 }
+// records [h, h + n) of one ring to another, by the whole wavefront, kCopyDepth KB in flight: a load-then-store loop
+// waits one memory round trip per KB, and the promotion of a deep-queue env (10-25 k records) was the send launch's
+// critical path in most steps (100-140 us of a 110-170 us launch)
+constexpr int kCopyDepth = 8;
+__device__ __forceinline__ void copy_records(double2 *dst, uint32_t dmask, const double2 *src, uint32_t smask, uint32_t h,
+                                             uint32_t n, uint32_t lane) {
+    for (uint32_t j0 = 0; j0 < n; j0 += kCopyDepth * kWave) {
+        double2 r[kCopyDepth];
+#pragma unroll
+        for (int b = 0; b < kCopyDepth; b++) {
+            const uint32_t j = j0 + (uint32_t)b * kWave + lane;
+            r[b].x = 0.0; r[b].y = 0.0;
+            if (j < n) r[b] = ld_rec(src + ((h + j) & smask));
+        }
+#pragma unroll
+        for (int b = 0; b < kCopyDepth; b++) {
+            const uint32_t j = j0 + (uint32_t)b * kWave + lane;
+            if (j < n) st_rec(dst + ((h + j) & dmask), r[b]);
+        }
+    }
+}
+
 // Move the rings of sender k (lane `l` of the wavefront owns it) to a free slot of tier >= want:
 // all 64 lanes copy the live records [ha, ta) / [hd, td); ring indices stay what they are, only
 // the address of index j changes.  The slot the sender leaves stays reserved for it until its env
@@ -341,8 +363,8 @@ __device__ __forceinline__ bool promote_rings(const Dev &D, uint32_t lane, uint3
     to.cap = tier_cap(D, got);
     to.base = D.tier_base[got < kMaxTiers ? got : 0] + (size_t)slot * tier_slot_bytes(D, got);
     const uint32_t h_a = rl_u32(ha, l), n_a = rl_u32(ta, l) - h_a, h_d = rl_u32(hd, l), n_d = rl_u32(td, l) - h_d;
-    for (uint32_t j = lane; j < n_a; j += kWave) st_rec(to.accepted() + ((h_a + j) & to.mask()), ld_rec(from.accepted() + ((h_a + j) & from.mask())));
-    for (uint32_t j = lane; j < n_d; j += kWave) st_rec(to.dropped() + ((h_d + j) & to.dmask()), ld_rec(from.dropped() + ((h_d + j) & from.dmask())));
+    copy_records(to.accepted(), to.mask(), from.accepted(), from.mask(), h_a, n_a, lane);
+    copy_records(to.dropped(), to.dmask(), from.dropped(), from.dmask(), h_d, n_d, lane);
     if (lane == l) {
         D.snd[k].ring_base = to.base;
         D.snd[k].ring_tier = (uint8_t)got;
@@ -2391,10 +2413,12 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
         if (lane <= (uint32_t)kClasses) D.cls_count[zero_buf * kClsStride + lane * kCntStride] = 0u;
         if (lane < kShards) D.cursors[((uint32_t)zero_buf * kShards + lane) * kCursorStride] = 0u;
     }
-    // ---- item table, longest items first: lane l < kClasses looks after class kClasses-1-l and ranks it
-    // by how long one of its items runs -- an env on the wave path costs ~12 ns per packet, a light item
-    // lasts as long as its lanes, ~0.4 us per packet of the class -- so the giants and the long light
-    // items start at once and the short items fill in behind them.
+    // ---- item table: lane l < kClasses looks after class kClasses-1-l and ranks it.  The light items go first,
+    // longest first, then the envs of the wave path, longest first (~12 ns per packet; a light item lasts as long
+    // as its lanes, ~0.4 us per packet of the class).  The lane rounds are bound by their scattered 16-byte stores
+    // (without them the launch takes 0.085 instead of 0.151 ms) and slow every other wavefront of their CU down
+    // while they run (a wave-path item next to four of them waits 100+ us for its first loads): started together at
+    // t = 0 and dealt round-robin over the CUs (first_item below) they are out of the way soonest.
     const bool listed = read_buf >= 0;
     const int cls_mine = kClasses - 1 - (int)lane;
     const int cls_heavy = D.use_cwnd ? kClasses : (D.heavy_predict >= 1e9 ? kClasses : class_of((float)D.heavy_predict));
@@ -2405,7 +2429,7 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
         const bool hv = cls_mine >= cls_heavy;
         items_mine = hv ? n_mine : (n_mine + E - 1) / E;
         const float pk = 8.0f * __expf(0.22314355f * ((float)cls_mine - 0.5f));  // 8 * 1.25^(c - 1/2)
-        est = pk * (hv ? 0.012f : 0.4f);
+        est = hv ? pk * 0.012f : 1000.0f + pk * 0.4f;  // us; the light items, all of them, go first (see below)
     }
     uint32_t rank = 0;  // classes that go before mine
     for (uint32_t l = 0; l < (uint32_t)kClasses; l++) {
@@ -2428,7 +2452,9 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
     if (D.pass_stats && wave == 0 && lane == 0) D.pass_stats[15] = n_items;
     uint32_t *cursors = D.cursors + (uint32_t)(listed ? read_buf : 2) * kShards * kCursorStride;
     const uint32_t s_mine = wave % kShards, c0 = n_waves / kShards;
-    uint32_t t = wave;  // the first item: no claim
+    // the first item, no claim: workgroup g (they go round-robin over the CUs) starts with items g, g + G, g + 2G, g + 3G
+    // of the order above, so a CU's light items are one of every quarter of the ranking, not four neighbours
+    uint32_t t = listed ? (threadIdx.x / kWave) * gridDim.x + blockIdx.x : wave;
     for (;;) {
         if (t >= n_items) {
             t = 0xFFFFFFFFu;

@@ -426,7 +426,20 @@ long pcc_model_episodes(int n_envs, int n_steps, uint64_t seed, uint32_t gid_bas
                 if (hist_out) hist_out[lg]++;
                 if (sa.sent >= min_packets) {
                     heavy_pk += sa.sent; heavy_mis++;
+                    const mstats_t before = st;
                     model_mi(&sb, gap, end, dl, maxq, ebw, loss, ba, bd, &st);
+                    if (getenv("PCC_MODEL_VERBOSE") && sa.sent >= 800) {  /* which MIs need many passes, and why */
+                        const uint64_t passes = (st.pass_a - before.pass_a) + (st.pass_b - before.pass_b) + (st.pass_s - before.pass_s);
+                        if (sa.sent / (passes ? passes : 1) < (uint64_t)atoi(getenv("PCC_MODEL_VERBOSE")))
+                            fprintf(stderr, "env %d step %d sent %u passes A %llu B %llu S %llu (pk S %llu) Q %.0f rate/bw %.3f q/maxq %.6f "
+                                    "maxq %.17g ebw %.17g q %.17g t %.6f why %llu %llu %llu %llu %llu %llu\n", b, tstep, sa.sent,
+                                    (unsigned long long)(st.pass_a - before.pass_a), (unsigned long long)(st.pass_b - before.pass_b),
+                                    (unsigned long long)(st.pass_s - before.pass_s), (unsigned long long)(st.pk_s - before.pk_s),
+                                    maxq / ebw, ebw / gap, s0.q / maxq, maxq, ebw, s0.q, s0.t,
+                                    (unsigned long long)(st.why[0] - before.why[0]), (unsigned long long)(st.why[1] - before.why[1]),
+                                    (unsigned long long)(st.why[2] - before.why[2]), (unsigned long long)(st.why[3] - before.why[3]),
+                                    (unsigned long long)(st.why[4] - before.why[4]), (unsigned long long)(st.why[5] - before.why[5]));
+                    }
                     const int rc = compare_mi(&sa, &sb, aa, ad, ba, bd);
                     if (rc) {
                         if (bad < 5) fprintf(stderr, "episode env %d step %d mismatch rc=%d sent %u/%u\n", b, tstep, rc, sa.sent, sb.sent);

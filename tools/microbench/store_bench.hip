@@ -62,6 +62,16 @@ __global__ void k(char *base, const uint32_t *start, int iters, int rings_per_wa
                 v.x += 1.0;
             }
         }
+    } else if (MODE == 10) {
+        for (int i = 0; i < iters; i += 4) {
+            for (int c = 0; c < 4; c++) {
+                const size_t ring = perm[wave * 64 + 16 * c + (lane >> 2)];
+                char *p = base + ring * kRing;
+                const uint32_t pos = ((start[ring] & 1020u) + i + (lane & 3u)) & 1023u;
+                *(__attribute__((address_space(1))) gvec2 *)(void *)(p + (size_t)pos * 16) = v;
+                v.x += 1.0;
+            }
+        }
     } else {
         // 4 iterations of 64 rings -> 4 instructions of 16 rings x 64 B
         for (int i = 0; i < iters; i += 4) {
@@ -92,7 +102,8 @@ int main() {
     for (int i = 0; i < n_rings; i++) hp[i] = i;
     for (int i = n_rings - 1; i > 0; i--) { int j = rand() % (i + 1); std::swap(hp[i], hp[j]); }
     uint32_t *perm; CK(hipMalloc(&perm, n_rings * 4)); CK(hipMemcpy(perm, hp.data(), n_rings * 4, hipMemcpyHostToDevice));
-    for (int mode = 3; mode < 10; mode++) {
+    for (int mode = 2; mode < 11; mode++) {
+        if (mode > 3 && mode < 10) continue;
         if (mode == 5) continue;
         for (int waves : {1024, 4096}) {
             // `waves` wavefronts, each owning 64 rings; records per launch = waves * 64 * iters
@@ -109,11 +120,12 @@ int main() {
                 if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(waves), dim3(64), 0, 0, base, start, iters, rpw, perm);
                 if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(waves), dim3(64), 0, 0, base, start, iters, rpw, perm);
                 if (mode == 9) hipLaunchKernelGGL(k<9>, dim3(waves), dim3(64), 0, 0, base, start, iters, rpw, perm);
+                if (mode == 10) hipLaunchKernelGGL(k<10>, dim3(waves), dim3(64), 0, 0, base, start, iters, rpw, perm);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             }
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             const double recs = (double)waves * 64 * iters;
-            printf("%-8s waves %5d  %8.3f ms  %7.2f G records/s  %7.1f GB/s\n", mode == 0 ? "scatter" : mode == 1 ? "dense" : mode == 2 ? "chunk64" : mode == 3 ? "scat-rnd" : mode == 4 ? "alu+1st" : mode == 5 ? "alu+4st" : mode == 6 ? "grp1024" : mode == 7 ? "grp2048" : mode == 8 ? "grp4096" : "grp8192",
+            printf("%-8s waves %5d  %8.3f ms  %7.2f G records/s  %7.1f GB/s\n", mode == 0 ? "scatter" : mode == 1 ? "dense" : mode == 2 ? "chunk64" : mode == 3 ? "scat-rnd" : mode == 4 ? "alu+1st" : mode == 5 ? "alu+4st" : mode == 6 ? "grp1024" : mode == 7 ? "grp2048" : mode == 8 ? "grp4096" : mode == 9 ? "grp8192" : "chunk-rnd",
                    waves, ms, recs / ms * 1e-6, recs * 16 / ms * 1e-6);
         }
     }
