@@ -432,6 +432,49 @@ def test_envs_out_of_lockstep_match_oracle():
     env.close()
 
 
+def test_two_senders_out_of_lockstep_match_oracle():
+    """The same schedule with two senders on the link (restart items run the two-sender wave path and both senders'
+    warm-up retires): masked resets, then auto-resets at each env's own episode end, every env against its oracle."""
+    n, seed, max_steps, T = 40, 21, 12, 40
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=seed, n_senders=2, record_steps=True, auto_reset=True,
+                                       max_steps=max_steps)
+    oenvs = []
+    for i in range(n):
+        o = oracle.OracleEnv(2)
+        o.rng_philox(seed, i)
+        oenvs.append(o)
+    obs = env.reset().cpu().numpy()
+    oobs = np.stack([o.reset() for o in oenvs])
+    assert np.array_equal(obs, oobs.astype(np.float32))
+    osteps = np.zeros(n, dtype=int)
+    rs = np.random.RandomState(6)
+    idx = np.arange(n)
+    for t in range(T):
+        if t % 5 == 2 and t < 20:
+            mask = (idx % 4) == ((t // 5) % 4)
+            got = env.reset(torch.as_tensor(mask)).cpu().numpy()
+            for i in idx[mask]:
+                want = oenvs[i].reset()
+                osteps[i] = 0
+                assert np.array_equal(got[i], want.astype(np.float32)), (t, i)
+        a = rs.uniform(-1, 1.5, (n, 2))
+        o_gpu, r_gpu, d_gpu, info = env.step(torch.as_tensor(a, device=DEV))
+        rows = info["steps"].cpu().numpy()
+        o_gpu, d_gpu = o_gpu.cpu().numpy(), d_gpu.cpu().numpy()
+        for i in range(n):
+            o_ref, r_ref, _, _ = oenvs[i].step(a[i])
+            osteps[i] += 1
+            done = osteps[i] >= max_steps
+            assert np.array_equal(rows[i], oenvs[i].last_row), (t, i)
+            assert bool(d_gpu[i]) == done, (t, i)
+            if done:
+                o_ref = oenvs[i].reset()
+                osteps[i] = 0
+            assert np.array_equal(o_gpu[i], o_ref.astype(np.float32)), (t, i)
+    env.check_flags()
+    env.close()
+
+
 def test_two_senders_at_full_size():
     """BASELINE.json configs[4] at its full size (32 768 envs x 2 senders): conservation per sender, the
     queue bound, and the first 256 envs of the batch against the oracle, bit for bit."""
