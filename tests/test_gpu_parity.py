@@ -663,6 +663,54 @@ def test_use_latency_noise_philox_batch_matches_oracle():
     env.close()
 
 
+@pytest.mark.parametrize("option", ["noise", "cwnd"])
+def test_engine_options_out_of_lockstep_match_oracle(option):
+    """With the dormant engine options the auto-reset of envs that are out of lockstep stays the gated reset
+    launches after the step (no wave path / no send half for restart items): masked resets, then every env's
+    own episode ends, against per-env oracles."""
+    n, seed, max_steps, T = 24, 31, 10, 27
+    kw = dict(latency_noise=1.1) if option == "noise" else dict(use_cwnd=True)
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=seed, record_steps=True, auto_reset=True, max_steps=max_steps, **kw)
+    oenvs = []
+    for i in range(n):
+        o = oracle.OracleEnv()
+        o.rng_philox(seed, i)
+        if option == "noise":
+            o.use_latency_noise(True, 1.1)
+        else:
+            o.use_cwnd(True)
+        oenvs.append(o)
+    obs = env.reset().cpu().numpy()
+    assert np.array_equal(obs, np.stack([o.reset() for o in oenvs]).astype(np.float32))
+    osteps = np.zeros(n, dtype=int)
+    rs = np.random.RandomState(8)
+    idx = np.arange(n)
+    for t in range(T):
+        if t in (3, 6):
+            mask = (idx % 3) == (t // 3 - 1)
+            got = env.reset(torch.as_tensor(mask)).cpu().numpy()
+            for i in idx[mask]:
+                want = oenvs[i].reset()
+                osteps[i] = 0
+                assert np.array_equal(got[i], want.astype(np.float32)), (t, i)
+        a = rs.uniform(-1, 1.5, (n, 2) if option == "cwnd" else n)
+        o_gpu, r_gpu, d_gpu, info = env.step(torch.as_tensor(a, device=DEV))
+        rows = info["steps"].cpu().numpy()
+        o_gpu, d_gpu = o_gpu.cpu().numpy(), d_gpu.cpu().numpy()
+        for i in range(n):
+            o_ref, r_ref, _, _ = oenvs[i].step(a[i])
+            osteps[i] += 1
+            done = osteps[i] >= max_steps
+            assert np.array_equal(rows[i], oenvs[i].last_row[0]), (t, i)
+            assert bool(d_gpu[i]) == done, (t, i)
+            if done:
+                o_ref = oenvs[i].reset()
+                osteps[i] = 0
+            assert np.array_equal(o_gpu[i], o_ref.astype(np.float32)), (t, i)
+    env.check_flags()
+    env.close()
+
+
 def test_latency_noise_refuses_what_it_does_not_cover():
     env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, n_senders=2, auto_reset=False)
     with pytest.raises(pcc_rl_amd.PccError):
