@@ -2417,8 +2417,8 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
     // longest first, then the envs of the wave path, longest first (~12 ns per packet; a light item lasts as long
     // as its lanes, ~0.4 us per packet of the class).  The lane rounds are bound by their scattered 16-byte stores
     // (without them the launch takes 0.085 instead of 0.151 ms) and slow every other wavefront of their CU down
-    // while they run (a wave-path item next to four of them waits 100+ us for its first loads): started together at
-    // t = 0 and dealt round-robin over the CUs (first_item below) they are out of the way soonest.
+    // while they run: started together at t = 0, one workgroup of them per CU (see the first item below), they are
+    // out of the way soonest.
     const bool listed = read_buf >= 0;
     const int cls_mine = kClasses - 1 - (int)lane;
     const int cls_heavy = D.use_cwnd ? kClasses : (D.heavy_predict >= 1e9 ? kClasses : class_of((float)D.heavy_predict));
@@ -2452,9 +2452,19 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
     if (D.pass_stats && wave == 0 && lane == 0) D.pass_stats[15] = n_items;
     uint32_t *cursors = D.cursors + (uint32_t)(listed ? read_buf : 2) * kShards * kCursorStride;
     const uint32_t s_mine = wave % kShards, c0 = n_waves / kShards;
-    // the first item, no claim: workgroup g (they go round-robin over the CUs) starts with items g, g + G, g + 2G, g + 3G
-    // of the order above, so a CU's light items are one of every quarter of the ranking, not four neighbours
-    uint32_t t = listed ? (threadIdx.x / kWave) * gridDim.x + blockIdx.x : wave;
+    // the first item, no claim.  The ranking is dealt over the workgroups from the YOUNGEST quarter (the last
+    // to be dispatched) to the oldest: the light items land on the youngest workgroup of every CU, the largest
+    // wave-path envs on the next, and so on.  A CU's memory pipeline serves its oldest wavefronts first, and four
+    // lane-round wavefronts keep it busy all the time: as the oldest they starve everybody else on the CU (a
+    // wave-path item next to them waited 100-160 us for its first loads), as the youngest they fill the gaps
+    // (send 0.163 -> 0.148 ms; largest wave-path envs on the OLDEST workgroups instead: 0.156).  Speed only: which
+    // wavefront sends an env never changes a result.
+    // (The RESTART build deals oldest first: its ranking starts with the restart items, the launch's critical path.)
+    uint32_t t = wave;
+    if (listed && !RESTART) {
+        const uint32_t G = gridDim.x, Qz = G / 4u, inv = G - 1u - blockIdx.x;  // G is a multiple of kShards = 16
+        t = (inv / Qz) * G + (threadIdx.x / kWave) * Qz + inv % Qz;
+    }
     for (;;) {
         if (t >= n_items) {
             t = 0xFFFFFFFFu;
