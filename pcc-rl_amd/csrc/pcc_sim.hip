@@ -62,8 +62,9 @@ constexpr int kMaxFeatures = 16;
 constexpr int kMaxSenders = 2;
 constexpr int kWave = 64;
 constexpr int kGroup = 16;            // lanes per env in retire_kernel
-constexpr int kRetireBlock = 256;     // 16 envs per workgroup (one wavefront per workgroup was tried: the launch then
-                                      // waits for the dispatcher, 16 384 workgroups at ~80 per us -- 0.212 vs 0.117 ms)
+constexpr int kRetireBlock = 128;     // 8 envs per workgroup: 0.118 ms; 16 envs: 0.122 (a workgroup's slots are refilled
+                                      // together); one wavefront per workgroup: 0.212 (the launch then waits for the
+                                      // dispatcher, 16 384 workgroups at ~80 per us)
 #ifndef PCC_RETIRE_OCC
 #define PCC_RETIRE_OCC 4  // retire workgroups per SIMD the register budget is cut for: 5 spills (48 B/lane) and is slower
 #endif
