@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Shape of one retire launch (PCC_DEBUG_TIMELINE=1; GPU box only): span of the launch, time of its
-workgroups (16 envs each), how many run at a time, and which workgroups are still running at the end."""
+workgroups, how many run at a time, and which workgroups are still running at the end."""
 import json, os, sys
 os.environ.setdefault("PCC_DEBUG_TIMELINE", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
