@@ -2464,13 +2464,14 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
     uint32_t t = wave;
     if (listed && !RESTART) {
         const uint32_t G = gridDim.x, Qz = G / 4u, inv = G - 1u - blockIdx.x;  // G is a multiple of kShards = 16
-        t = (inv / Qz) * G + (threadIdx.x / kWave) * Qz + inv % Qz;
+        const uint32_t blk_items = (blockDim.x / kWave) * Qz;                   // = n_waves / 4: a quarter's wavefronts
+        t = (inv / Qz) * blk_items + (threadIdx.x / kWave) * Qz + inv % Qz;
         // ... except the 32 longest light items, the launch's critical path for most of an episode: they trade places
         // with items of the oldest quarter, one per CU (0.148 -> 0.143 ms; 16: 0.146, 64: 0.144, 256: 0.151)
         constexpr uint32_t kFront = 32;
-        if (Qz >= kFront) {  // (a bijection of the first 4 G items only then)
-            if (t >= 3u * G && t < 3u * G + kFront) t -= 3u * G;
-            else if (t < kFront) t += 3u * G;
+        if (Qz >= kFront) {  // (a bijection of the first n_waves items only then)
+            if (t >= 3u * blk_items && t < 3u * blk_items + kFront) t -= 3u * blk_items;
+            else if (t < kFront) t += 3u * blk_items;
         }
     }
     for (;;) {

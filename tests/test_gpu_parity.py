@@ -475,6 +475,21 @@ def test_two_senders_out_of_lockstep_match_oracle():
     env.close()
 
 
+@pytest.mark.parametrize("wg_waves", ["1", "2"])
+def test_send_workgroup_size_does_not_matter(wg_waves, monkeypatch):
+    """PCC_SEND_WG_WAVES (wavefronts per send workgroup, read at creation): the dealing of the first items must stay
+    a bijection for every workgroup size -- a duplicate item would send an env twice."""
+    monkeypatch.setenv("PCC_SEND_WG_WAVES", wg_waves)
+    n_envs, n_steps, seed = 3000, 40, 17
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=False)
+    env.reset()
+    acts = np.random.RandomState(seed).uniform(-1, 1.5, (n_envs, n_steps))
+    steps, obs, done = run_gpu(env, acts, n_steps)
+    ref = oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=seed)
+    assert np.array_equal(steps, ref["steps"])
+    env.close()
+
+
 def test_two_senders_at_full_size():
     """BASELINE.json configs[4] at its full size (32 768 envs x 2 senders): conservation per sender, the
     queue bound, and the first 256 envs of the batch against the oracle, bit for bit."""
