@@ -32,7 +32,7 @@
 //
 // Kernels per step:
 //   send_kernel    persistent wavefronts take work items off the class lists the previous retire filed,
-//                  heaviest first (send_item): a light item is 64 envs of about the same predicted
+//                  light items first (send_item): a light item is 64 envs of about the same predicted
 //                  packet count sent lane-per-env in rounds (no loads in the loop); a heavy item is one
 //                  env sent by all 64 lanes, 256 packets per pass, from closed forms (heavy_mi).
 //   retire_kernel  retire_env, 16 lanes per env: searches of the rings for the hop-2 / hop-1
@@ -1341,7 +1341,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
 // items come off those lists, heaviest class first: every env of a class at or above the heavy
 // threshold is an item of its own (wave path), the envs of a lighter class go 64 at a time to
 // lane-per-env rounds -- lanes of about the same length, so a wavefront's lanes finish together.
-// Persistent wavefronts take the items off one atomic cursor: longest first, nobody waits for a
+// Persistent wavefronts take the items off sharded cursors (send_kernel): nobody waits for a
 // neighbour.  The lists are a permutation of the envs whatever the predictions say (a reset in
 // between leaves stale predictions: harmless).
 constexpr int kClasses = 32;
@@ -2886,7 +2886,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.delta_scale = 0.025;  // src/common/config.py:17
     d.max_steps = 400;      // ns:41
     d.round_packets = 256;
-    d.takeover_lanes = 1;  // measured with three heavy wavefronts per block: 1 -> 0.487, 2 -> 0.516, 3 -> 0.595 ms/step
+    d.takeover_lanes = 1;  // the last lane of a light item goes to the wave path (more lanes handed over measured slower)
     d.send_waves = 16;  // persistent send wavefronts per compute unit (4 per SIMD at <= 128 VGPRs)
     d.send_envs_per_wave = 64;
     d.heavy_predict = 512.0;
