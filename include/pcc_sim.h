@@ -97,7 +97,13 @@ enum {
                                       then also overflow: RING_OVERFLOW); raise the pools with PCC_RING_POOLS */
 #define PCC_FLAG_INTERNAL 4u       /* reserved (a queue protocol of an earlier build; never set) */
 #define PCC_FLAG_BAD_PARAMS 16u    /* pcc_set_link_params gave this env a link outside what the exact formulation covers
-                                      (bw in (0, 1e8], latency > 0, queue >= 1, loss in [0, 1]): results invalid */
+                                      (bw in (0, 1e8], latency > 0, queue >= 1, loss in [0, 1], rate0 > 0 and finite):
+                                      results invalid; the env runs on a harmless stand-in link so that no kernel spins */
+#define PCC_FLAG_BAD_ACTION 32u    /* an action was NaN (the reference would carry the NaN into its rate and clock): it was
+                                      applied as 0.0 */
+#define PCC_FLAG_TIME_RANGE 64u    /* the env's clock left the range in which event times 1e-12 apart (relative) are still far
+                                      closer than one packet time 1/bw -- the assumption behind the ordering of dropped
+                                      packets: shorten the episode (pcc_set_max_steps) or slow the link */
 
 /* last error text of the calling thread ("" if none) */
 const char *pcc_last_error(void);
@@ -167,7 +173,11 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_SEND_ENVS_PER_WAVE = 4 /* envs per light work item, 1..64 */,
        PCC_TUNE_HEAVY_PREDICT = 5 /* predicted packets per interval above which an env is a work item of
                                     its own (wave path); default 512, 0 = every env, >= 1e9 = none */,
-       PCC_TUNE_SEND_WAVES = 8 /* persistent send wavefronts per compute unit, 1..32 (default 16) */ };
+       PCC_TUNE_SEND_WAVES = 8 /* persistent send wavefronts per compute unit, 1..32 (default 16) */,
+       PCC_TUNE_TEAM_PREDICT = 9 /* predicted packets per interval above which an env is sent by a whole workgroup (four
+                                    wavefronts, 1 024 packets per pass); default 4096, >= 1e9 = never (one sender only) */,
+       PCC_TUNE_HEAVY_ITEM_PACKETS = 10 /* a wave-path work item holds as many envs of one class (1..8) as make up about this
+                                    many predicted packets; default 2048, 0 = one env per item */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* The reference's dormant engine option USE_CWND (ns:54; off in the reference): window-limited

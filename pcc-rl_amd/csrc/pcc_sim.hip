@@ -126,6 +126,12 @@ struct alignas(128) SndBlk {
     uint32_t ha, hd, ta, td;     // 64  accepted/dropped ring heads and tails
     uint32_t mi_sent;            // 80
     uint32_t ring_held[kMaxTiers];  // pool slot + 1 the sender holds in tier c (0 = none) until reset
+    uint32_t pad1[3];
+    // 112  retire half: where the last interval's four ring boundaries fell, as predictions of the next ones (speed only:
+    // search_many verifies them) -- acknowledgements and loss reports per second of simulated time, and the packets that were
+    // on the return hop at the interval's end (accepted / dropped ring)
+    float ack_rate, loss_rate;
+    uint32_t on_return_a, on_return_d;
 };
 static_assert(sizeof(EnvBlk) == 128 && sizeof(SndBlk) == 128, "one line per block");
 
@@ -154,9 +160,12 @@ struct Dev {
     int pass_counters;               // ... per-pass counters on (PCC_DEBUG_TIMELINE=2: contended atomics, they slow the passes down)
     uint32_t send_wg_waves;  // tuning: wavefronts per send workgroup (each works on its own)
     uint32_t retire_sorted;  // debug: 0 = the retire launch walks the envs in index order even when there are lists
-    int debug_skip;  // profiling only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs
+    int debug_skip;  // profile build only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs, bit2 skip the
+                     // lane rounds' record stores, bit3 skip their Philox -- results wrong, timing only
     uint32_t round_packets, takeover_lanes, send_envs_per_wave, send_waves;
     double heavy_predict;  // predicted packets per MI above which an env goes to the heavy wave
+    double team_predict;   // ... above which a whole workgroup sends it (team pass)
+    float heavy_item_packets;  // a heavy work item is as many envs of its class as make up about this many packets (1..8 envs)
     double lo[5], hi[5];
     int rng_mode;
     const double *trace;
@@ -176,6 +185,17 @@ struct Dev {
     float *hist;    // [N][S][HF]
     double2 *ring;  // [N][S][2][cap]: accepted ring, dropped ring
 };
+
+// Profiling hooks (per-item timeline, pass counters, the "skip" switches that drop work to see what a phase costs --
+// the latter make results WRONG) exist only in the -DPCC_PROFILE=1 build (libpcc_sim_prof.so, used by tools/): the
+// product library carries none of it, and no environment variable can change what it computes.
+#ifndef PCC_PROFILE
+#define PCC_PROFILE 0
+#endif
+constexpr bool kProfile = PCC_PROFILE != 0;
+__device__ __forceinline__ bool prof_on(const Dev &D) { return kProfile && D.timeline != nullptr; }
+__device__ __forceinline__ bool prof_counters(const Dev &D) { return kProfile && D.pass_counters != 0; }
+__device__ __forceinline__ bool prof_skip(const Dev &D, int bit) { return kProfile && (D.debug_skip & bit) != 0; }
 
 // --------------------------------------------------------------------------------------
 // small helpers
@@ -397,17 +417,34 @@ __device__ __forceinline__ void lind_step(int &s, int &c) {
     c = nc;
 }
 
-// exclusive prefix over the 64 lanes: on return (s, c) is the composite of all lower lanes' maps
-__device__ __forceinline__ void lind_exclusive_scan(int &s, int &c) {
+// exclusive prefix over the 64 lanes: on return (s, c) is the composite of all lower lanes' maps, (tot_s, tot_c) the
+// composite of all 64 (what the next wavefront of a team starts from)
+__device__ __forceinline__ void lind_exclusive_scan(int &s, int &c, int &tot_s, int &tot_c) {
     lind_step<0x111, 0xF>(s, c);  // row_shr:1
     lind_step<0x112, 0xF>(s, c);  // row_shr:2
     lind_step<0x114, 0xF>(s, c);  // row_shr:4
     lind_step<0x118, 0xF>(s, c);  // row_shr:8  -> inclusive inside each row of 16
     lind_step<0x142, 0xA>(s, c);  // row_bcast:15 into rows 1 and 3
     lind_step<0x143, 0xC>(s, c);  // row_bcast:31 into rows 2 and 3 -> inclusive over the wave
+    tot_s = __builtin_amdgcn_readlane(s, kWave - 1);
+    tot_c = __builtin_amdgcn_readlane(c, kWave - 1);
     s = __builtin_amdgcn_update_dpp(0, s, 0x138, 0xF, 0xF, false);          // wave_shr:1
     c = __builtin_amdgcn_update_dpp(kLindNone, c, 0x138, 0xF, 0xF, false);
 }
+
+// What the W wavefronts of a TEAM pass tell each other through LDS (heavy_mi<.., W> with W > 1: one env sent by a whole
+// workgroup, 256 W positions per pass).  Three exchanges per pass, each followed by one workgroup barrier.
+constexpr int kTeamMax = 4;
+struct TeamX {
+    int cnt[kTeamMax];           // 1: packets the wavefront accepts (regimes without the token scan)
+    int ls[kTeamMax], lc[kTeamMax];  // 1: the wavefront's composite Lindley map (token scan)
+    int b0;                      // 1: tokens in front of the pass's first packet
+    uint32_t pstop[kTeamMax];    // 2: first position of the wavefront that ends the pass (256 = none)
+    uint32_t jstop[kTeamMax];    // 2: packets accepted before it (by the whole team)
+    uint32_t sflag[kTeamMax];    // 2: ... and whether a broken precondition ended it
+    uint32_t has_last[kTeamMax]; // 3: the wavefront committed a packet that reached the queue,
+    double last_q[kTeamMax], last_t[kTeamMax];  // 3: and the link state behind its last one
+};
 
 __device__ __forceinline__ double pow2_f64(int e_unbiased) {  // 2^e for a normal result
     return __hiloint2double((e_unbiased + 1023) << 20, 0);
@@ -438,18 +475,28 @@ __device__ __forceinline__ double pow2_f64(int e_unbiased) {  // 2^e for a norma
 //   * Otherwise (episode start, binade changes, ties of the rounding of 1/bw): a few packets with the
 //     plain recurrence, wave-uniform.
 // Records leave in send order as dense runs per ring -> coalesced stores.
-template <bool TRACE>
-__device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl, double lr, uint32_t thr, bool always,
-                                         double maxq, double ebw, double gap, double end, uint32_t episode,
-                                         uint32_t mi, uint32_t gid, const double *trace, char *base, uint32_t cap,
-                                         SendState &st) {
+// W > 1: a TEAM pass -- the W wavefronts of a workgroup send one env together, wavefront wv owning positions
+// 256 wv .. 256 wv + 255 of a pass of 256 W.  Every wavefront carries the same SendState and takes the same decisions
+// (what one wavefront needs of the others -- accepted packets / Lindley composite of the wavefronts before it, the first
+// position that ends the pass, the link state behind the last packet -- goes through X in LDS, one barrier each); the
+// serial and accept-chain fallbacks are computed by all of them alike and stored by wavefront 0.  The same pass with 256
+// lanes is what tests/models/send_pass_model.c checks (pcc_model_set_lanes).
+template <bool TRACE, int W>
+__device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint32_t wv, TeamX *X, double dl, double lr,
+                                         uint32_t thr, bool always, double maxq, double ebw, double gap, double end,
+                                         uint32_t episode, uint32_t mi, uint32_t gid, const double *trace, char *base,
+                                         uint32_t cap, SendState &st) {
+    static_assert(W >= 1 && W <= kTeamMax, "team size");
     const uint32_t mask_b = (cap - 1u) << 4, dmask_b = (2u * cap - 1u) << 4, cap_b = cap << 4;
     const uint64_t lt = (1ull << lane) - 1ull;
-    constexpr uint32_t kPass = 4u * kWave;
+    constexpr uint32_t kPass = 4u * kWave * W;
+    const uint32_t glane = (W > 1 ? wv * kWave : 0u) + lane;  // lane of the team
+    const bool first_lane = glane == 0u;
+    const bool writer = W == 1 || wv == 0u;  // who stores what every wavefront of the team computes alike
     uint32_t serial_len = 8;
     uint32_t chain_left = 0;  // passes to send by the accept chain before the closed forms are tried again
     while (st.t < end) {
-        const uint64_t dbg_c0 = D.pass_counters ? __builtin_readcyclecounter() : 0;
+        const uint64_t dbg_c0 = prof_counters(D) ? __builtin_readcyclecounter() : 0;
         const double t0 = st.t;
         const double t1s = t0 + gap;
         const double G = t1s - t0;
@@ -492,10 +539,10 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                         D0i = (int64_t)(D0 * inv_u);
                         Gi = (int64_t)(G * inv_u);
                         Ri = (int64_t)(R * inv_u);
-                        // room in the queue in packets (estimate): with >= 300 no packet of this pass can be
+                        // room in the queue in packets (estimate): with >= kPass + 44 no packet of this pass can be
                         // tail-dropped and the token arithmetic is not needed (maxq / u may not fit an int64)
                         const double room = ((maxq - R) - x0) / R;
-                        free_mode = room >= 300.0;
+                        free_mode = room >= (double)kPass + 44.0;
                         const int64_t Mi = free_mode ? 0 : (int64_t)(maxq * inv_u);
                         Ci = (Mi - Ri) - Q0i + D0i;  // tokens before packet k: floor((Ci + Ri + k Gi) / Ri) >= 0
                         // a tie rounds to even: x + R holds only while every x is an even multiple of u
@@ -512,7 +559,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
 
         if (regime != 0) {
             // ---- loss decisions of the lane's four positions (bit i: lost at random, ns:73)
-            const int kbase = 4 * (int)lane - (int)skip;  // packet index (within the pass) of position 0 of this lane
+            const int kbase = 4 * (int)glane - (int)skip;  // packet index (within the pass) of position 0 of this lane
             uint32_t rnd4 = 0;
             if (TRACE) {
 #pragma unroll
@@ -525,7 +572,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                 }
             } else {
                 uint32_t w[4];
-                philox4x32_10((st.sent >> 2) + lane, mi, episode, gid, D.key0, D.key1, w);
+                philox4x32_10((st.sent >> 2) + glane, mi, episode, gid, D.key0, D.key1, w);
 #pragma unroll
                 for (int i = 0; i < 4; i++) rnd4 |= ((always || w[i] < thr) ? 1u : 0u) << i;
             }
@@ -546,8 +593,18 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
             int j_base = 0;
             if (regime == 1) {
                 acc4 = m4;
+                int in_wave = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) j_base += (int)__popcll(__ballot((acc4 >> i) & 1u) & lt);
+                for (int i = 0; i < 4; i++) {
+                    const uint64_t bm = __ballot((acc4 >> i) & 1u);
+                    j_base += (int)__popcll(bm & lt);
+                    in_wave += (int)__popcll(bm);
+                }
+                if constexpr (W > 1) {  // exchange 1: packets accepted by the wavefronts before this one
+                    if (lane == 0) X->cnt[wv] = in_wave;
+                    __syncthreads();
+                    for (uint32_t w2 = 0; w2 < wv; w2++) j_base += X->cnt[w2];
+                }
             } else {
                 const bool over = !free_mode && Gi < Ri;  // overdriven and close to full: the token scan decides
                 const int k0 = kbase < 0 ? 0 : kbase;
@@ -573,8 +630,22 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                         cmax = cmax + sft > a ? cmax + sft : a;  // this packet's map after the earlier ones
                         ssum += sft;
                     }
-                    const int b0 = __builtin_amdgcn_readfirstlane(N);  // lane 0's first packet is packet 0
-                    lind_exclusive_scan(ssum, cmax);
+                    int b0 = __builtin_amdgcn_readfirstlane(N);  // lane 0's first packet is packet 0
+                    int tot_s, tot_c;
+                    lind_exclusive_scan(ssum, cmax, tot_s, tot_c);
+                    if constexpr (W > 1) {  // exchange 1: the composite of the wavefronts before this one goes first
+                        if (lane == 0) { X->ls[wv] = tot_s; X->lc[wv] = tot_c; if (wv == 0u) X->b0 = b0; }
+                        __syncthreads();
+                        int ps = 0, pc = kLindNone;
+                        for (uint32_t w2 = 0; w2 < wv; w2++) {
+                            const int s2 = X->ls[w2], c2 = X->lc[w2];
+                            pc = pc + s2 > c2 ? pc + s2 : c2;
+                            ps += s2;
+                        }
+                        cmax = pc + ssum > cmax ? pc + ssum : cmax;
+                        ssum += ps;
+                        b0 = X->b0;
+                    }
                     b = b0 + ssum > cmax ? b0 + ssum : cmax;
                     j_base = N - b;
                 } else {
@@ -582,9 +653,19 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                     // sender slower than the link (or >= 300 packets of room), a token is always there:
                     // accepted = not lost, accepted before the lane = a prefix popcount
                     acc4 = m4;
-                    if (lane == 0 && !(free_mode || Ci >= 0)) acc4 &= ~(1u << skip);
+                    if (first_lane && !(free_mode || Ci >= 0)) acc4 &= ~(1u << skip);
+                    int in_wave = 0;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) j_base += (int)__popcll(__ballot((acc4 >> i) & 1u) & lt);
+                    for (int i = 0; i < 4; i++) {
+                        const uint64_t bm = __ballot((acc4 >> i) & 1u);
+                        j_base += (int)__popcll(bm & lt);
+                        in_wave += (int)__popcll(bm);
+                    }
+                    if constexpr (W > 1) {  // exchange 1
+                        if (lane == 0) X->cnt[wv] = in_wave;
+                        __syncthreads();
+                        for (uint32_t w2 = 0; w2 < wv; w2++) j_base += X->cnt[w2];
+                    }
                 }
                 // exact base: x = (Q0 + j R - D0 - k0 G) u in integers, one exact conversion
                 const int64_t xi = Q0i + (int64_t)j_base * Ri - D0i - (int64_t)k0 * Gi;
@@ -612,9 +693,9 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
             }
             // ---- the pass stops at the first position that is past the MI end or breaks a precondition
             uint32_t stop4 = (~ex4 | flag4) & 0xFu;
-            if (lane == 0) stop4 &= ~((1u << skip) - 1u);  // positions before `skip` are not part of the pass
+            if (first_lane) stop4 &= ~((1u << skip) - 1u);  // positions before `skip` are not part of the pass
             const uint64_t stop_lanes = __ballot(stop4 != 0u);
-            uint32_t p_stop = kPass, j_stop;
+            uint32_t p_stop = 4u * kWave, j_stop;  // (in this wavefront's 256 positions)
             bool stopped_by_flag = false;
             if (stop_lanes) {
                 const uint32_t ls = (uint32_t)__ffsll((unsigned long long)stop_lanes) - 1u;
@@ -624,6 +705,15 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                 stopped_by_flag = rl_u32((flag4 >> is) & 1u, ls) != 0u;
             } else {
                 j_stop = rl_u32((uint32_t)j_base + (uint32_t)__popc(acc4), kWave - 1u);
+            }
+            if constexpr (W > 1) {  // exchange 2: the first wavefront with a stop ends the team's pass
+                if (lane == 0) { X->pstop[wv] = p_stop; X->jstop[wv] = j_stop; X->sflag[wv] = stopped_by_flag ? 1u : 0u; }
+                __syncthreads();
+                uint32_t w2 = 0;
+                while (w2 + 1u < (uint32_t)W && X->pstop[w2] == 4u * kWave) w2++;
+                p_stop = w2 * 4u * kWave + X->pstop[w2];
+                j_stop = X->jstop[w2];
+                stopped_by_flag = X->sflag[w2] != 0u;
             }
             const uint32_t ncommit = p_stop - skip;
             // q hovering around a power of two (or a queue that keeps running empty) breaks a pass after a
@@ -640,7 +730,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                 uint32_t j = (uint32_t)j_base;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint32_t p = 4u * lane + (uint32_t)i;
+                    const uint32_t p = 4u * glane + (uint32_t)i;
                     const bool a = (acc4 >> i) & 1u;
                     if (p >= skip && p < p_stop) {
                         const uint32_t kk = p - skip;             // packets of the pass before this one
@@ -663,12 +753,21 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                     }
                 }
                 const uint64_t lm = __ballot(have_last);
-                if (lm) {
-                    const uint32_t ll = 63u - (uint32_t)__clzll((long long)lm);
-                    st.q = rl_f64(last_q, ll);
-                    st.tu = rl_f64(last_t, ll);
+                if constexpr (W == 1) {
+                    if (lm) {
+                        const uint32_t ll = 63u - (uint32_t)__clzll((long long)lm);
+                        st.q = rl_f64(last_q, ll);
+                        st.tu = rl_f64(last_t, ll);
+                    }
+                } else {  // exchange 3: the last wavefront that committed a packet which reached the queue
+                    const uint32_t ll = lm ? 63u - (uint32_t)__clzll((long long)lm) : 0u;
+                    const double wq = rl_f64(last_q, ll), wt = rl_f64(last_t, ll);
+                    if (lane == 0) { X->has_last[wv] = lm ? 1u : 0u; X->last_q[wv] = wq; X->last_t[wv] = wt; }
+                    __syncthreads();
+                    for (int w2 = W - 1; w2 >= 0; w2--)
+                        if (X->has_last[w2]) { st.q = X->last_q[w2]; st.tu = X->last_t[w2]; break; }
                 }
-                if (D.pass_counters && lane == 0) {
+                if (prof_counters(D) && lane == 0 && writer) {
                     const int c = regime == 1 ? 0 : (!free_mode && Gi < Ri) ? 1 : 2;
                     atomicAdd(&D.pass_stats[c], 1ull);
                     atomicAdd(&D.pass_stats[4 + c], (unsigned long long)ncommit);
@@ -681,8 +780,8 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
                 serial_len = 8;
                 continue;
             }
-            if (D.pass_counters && lane == 0) atomicAdd(&D.pass_stats[8], 1ull);  // nothing to commit: first packet flagged
-        } else if (D.pass_counters && lane == 0) {
+            if (prof_counters(D) && lane == 0 && writer) atomicAdd(&D.pass_stats[8], 1ull);  // nothing to commit: first packet flagged
+        } else if (prof_counters(D) && lane == 0 && writer) {
             atomicAdd(&D.pass_stats[ok_t ? 10 : 9], 1ull);
         }
         // ---- serial pass: up to serial_len packets with the plain recurrence, wave-uniform (every lane
@@ -785,7 +884,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
             const bool valid = lane < nv;
             if (TRACE && (int64_t)((uint64_t)st.a + st.d + nv) > D.trace_stride) st.flags |= PCC_FLAG_TRACE_OVERRUN;
             const uint64_t dm = __ballot(valid && my_drop), am = __ballot(valid && !my_drop);
-            if (valid) {
+            if (valid && writer) {
                 double2 rec;
                 rec.x = my_t;
                 rec.y = my_lat;
@@ -796,7 +895,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, double dl,
             st.a += (uint32_t)__popcll(am);
             st.d += (uint32_t)__popcll(dm);
             st.sent += nv;
-            if (D.pass_counters && lane == 0) {
+            if (prof_counters(D) && lane == 0 && writer) {
                 atomicAdd(&D.pass_stats[3], 1ull);
                 atomicAdd(&D.pass_stats[7], (unsigned long long)nv);
                 atomicAdd(&D.pass_stats[14], (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));
@@ -954,14 +1053,18 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
 // the same predicted packet count, sent lane-per-env in rounds; a heavy item (`heavy_wave`) is ONE env
 // sent by all 64 lanes (heavy_mi).  Which path sends an env is a performance choice only: every path
 // is exact.  Lanes without an env stay in: the wave path needs all 64 lanes as workers.
-template <int NS, bool TRACE>
+// W > 1: a TEAM item -- one env (lane 0 of every wavefront names it) sent by the W wavefronts of the workgroup together
+// (heavy_mi<.., W>); every wavefront loads the env's state and computes everything alike, wavefront 0 writes.
+template <int NS, bool TRACE, int W = 1>
 __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, const int64_t i, const bool in_range,
                                           const bool heavy_wave, const uint32_t tl_slot, int warm, uint32_t warm_mi,
-                                          const void *actions, int actions_f64) {
+                                          const void *actions, int actions_f64, const uint32_t wv = 0, TeamX *X = nullptr) {
+    static_assert(W == 1 || NS == 1, "team items are built for one sender");
+    const bool writer = W == 1 || wv == 0u;
     const bool live = in_range && !(warm && !D.env[in_range ? i : 0].resetting);
     if (!__ballot(live)) return;
     const int64_t ii = live ? i : 0;
-    const uint64_t tl0 = D.timeline ? wall_clock64() : 0;
+    const uint64_t tl0 = prof_on(D) ? wall_clock64() : 0;
     uint64_t tl1 = 0, tl_heavy = 0, tl_heavy_pk = 0;
 
     const double dl = D.env[ii].dl, lr = D.env[ii].lr, maxq = D.env[ii].maxq, ebw = D.env[ii].ebw;
@@ -982,11 +1085,16 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
         if (!warm && live) {
             const int64_t a = D.use_cwnd ? ii * 2 : ii * NS + s;  // USE_CWND: [rate action, cwnd action] per env
             double delta = actions_f64 ? ((const double *)actions)[a] : (double)((const float *)actions)[a];
+            if (delta != delta) { delta = 0.0; flags |= PCC_FLAG_BAD_ACTION; }  // NaN: never silent, never in the clock
             delta *= D.delta_scale;
             rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
             if (rate > kMaxRate) rate = kMaxRate;
             if (rate < kMinRate) rate = kMinRate;
-            D.snd[k].rate = rate;
+            if constexpr (W == 1) D.snd[k].rate = rate;
+        }
+        if constexpr (W > 1) {  // the new rate is stored once every wavefront of the team has read the old one
+            __syncthreads();
+            if (writer && !warm && live) D.snd[k].rate = rate;
         }
         gap[s] = 1.0 / rate;  // ns:161
         nsend[s] = D.snd[k].next_send;
@@ -1011,11 +1119,12 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
             want = tier_for(D, ta[s] - ha[s] + n_max, td[s] - hd[s] + n_max);
         }
         uint64_t pm = __ballot(run && want > (uint32_t)D.snd[k].ring_tier && want < (uint32_t)D.n_tiers);
-        while (pm) {
+        while (pm && writer) {
             const uint32_t l = (uint32_t)__ffsll((unsigned long long)pm) - 1u;
             pm &= pm - 1ull;
             if (!promote_rings(D, lane, l, k, want, ha[s], ta[s], hd[s], td[s]) && lane == l) flags |= PCC_FLAG_POOL_EXHAUSTED;
         }
+        if constexpr (W > 1) __syncthreads();  // the other wavefronts of a team read the address wavefront 0 just stored
         rings[s] = ring_ref(D, k);
     }
     const uint32_t mask_b = (rings[0].cap - 1u) << 4, dmask_b = (2u * rings[0].cap - 1u) << 4, cap_b = rings[0].cap << 4;
@@ -1038,6 +1147,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
             if (!warm && live) {  // apply_cwnd_delta + set_cwnd: ns:243-249, 283-289
                 const int64_t ai = ii * 2 + 1;
                 double delta = actions_f64 ? ((const double *)actions)[ai] : (double)((const float *)actions)[ai];
+                if (delta != delta) { delta = 0.0; flags |= PCC_FLAG_BAD_ACTION; }
                 delta *= D.delta_scale;
                 const double c = delta >= 0.0 ? (double)cw * (1.0 + delta) : (double)cw / (1.0 - delta);
                 cw = c >= 5000.0 ? 5000u : (c < 4.0 ? 4u : (uint32_t)c);  // int(), then [MIN_CWND, MAX_CWND] (ns:33-34)
@@ -1114,14 +1224,14 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
                     uint32_t budget4 = D.round_packets / 4 - safe4;
                     for (; safe4; safe4--) {
                         uint32_t w[4];
-                        if (D.debug_skip & 8) { w[0] = blk * 2654435761u; w[1] = w[0] ^ gid; w[2] = w[1] * 40503u; w[3] = w[2] ^ mi; } else philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                        if (prof_skip(D, 8)) { w[0] = blk * 2654435761u; w[1] = w[0] ^ gid; w[2] = w[1] * 40503u; w[3] = w[2] ^ mi; } else philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
                         blk++;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             bool dropped;
                             const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
                             const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                            if (!(D.debug_skip & 4)) st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                            if (!prof_skip(D, 4)) st_rec(reinterpret_cast<double2 *>(base + off), rec);
                             a += dropped ? 0u : 1u;
                             d += dropped ? 1u : 0u;
                             t += gap[0];  // ns:161
@@ -1129,7 +1239,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
                     }
                     for (; budget4 && t < end; budget4--) {
                         uint32_t w[4];
-                        if (D.debug_skip & 8) { w[0] = blk * 2654435761u; w[1] = w[0] ^ gid; w[2] = w[1] * 40503u; w[3] = w[2] ^ mi; } else philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                        if (prof_skip(D, 8)) { w[0] = blk * 2654435761u; w[1] = w[0] ^ gid; w[2] = w[1] * 40503u; w[3] = w[2] ^ mi; } else philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
                         blk++;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
@@ -1137,7 +1247,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
                             bool dropped;
                             const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
                             const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                            if (!(D.debug_skip & 4)) st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                            if (!prof_skip(D, 4)) st_rec(reinterpret_cast<double2 *>(base + off), rec);
                             a += dropped ? 0u : 1u;
                             d += dropped ? 1u : 0u;
                             t += gap[0];  // ns:161
@@ -1169,7 +1279,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
         }
         // the envs for the wave path (a heavy item's env, or the tail of a light item), one after the other
         uint64_t hm = __ballot(heavy_now);
-        if (D.timeline) {
+        if (prof_on(D)) {
             tl1 = wall_clock64();
             tl_heavy = (uint64_t)__popcll(hm);
             tl_heavy_pk = (uint64_t)0 - ((a - ta[0]) + (d - td[0]));  // completed below with the final count
@@ -1179,11 +1289,11 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
             const uint32_t l = (uint32_t)__ffsll((unsigned long long)hm) - 1u;
             hm &= hm - 1ull;
             SendState st;
-            if (D.pass_counters && lane == 0) atomicAdd(&D.pass_stats[heavy_wave ? 11 : 12], 1ull);
+            if (prof_counters(D) && lane == 0 && writer) atomicAdd(&D.pass_stats[heavy_wave ? 11 : 12], 1ull);
             st.q = rl_f64(q, l); st.tu = rl_f64(tu, l); st.t = rl_f64(t, l);
             st.a = rl_u32(a, l); st.d = rl_u32(d, l); st.flags = 0;
             st.sent = (st.a - rl_u32(ta[0], l)) + (st.d - rl_u32(td[0], l));  // packets of this MI already sent by the lane
-            heavy_mi<TRACE>(D, lane, rl_f64(dl, l), rl_f64(lr, l), rl_u32(thr, l), rl_u32(always ? 1u : 0u, l) != 0u,
+            heavy_mi<TRACE, W>(D, lane, wv, X, rl_f64(dl, l), rl_f64(lr, l), rl_u32(thr, l), rl_u32(always ? 1u : 0u, l) != 0u,
                             rl_f64(maxq, l), rl_f64(ebw, l), rl_f64(gap[0], l), rl_f64(end, l), rl_u32(episode, l),
                             rl_u32(mi, l), rl_u32(gid, l),
                             reinterpret_cast<const double *>(rl_u64(reinterpret_cast<uint64_t>(trace), l)),
@@ -1193,7 +1303,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
         nsend[0] = t;
         sent[0] = (a - ta[0]) + (d - td[0]);
         ta[0] = a; td[0] = d;
-        if (D.timeline && heavy_now) tl_heavy_pk += sent[0];
+        if (prof_on(D) && heavy_now) tl_heavy_pk += sent[0];
         }  // !use_cwnd
     } else {
         // two senders merged in (time, sender id) order: lane-serial rounds, then the tail of the
@@ -1304,7 +1414,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
         }
     }
 
-    if (D.timeline) {
+    if (prof_on(D)) {
         // words: start, end of the lane rounds, end (100 MHz ticks), envs sent by the wave path,
         // packets of the wave, packets of its largest env, packets sent by the wave path, live lanes
         uint64_t sum = live ? sent[0] : 0, mx = sum, hp = tl_heavy_pk;
@@ -1314,13 +1424,13 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
             const uint64_t other = __shfl_xor(mx, o);
             mx = other > mx ? other : mx;
         }
-        if (lane == 0) {
+        if (lane == 0 && writer) {
             uint64_t *w = D.timeline + (int64_t)tl_slot * 8;
             w[0] = tl0; w[1] = tl1; w[2] = wall_clock64(); w[3] = tl_heavy; w[4] = sum; w[5] = mx; w[6] = hp;
             w[7] = (uint64_t)__popcll(__ballot(live));
         }
     }
-    if (!live) return;
+    if (!live || !writer) return;
     D.env[i].q = q; D.env[i].tu = tu;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
@@ -1427,20 +1537,100 @@ struct Bound {
 template <int K>
 __device__ __forceinline__ void search_many(const Group &g, const double2 *const (&ring)[K], const uint32_t (&mask)[K],
                                             const uint32_t (&lo0)[K], const uint32_t (&hi0)[K], const double (&add)[K],
-                                            double end, Bound (&out)[K]) {
+                                            double end, const uint32_t (&hint)[K], Bound (&out)[K],
+                                            unsigned long long *stat = nullptr /* profile build: hit counters */) {
     static_assert(K == 4 && kGroup == 16, "one search per quad of the 16-lane group");
-    // Narrowing rounds: search q belongs to lanes 4q..4q+3, which sample the ends of 4 equal
-    // sub-ranges -- all four searches in the same instructions, 16 scattered lines per round instead
-    // of 64 (the retire half is bound by the rate of scattered memory operations), at the price of
-    // one or two more rounds than a 16-way split would need.
+    // The window step (first and last): lane l looks at record base + l of the 16 records around [lo, hi], hi - lo <= 12,
+    // base = lo - 2 (clamped to the ring's start).  It finds the transition inside [lo, hi] and tells whether the records
+    // next to it are "near" -- and, from records lo - 1 and hi, whether the transition IS inside: with a good prediction of
+    // the boundary (hint: where it would be if this interval retired what the last one did) the whole search is this one
+    // round trip, 2-3 lines per ring instead of the 12-16 of a descent from the ring's ends.
+    uint32_t lo[K], hi[K];
+    bool inside[K];
+    bool all_inside = true;
+    auto window = [&](const bool (&need)[K], const bool last) {
+        double2 r[K];
+        uint32_t base[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            base[k] = lo[k] - lo0[k] >= 2u ? lo[k] - 2u : lo0[k];
+            const uint32_t idx = base[k] + g.lane;
+            r[k].x = 0.0; r[k].y = 0.0;
+            if (need[k] && idx < hi0[k]) r[k] = ld_rec(ring[k] + (idx & mask[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (!need[k]) continue;  // (the same for the 16 lanes of the group)
+            const uint32_t idx = base[k] + g.lane;
+            const bool in = idx < hi0[k];
+            const bool passes = in && (r[k].x + add[k] < end);
+            const uint32_t mpass = gballot(g, passes);
+            const bool fail = in && idx >= lo[k] && idx < hi[k] && !passes;
+            const uint32_t m = gballot(g, fail);
+            const uint32_t b = m ? base[k] + (uint32_t)__ffs((int)m) - 1u : hi[k];
+            // the transition lies in [lo, hi] iff record lo - 1 passes and record hi fails (where they exist)
+            const bool lo_ok = lo[k] == lo0[k] || ((mpass >> (lo[k] - 1u - base[k])) & 1u);
+            const bool hi_ok = hi[k] == hi0[k] || !((mpass >> (hi[k] - base[k])) & 1u);
+            inside[k] = last || (lo_ok && hi_ok);  // (after the descent the window holds the transition by construction)
+            if (!inside[k]) {  // the descent goes on in the part of the ring the window points to
+                if (!lo_ok) { hi[k] = lo[k] - 1u; lo[k] = lo0[k]; }
+                else { lo[k] = hi[k] + 1u; hi[k] = hi0[k]; }
+                continue;
+            }
+            // near flag of lane l: records idx and idx+1 both exist and are within rounding distance
+            const double tn = __shfl_down(r[k].x, 1, kGroup);
+            const bool nr = in && (idx + 1 < hi0[k]) && g.lane + 1 < kGroup && near_time(r[k].x, tn);
+            const uint32_t mnear = gballot(g, nr);
+            // pairs that matter: (b-2,b-1), (b-1,b), (b,b+1) -> lanes (b-2-base), (b-1-base), (b-base)
+            uint32_t want = 0;
+            for (int d = 0; d < 3; d++) {
+                const int l = (int)(b - base[k]) - 2 + d;
+                if (l >= 0 && l < kGroup) want |= 1u << l;
+            }
+            out[k].b = b;
+            out[k].clean = (mnear & want) == 0u;
+            const uint32_t lb = b - base[k];
+            out[k].t = gbcast(r[k].x, lb < (uint32_t)kGroup ? lb : 0u);
+            out[k].lat = gbcast(r[k].y, lb < (uint32_t)kGroup ? lb : 0u);
+        }
+    };
+    // ---- 1. the predicted windows
+    bool need[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        uint32_t h = hint[k] < lo0[k] ? lo0[k] : (hint[k] > hi0[k] ? hi0[k] : hint[k]);
+        lo[k] = h - lo0[k] >= 5u ? h - 5u : lo0[k];
+        hi[k] = hi0[k] - lo[k] > 12u ? lo[k] + 12u : hi0[k];
+        need[k] = true;
+    }
+    window(need, false);
+#pragma unroll
+    for (int k = 0; k < K; k++) all_inside = all_inside && inside[k];
+    if (kProfile && stat) {  // searches, searches whose predicted window held the boundary; wavefronts, wavefronts without a descent
+        if (g.lane == 0) {
+            atomicAdd(&stat[0], (unsigned long long)K);
+            atomicAdd(&stat[1], (unsigned long long)((inside[0] ? 1 : 0) + (inside[1] ? 1 : 0) + (inside[2] ? 1 : 0) + (inside[3] ? 1 : 0)));
+        }
+        const uint64_t act = __ballot(true), hit = __ballot(all_inside);
+        if ((threadIdx.x & (kWave - 1)) == (uint32_t)__ffsll((unsigned long long)act) - 1u) {
+            atomicAdd(&stat[2], 1ull);
+            if (act == hit) atomicAdd(&stat[3], 1ull);
+        }
+    }
+    if (all_inside) return;
+    // ---- 2. narrowing rounds for the searches whose window missed: search q belongs to lanes 4q..4q+3, which sample the
+    // ends of 4 equal sub-ranges -- all four searches in the same instructions, 16 scattered lines per round instead
+    // of 64 (the retire half is bound by the rate of scattered memory operations), at the price of one or two more
+    // rounds than a 16-way split would need.
     const uint32_t q = g.lane >> 2, j = g.lane & 3u;
-    uint32_t lo_m = q == 0 ? lo0[0] : q == 1 ? lo0[1] : q == 2 ? lo0[2] : lo0[3];
-    uint32_t hi_m = q == 0 ? hi0[0] : q == 1 ? hi0[1] : q == 2 ? hi0[2] : hi0[3];
+    uint32_t lo_m = q == 0 ? lo[0] : q == 1 ? lo[1] : q == 2 ? lo[2] : lo[3];
+    uint32_t hi_m = q == 0 ? hi[0] : q == 1 ? hi[1] : q == 2 ? hi[2] : hi[3];
+    const bool done_m = q == 0 ? inside[0] : q == 1 ? inside[1] : q == 2 ? inside[2] : inside[3];
     const double2 *ring_m = q == 0 ? ring[0] : q == 1 ? ring[1] : q == 2 ? ring[2] : ring[3];
     const uint32_t mask_m = q == 0 ? mask[0] : q == 1 ? mask[1] : q == 2 ? mask[2] : mask[3];
     const double add_m = q == 0 ? add[0] : q == 1 ? add[1] : q == 2 ? add[2] : add[3];
     for (;;) {
-        const bool active = hi_m - lo_m > 12u;
+        const bool active = !done_m && hi_m - lo_m > 12u;
         if (!gballot(g, active)) break;
         const uint32_t stride = (hi_m - lo_m + 3u) / 4u;
         uint32_t x = lo_m + (j + 1u) * stride;
@@ -1462,42 +1652,13 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
             }
         }
     }
-    uint32_t lo[K], hi[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) { lo[k] = gbcast(lo_m, 4u * k); hi[k] = gbcast(hi_m, 4u * k); }
-    // final step: lane l looks at record base + l, base = lo - 2 (clamped to the ring's start)
-    double2 r[K];
-    uint32_t base[K];
+    // ---- 3. the window around each of those transitions
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        base[k] = lo[k] - lo0[k] >= 2u ? lo[k] - 2u : lo0[k];
-        const uint32_t idx = base[k] + g.lane;
-        r[k].x = 0.0; r[k].y = 0.0;
-        if (idx < hi0[k]) r[k] = ld_rec(ring[k] + (idx & mask[k]));
+        need[k] = !inside[k];
+        if (need[k]) { lo[k] = gbcast(lo_m, 4u * k); hi[k] = gbcast(hi_m, 4u * k); }
     }
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const uint32_t idx = base[k] + g.lane;
-        const bool in = idx < hi0[k];
-        const bool fail = in && idx >= lo[k] && idx < hi[k] && !(r[k].x + add[k] < end);
-        const uint32_t m = gballot(g, fail);
-        const uint32_t b = m ? base[k] + (uint32_t)__ffs((int)m) - 1u : hi[k];
-        // near flag of lane l: records idx and idx+1 both exist and are within rounding distance
-        const double tn = __shfl_down(r[k].x, 1, kGroup);
-        const bool nr = in && (idx + 1 < hi0[k]) && g.lane + 1 < kGroup && near_time(r[k].x, tn);
-        const uint32_t mnear = gballot(g, nr);
-        // pairs that matter: (b-2,b-1), (b-1,b), (b,b+1) -> lanes (b-2-base), (b-1-base), (b-base)
-        uint32_t want = 0;
-        for (int d = 0; d < 3; d++) {
-            const int l = (int)(b - base[k]) - 2 + d;
-            if (l >= 0 && l < kGroup) want |= 1u << l;
-        }
-        out[k].b = b;
-        out[k].clean = (mnear & want) == 0u;
-        const uint32_t lb = b - base[k];
-        out[k].t = gbcast(r[k].x, lb < (uint32_t)kGroup ? lb : 0u);
-        out[k].lat = gbcast(r[k].y, lb < (uint32_t)kGroup ? lb : 0u);
-    }
+    window(need, true);
 }
 
 // ---- serial paths on the dropped ring (one lane) -----------------------------------------
@@ -2007,8 +2168,19 @@ __device__ __forceinline__ void reset_env(const Dev &D, const int64_t i, float *
 #pragma unroll
         for (int s = 0; s < NS; s++) rate0[s] = (D.lo[4] + (D.hi[4] - D.lo[4]) * u32_to_unit(w1[s])) * bw;
     }
-    // caller-supplied parameters cannot be checked on the host (device arrays): never silent
-    if (!(bw > 0.0) || !(bw <= 1e8) || !(lat > 0.0) || !(queue >= 1.0) || !(loss >= 0.0) || !(loss <= 1.0)) D.env[i].flags |= PCC_FLAG_BAD_PARAMS;
+    // caller-supplied parameters cannot be checked on the host (device arrays): never silent.  A link outside what
+    // the formulation covers is flagged and replaced by a harmless stand-in -- with rate0 <= 0 or NaN the SEND times
+    // would not advance and the send loops would never end
+    bool bad = !(bw > 0.0) || !(bw <= 1e8) || !(lat > 0.0) || !(lat <= 1e6) || !(queue >= 1.0) || !(queue <= 1e9) ||
+               !(loss >= 0.0) || !(loss <= 1.0);
+#pragma unroll
+    for (int s = 0; s < NS; s++) bad = bad || !(rate0[s] > 0.0) || !(rate0[s] <= 1e9);
+    if (bad) {
+        D.env[i].flags |= PCC_FLAG_BAD_PARAMS;
+        bw = 100.0; lat = 0.1; queue = 2.0; loss = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) rate0[s] = 100.0;
+    }
     D.env[i].bw = bw; D.env[i].dl = lat; D.env[i].lr = loss;
     D.env[i].maxq = queue / bw;   // ns:64
     D.env[i].ebw = 1.0 / bw;      // ns:77
@@ -2027,6 +2199,7 @@ __device__ __forceinline__ void reset_env(const Dev &D, const int64_t i, float *
         D.snd[k].next_send = 1.0 / rate0[s];  // ns:111
         D.snd[k].ha = 0; D.snd[k].hd = 0; D.snd[k].ta = 0; D.snd[k].td = 0; D.snd[k].mi_sent = 0;
         D.snd[k].min_lat = 0.0;   // fresh sender id => no connection minimum yet (ns:229-233, so:158)
+        D.snd[k].ack_rate = 0.f; D.snd[k].loss_rate = 0.f; D.snd[k].on_return_a = 0; D.snd[k].on_return_d = 0;
         D.snd[k].ep_return = 0.0;
         // all-empty history (so:57-62): every metric of an empty MI is 0 except the two ratios
         float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
@@ -2052,8 +2225,8 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
     if (warm && !D.env[i].resetting) return -1.0f;
     const bool lead = g.lane == 0;
     // profiling only: where a wavefront's retire time goes (lane 0's view), summed per workgroup
-    const bool tl = D.timeline != nullptr && (threadIdx.x & (kWave - 1)) == 0;
-    uint64_t *tlw = D.timeline ? D.timeline + (int64_t)2 * D.n * 8 + (int64_t)blockIdx.x * 16 : nullptr;
+    const bool tl = prof_on(D) && (threadIdx.x & (kWave - 1)) == 0;
+    uint64_t *tlw = prof_on(D) ? D.timeline + (int64_t)2 * D.n * 8 + (int64_t)blockIdx.x * 16 : nullptr;
     uint64_t tl_t = tl ? wall_clock64() : 0;
     if (tl && threadIdx.x == 0) tlw[0] = tl_t;  // this launch's start of the workgroup (slot 1: its end)
 #define PCC_TL_STAMP(slot)                                                                               \
@@ -2095,6 +2268,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         double rate = D.snd[i].rate;
         if (!warm) {
             double delta = actions_f64 ? ((const double *)actions)[i] : (double)((const float *)actions)[i];
+            if (delta != delta) { delta = 0.0; flags |= PCC_FLAG_BAD_ACTION; }
             delta *= D.delta_scale;
             rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
             if (rate > kMaxRate) rate = kMaxRate;
@@ -2131,8 +2305,23 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             const uint32_t his[4] = {ta[s], ta[s], td[s], td[s]};
             const double adds[4] = {dl, 0.0, dl, 0.0};
             Bound bnd[4];
+            // where the boundaries would be if this interval retired what the last one did (per second of simulated time)
+            const int64_t k_s = (int64_t)s * D.n + i;
+            const float span = (float)run_dur;
+            const uint32_t h_pa = ha[s] + (uint32_t)(D.snd[k_s].ack_rate * span), h_pd = hd[s] + (uint32_t)(D.snd[k_s].loss_rate * span);
+            const uint32_t hints[4] = {h_pa, h_pa + D.snd[k_s].on_return_a, h_pd, h_pd + D.snd[k_s].on_return_d};
             PCC_TL_STAMP(3)  // state loads
-            search_many<4>(g, rings, masks, los, his, adds, end, bnd);
+            search_many<4>(g, rings, masks, los, his, adds, end, hints, bnd,
+                           prof_on(D) ? reinterpret_cast<unsigned long long *>(tlw + 12) : nullptr);
+            if (lead && run_dur > 0.0) {  // one 16-byte store (the ending event may move a boundary by one more: no matter)
+                const float inv = 1.0f / span;
+                uint4 pr;
+                pr.x = __float_as_uint((float)(bnd[0].b - ha[s]) * inv);
+                pr.y = __float_as_uint((float)(bnd[2].b - hd[s]) * inv);
+                pr.z = bnd[1].b - bnd[0].b;
+                pr.w = bnd[3].b >= bnd[2].b ? bnd[3].b - bnd[2].b : 0u;
+                *reinterpret_cast<uint4 *>(&D.snd[k_s].ack_rate) = pr;
+            }
             PCC_TL_STAMP(4)  // the joint boundary search
             // ---- accepted ring: send order is event order, the transitions are exact
             const uint32_t pa = bnd[0].b, ca = bnd[1].b;            // hop-2 / hop-1 events < end
@@ -2256,6 +2445,8 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
     unsigned long long sent_total = 0;
 #pragma unroll
     for (int s = 0; s < NS; s++) sent_total += sent[s];
+    // the ordering of dropped packets rests on kNearTol * now << 1/bw (near groups never span two packet times)
+    if (now * (64.0 * kNearTol) > D.env[i].ebw) flags |= PCC_FLAG_TIME_RANGE;
     if (lead) {
         if (flags) D.env[i].flags |= flags;
 #pragma unroll
@@ -2290,7 +2481,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         const int64_t k = (int64_t)s * D.n + i;
         double lat = 0.0, inc = 0.0;
         PCC_TL_STAMP(7)  // state write-back
-        if (acked[s] > 0 && !(D.debug_skip & 1))
+        if (acked[s] > 0 && !prof_skip(D, 1))
             rtt_means(g, ra[s], amask[s], from[s], acked[s], NOISE ? 0.0 : dl, need_halves, lat, inc);  // noise: the samples are whole RTTs
         PCC_TL_STAMP(8)  // RTT means
         // everything the rest of the MI reads, in one batch of loads (one round trip, not five)
@@ -2334,7 +2525,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         // an env that finishes its episode here and restarts (see the end of this function) shows the first observation
         // of its next episode: the all-empty history (so:57-62; every metric of an empty MI is 0 but the two ratios)
         const bool restarts = restart && steps + 1 >= D.max_steps;
-        for (int base = 0; base < D.HF && !(D.debug_skip & 2); base += kGroup) {
+        for (int base = 0; base < D.HF && !prof_skip(D, 2); base += kGroup) {
             const int x = base + (int)g.lane;
             float v = new_feat;  // x in [keep, HF): F <= 16, so a lane owns at most one feature entry
             if (x < keep) v = small_hist ? (base ? old_row[1] : old_row[0]) : hist[x + D.F];
@@ -2423,14 +2614,31 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
     const bool listed = read_buf >= 0;
     const int cls_mine = kClasses - 1 - (int)lane;
     const int cls_heavy = D.use_cwnd ? kClasses : (D.heavy_predict >= 1e9 ? kClasses : class_of((float)D.heavy_predict));
-    uint32_t n_mine = 0, items_mine = 0;
+    // classes from cls_team up are TEAM items: envs of thousands of packets, sent by a whole workgroup (the four wavefronts
+    // of the oldest quarter's workgroups, before they take other items) 1 024 packets per pass -- one wavefront at ~12 ns
+    // per packet made the 10-13 k-packet envs of the later part of an episode the launch's critical path (150-180 us)
+    constexpr bool kTeams = NS == 1 && !RESTART;
+    constexpr uint32_t kFront = 32;  // the longest light items that trade places with items of the oldest quarter (see below)
+    const uint32_t Qz0 = gridDim.x / 4u;
+    const uint32_t team_wgs_max = Qz0 >= kFront ? Qz0 - kFront : Qz0;  // workgroups of the oldest quarter that can take team items
+    const bool teams_on = kTeams && listed && !D.use_cwnd && D.team_predict < 1e9 && blockDim.x == kTeamMax * kWave &&
+                          team_wgs_max > 0u;
+    const int cls_team = teams_on ? (class_of((float)D.team_predict) > cls_heavy ? class_of((float)D.team_predict) : cls_heavy)
+                                  : kClasses;
+    uint32_t n_mine = 0, items_mine = 0, n_team_mine = 0, e_mine = 1;
     float est = -1.0f;  // lanes without a class sort last
     if (listed && lane < (uint32_t)kClasses) {
         n_mine = D.cls_count[read_buf * kClsStride + cls_mine * kCntStride];
         const bool hv = cls_mine >= cls_heavy;
-        items_mine = hv ? n_mine : (n_mine + E - 1) / E;
         const float pk = 8.0f * __expf(0.22314355f * ((float)cls_mine - 0.5f));  // 8 * 1.25^(c - 1/2)
-        est = hv ? pk * 0.012f : 1000.0f + pk * 0.4f;  // us; the light items, all of them, go first (see below)
+        // a heavy item is SEVERAL envs of a class when they are small (about heavy_item_packets packets together): the
+        // claim, the list entry and the envs' state are three dependent round trips through a memory pipeline the lane
+        // rounds keep full -- 10-17 us per 500-packet env, more than its passes take; lanes 0..e-1 load an env each and
+        // the wavefront sends them one after the other
+        e_mine = hv ? (uint32_t)fminf(fmaxf(D.heavy_item_packets / pk, 1.0f), 8.0f) : E;
+        items_mine = (n_mine + e_mine - 1) / e_mine;
+        if (cls_mine >= cls_team) { n_team_mine = n_mine; items_mine = 0; }
+        est = hv ? (float)e_mine * pk * 0.012f : 1000.0f + pk * 0.4f;  // us; the light items, all of them, go first (see below)
     }
     uint32_t rank = 0;  // classes that go before mine
     for (uint32_t l = 0; l < (uint32_t)kClasses; l++) {
@@ -2440,7 +2648,7 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
     // the table lives in LDS (one copy per wavefront: no barrier needed), indexed by rank
     __shared__ uint32_t s_tab[4][4][kClasses];
     uint32_t (*tab)[kClasses] = s_tab[threadIdx.x / kWave];
-    if (lane < (uint32_t)kClasses) { tab[1][rank] = items_mine; tab[2][rank] = n_mine; tab[3][rank] = (uint32_t)cls_mine; }
+    if (lane < (uint32_t)kClasses) { tab[1][rank] = items_mine; tab[2][rank] = n_mine; tab[3][rank] = (uint32_t)cls_mine | (e_mine << 8); }
     uint32_t incl = lane < (uint32_t)kClasses ? tab[1][lane] : 0u;  // inclusive prefix in rank order
     for (int o = 1; o < kClasses; o <<= 1) {
         const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
@@ -2450,9 +2658,16 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
     // the restart list (envs the last retire launch reset: warm-up intervals first) goes in front, one env per item
     const uint32_t n_restart = (RESTART && listed) ? D.cls_count[read_buf * kClsStride + kRestart * kCntStride] : 0u;
     const uint32_t n_items = listed ? n_restart + rl_u32(incl, kClasses - 1) : (uint32_t)((D.n + E - 1) / E);
-    if (D.pass_stats && wave == 0 && lane == 0) D.pass_stats[15] = n_items;
     uint32_t *cursors = D.cursors + (uint32_t)(listed ? read_buf : 2) * kShards * kCursorStride;
-    const uint32_t s_mine = wave % kShards, c0 = n_waves / kShards;
+    // team items: lane l looks after class kClasses-1-l, so the lane order is largest class first
+    uint32_t incl_team = n_team_mine;
+    for (int o = 1; o < kClasses; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl_team, o);
+        if (lane >= (uint32_t)o) incl_team += up;
+    }
+    const uint32_t n_team = rl_u32(incl_team, kClasses - 1);
+    if (kProfile && D.pass_stats && wave == 0 && lane == 0) D.pass_stats[15] = n_items + n_team;  // (team items: the last slots)
+    const uint32_t s_mine = wave % kShards;
     // the first item, no claim.  The ranking is dealt over the workgroups from the YOUNGEST quarter (the last
     // to be dispatched) to the oldest: the light items land on the youngest workgroup of every CU, the largest
     // wave-path envs on the next, and so on.  A CU's memory pipeline serves its oldest wavefronts first, and four
@@ -2462,29 +2677,61 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
     // wavefront sends an env never changes a result.
     // (The RESTART build deals oldest first: its ranking starts with the restart items, the launch's critical path.)
     uint32_t t = wave;
+    uint32_t n_orph = 0, orph_base = 0, orph_qz = 1;  // orphan j is item orph_base + (j % 4) * orph_qz - j / 4 (see the team items)
     if (listed && !RESTART) {
         const uint32_t G = gridDim.x, Qz = G / 4u, inv = G - 1u - blockIdx.x;  // G is a multiple of kShards = 16
         const uint32_t blk_items = (blockDim.x / kWave) * Qz;                   // = n_waves / 4: a quarter's wavefronts
         t = (inv / Qz) * blk_items + (threadIdx.x / kWave) * Qz + inv % Qz;
         // ... except the 32 longest light items, the launch's critical path for most of an episode: they trade places
         // with items of the oldest quarter, one per CU (0.148 -> 0.143 ms; 16: 0.146, 64: 0.144, 256: 0.151)
-        constexpr uint32_t kFront = 32;
         if (Qz >= kFront) {  // (a bijection of the first n_waves items only then)
             if (t >= 3u * blk_items && t < 3u * blk_items + kFront) t -= 3u * blk_items;
             else if (t < kFront) t += 3u * blk_items;
         }
+        if (n_team) {
+            // the oldest workgroups (first served by their CU's memory pipeline; not the kFront that hold the longest light
+            // items) send the team items, largest class first -- workgroup b items b, b + n_tw, ... -- and then claim like
+            // everybody; the first items the static hand-out gave their wavefronts ("orphans") go to the cursors instead
+            if constexpr (kTeams) {
+                const uint32_t n_tw = n_team < team_wgs_max ? n_team : team_wgs_max;  // workgroups that have a team item
+                n_orph = n_tw * (blockDim.x / kWave);
+                orph_base = 3u * blk_items + Qz - 1u;
+                orph_qz = Qz;
+                if (blockIdx.x < n_tw) {
+                    __shared__ TeamX s_team;
+                    const uint32_t wv = threadIdx.x / kWave;
+                    for (uint32_t tt = blockIdx.x; tt < n_team; tt += n_tw) {
+                        const uint64_t above = __ballot(lane < (uint32_t)kClasses && incl_team > tt);
+                        const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
+                        const uint32_t off = tt - (rl_u32(incl_team, L) - rl_u32(n_team_mine, L));
+                        const uint32_t *list = D.cls_list + ((size_t)read_buf * kListRows + (kClasses - 1u - L)) * (size_t)D.n;
+                        const int64_t i = lane == 0 ? (int64_t)list[off] : 0;
+                        send_item<NS, TRACE, kTeams ? kTeamMax : 1>(D, lane, i, lane == 0, true, n_items + tt, warm, warm_mi, actions,
+                                                                    actions_f64, wv, &s_team);
+                    }
+                    t = 0xFFFFFFF0u;  // (no first item: claim)
+                }
+            }
+        }
     }
+    const uint32_t c0 = n_waves / kShards;  // items below n_waves are dealt statically, one per wavefront
     for (;;) {
         if (t >= n_items) {
             t = 0xFFFFFFFFu;
             if (lane == 0 && listed) {
+                // the cursors hand out the orphans (if any) and then the items from n_waves on
+                const uint64_t n_claim = (uint64_t)(n_items > n_waves ? n_items : n_waves) + n_orph;
                 for (uint32_t k = 0; k < kShards && t == 0xFFFFFFFFu; k++) {
                     const uint32_t sh = (s_mine + k) % kShards;
                     uint32_t *cur = cursors + sh * kCursorStride;
                     const uint32_t seen = __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint64_t)(seen + c0) * kShards + sh >= n_items) continue;  // looks empty: no atomic
+                    if ((uint64_t)(seen + c0) * kShards + sh >= n_claim) continue;  // looks empty: no atomic
                     const uint64_t cand = (uint64_t)(atomicAdd(cur, 1u) + c0) * kShards + sh;
-                    if (cand < n_items) t = (uint32_t)cand;
+                    if (cand >= n_claim) continue;
+                    const uint32_t j = (uint32_t)cand - n_waves;
+                    const uint32_t item = j < n_orph ? orph_base + (j % (blockDim.x / kWave)) * orph_qz - j / (blockDim.x / kWave)
+                                                     : (uint32_t)cand - n_orph;
+                    if (item < n_items) t = item;  // (an orphan past the last item: nothing)
                 }
             }
             t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
@@ -2501,13 +2748,14 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
             const uint32_t tc = t - n_restart;
             const uint64_t above = __ballot(lane < (uint32_t)kClasses && tab[0][lane & (kClasses - 1)] > tc);
             const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
-            const int cls = (int)tab[3][L];
+            const int cls = (int)(tab[3][L] & 0xFFu);
+            const uint32_t e_cls = tab[3][L] >> 8;  // envs per item of this class
             const uint32_t off = tc - (tab[0][L] - tab[1][L]);
             const uint32_t n_cls = tab[2][L];
             const uint32_t *list = D.cls_list + ((size_t)read_buf * kListRows + cls) * (size_t)D.n;
             heavy = cls >= cls_heavy;
-            const uint32_t idx = heavy ? off : off * E + lane;
-            has = heavy ? lane == 0 : (lane < E && idx < n_cls);
+            const uint32_t idx = off * e_cls + lane;
+            has = lane < e_cls && idx < n_cls;
             i = has ? (int64_t)list[idx] : 0;
         } else {
             i = (int64_t)t * E + lane;
@@ -2604,7 +2852,8 @@ __global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(De
     // ---- file the workgroup's envs in the class lists of the next send (see "work lists")
     if (g.lane == 0) {
         const bool restart = pred == -2.0f;  // reset inside retire_env: its warm-up intervals come first in the next send
-        s_env[tid / kGroup] = (pred >= 0.0f || restart) ? (uint32_t)i : 0xFFFFFFFFu;
+        // every env that was stepped is filed (-1 = warm-up / no env); a prediction that is not a number goes to class 0
+        s_env[tid / kGroup] = (pred != -1.0f) ? (uint32_t)i : 0xFFFFFFFFu;
         s_cls[tid / kGroup] = restart ? (uint32_t)kRestart : (uint32_t)class_of(pred);
     }
     __threadfence_block();
@@ -2754,6 +3003,7 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
         else { if (rs) PCC_LAUNCH_SEND(2, false, true); else PCC_LAUNCH_SEND(2, false, false); }
     }
 #undef PCC_LAUNCH_SEND
+    if (rs && !warm) sim->restarts_pending = false;  // this launch runs what the restart list's envs were owed
     return check_hip(hipGetLastError(), "send kernel launch");
 }
 
@@ -2890,10 +3140,12 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.send_waves = 16;  // persistent send wavefronts per compute unit (4 per SIMD at <= 128 VGPRs)
     d.send_envs_per_wave = 64;
     d.heavy_predict = 512.0;
+    d.team_predict = 4096.0;
+    d.heavy_item_packets = 2048.0f;
     d.send_wg_waves = getenv("PCC_SEND_WG_WAVES") ? (uint32_t)atoi(getenv("PCC_SEND_WG_WAVES")) : 4u;
     if (d.send_wg_waves < 1u || d.send_wg_waves > 4u) d.send_wg_waves = 4u;
     d.retire_sorted = getenv("PCC_RETIRE_SORTED") ? (uint32_t)atoi(getenv("PCC_RETIRE_SORTED")) : 1u;
-    d.debug_skip = getenv("PCC_DEBUG_SKIP") ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;
+    d.debug_skip = (kProfile && getenv("PCC_DEBUG_SKIP")) ? atoi(getenv("PCC_DEBUG_SKIP")) : 0;  // profile build only
     const double lo[5] = {100, 0.05, 0, 0.0, 0.3}, hi[5] = {500, 0.5, 8, 0.05, 1.5};  // ns:355-358,466
     memcpy(d.lo, lo, sizeof lo); memcpy(d.hi, hi, sizeof hi);
     d.rng_mode = PCC_RNG_PHILOX;
@@ -2956,7 +3208,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         pcc_destroy(sim);
         return fail(PCC_EHIP, "initialising the env state failed");
     }
-    if (getenv("PCC_DEBUG_TIMELINE") && atoi(getenv("PCC_DEBUG_TIMELINE"))) {
+    if (kProfile && getenv("PCC_DEBUG_TIMELINE") && atoi(getenv("PCC_DEBUG_TIMELINE"))) {  // profile build only
         sim->timeline_bytes = (size_t)n_envs * 4 * 8 * sizeof(uint64_t);
         if (hipMalloc(&sim->timeline_blob, sim->timeline_bytes) != hipSuccess ||
             hipMemset(sim->timeline_blob, 0, sim->timeline_bytes) != hipSuccess) {
@@ -3085,6 +3337,11 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             sim->d.send_envs_per_wave = (uint32_t)value;
             return PCC_OK;
         case PCC_TUNE_HEAVY_PREDICT: sim->d.heavy_predict = value; return PCC_OK;
+        case PCC_TUNE_TEAM_PREDICT: sim->d.team_predict = value; return PCC_OK;
+        case PCC_TUNE_HEAVY_ITEM_PACKETS:
+            if (!(value >= 0.0 && value <= 1e9)) return fail(PCC_EINVAL, "heavy_item_packets out of range");
+            sim->d.heavy_item_packets = (float)value;
+            return PCC_OK;
         case PCC_TUNE_SEND_WAVES:
             if (!(value >= 1.0 && value <= 32.0)) return fail(PCC_EINVAL, "send_waves out of range");
             sim->d.send_waves = (uint32_t)value;

@@ -168,10 +168,10 @@ class BatchedNetworkEnv(object):
         self._trace = t
 
     def set_tuning(self, round_packets=None, takeover_lanes=None, send_envs_per_wave=None, heavy_predict=None,
-                   send_waves=None):
+                   send_waves=None, team_predict=None, heavy_item_packets=None):
         """Performance knobs of the send half (results do not depend on them); see pcc_set_tuning."""
         for key, value in ((2, round_packets), (3, takeover_lanes), (4, send_envs_per_wave), (5, heavy_predict),
-                           (8, send_waves)):
+                           (8, send_waves), (9, team_predict), (10, heavy_item_packets)):
             if value is not None:
                 check(self._L.pcc_set_tuning(self._h, key, float(value)))
 
@@ -263,9 +263,11 @@ class BatchedNetworkEnv(object):
         if bad:
             count = lambda bit: int(((flags & bit) != 0).sum().item())
             raise PccError(-6, "%d envs overflowed the in-flight ring, %d ran past the loss trace, %d found the ring pools "
-                               "empty (PCC_RING_POOLS), %d have link parameters out of range"
+                               "empty (ring_pools), %d have link parameters out of range, %d were given a NaN action, "
+                               "%d ran their clock out of the supported range"
                            % (count(native.PCC_FLAG_RING_OVERFLOW), count(native.PCC_FLAG_TRACE_OVERRUN),
-                              count(native.PCC_FLAG_POOL_EXHAUSTED), count(native.PCC_FLAG_BAD_PARAMS)))
+                              count(native.PCC_FLAG_POOL_EXHAUSTED), count(native.PCC_FLAG_BAD_PARAMS),
+                              count(native.PCC_FLAG_BAD_ACTION), count(native.PCC_FLAG_TIME_RANGE)))
 
     @property
     def device_bytes(self):

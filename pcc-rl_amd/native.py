@@ -5,10 +5,11 @@ binding's entry points raises, loudly, with the build command to run."""
 import ctypes
 import os
 
-from .build import library_path
+from .build import build_library, library_path
 
 PCC_RNG_PHILOX, PCC_RNG_TRACE = 0, 1
 PCC_FLAG_RING_OVERFLOW, PCC_FLAG_TRACE_OVERRUN, PCC_FLAG_INTERNAL, PCC_FLAG_POOL_EXHAUSTED, PCC_FLAG_BAD_PARAMS = 1, 2, 4, 8, 16
+PCC_FLAG_BAD_ACTION, PCC_FLAG_TIME_RANGE = 32, 64
 PCC_STEP_COLS = 19
 STEP_COLUMNS = ["sent", "acked", "lost", "rate", "cur_time", "run_dur", "reward",
                 "send rate", "recv rate", "recv dur", "send dur", "avg latency", "loss ratio",
@@ -49,7 +50,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = library_path()
+    # tools that ask for the profiling hooks (PCC_DEBUG_TIMELINE / PCC_DEBUG_SKIP in the environment) get the -DPCC_PROFILE=1
+    # build; the product library has none of them compiled in and reads neither variable
+    profile = bool(os.environ.get("PCC_DEBUG_TIMELINE") or os.environ.get("PCC_DEBUG_SKIP"))
+    path = build_library(profile=True) if profile else library_path()
+    if os.environ.get("PCC_SIM_LIBRARY"):   # tools/ experiments: another build of the same sources (A/B runs of compile-time variants)
+        path = os.environ["PCC_SIM_LIBRARY"]
     if not os.path.exists(path):
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -72,9 +72,19 @@ static void serial_mi(sstate_t *s, double gap, double end, double dl, double max
     }
 }
 
-#define LANES 64
+/* lanes of one pass: 64 = one wavefront (heavy_mi<.., 1>), 256 = a team of four wavefronts (heavy_mi<.., 4>: the same pass over
+ * 1 024 positions, the prefix sums carried from wavefront to wavefront through LDS).  pcc_model_set_lanes picks it. */
+#define MAX_LANES 1024
 #define PER_LANE 4
-#define PASS (LANES * PER_LANE)
+static int g_lanes = 64;
+#define LANES g_lanes
+#define PASS (g_lanes * PER_LANE)
+#define MAX_PASS (MAX_LANES * PER_LANE)
+int pcc_model_set_lanes(int lanes) {
+    if (lanes < 1 || lanes > MAX_LANES) return -1;
+    g_lanes = lanes;
+    return 0;
+}
 
 /* one MI by passes; mirrors heavy_mi in pcc_sim.hip */
 static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq, double ebw, const uint8_t *loss,
@@ -124,11 +134,11 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
                         D0i = (int64_t)(D0 * inv_u);
                         Gi = (int64_t)(G * inv_u);
                         Ri = (int64_t)(R * inv_u);
-                        /* room in the queue, in packets (estimate): with >= 300 every packet of the pass
+                        /* room in the queue, in packets (estimate): with >= PASS + 44 every packet of the pass
                          * that is not lost at random is accepted and the token arithmetic is not needed
                          * (maxq / u may not even fit an int64 then) */
                         const double room = ((maxq - R) - x0) / R;
-                        free_mode = room >= 300.0;
+                        free_mode = room >= (double)PASS + 44.0;
                         Mi = free_mode ? 0 : (int64_t)(maxq * inv_u);
                         if (tie && ((Q0i | D0i | Gi) & 1)) { ok = 0; why = 4; }
                         maxq_above = exp_bits(maxq) > e;
@@ -168,8 +178,8 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
              * (positions before `skip` belong to packets the lane rounds already sent: they do not exist). */
             const int64_t C = (Mi - Ri) - Q0i + D0i;   /* A_k = C + k Gi;  N_k = floor((A_k + Ri) / Ri) >= 0 */
             const int over = !free_mode && Gi < Ri;     /* overdriven and close to full: the token scan decides */
-            uint8_t m_k[PASS], ex_k[PASS], acc_k[PASS], flag_k[PASS];
-            double x_k[PASS];
+            uint8_t m_k[MAX_PASS], ex_k[MAX_PASS], acc_k[MAX_PASS], flag_k[MAX_PASS];
+            double x_k[MAX_PASS];
             for (uint32_t p = 0; p < PASS; p++) {
                 const int32_t k = (int32_t)p - (int32_t)skip;
                 const double tk = t0 + (double)(k < 0 ? 0 : k) * G;
@@ -179,7 +189,7 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
             /* phase 1 (overdriven only), per lane: tokens at the lane's first packet by one division
              * (double estimate + exact integer correction), token arrivals a of its packets, and the
              * lane's composite Lindley map b -> max(b + S, C) */
-            int32_t S_l[LANES], C_l[LANES], N_l[LANES], a_k[PASS];
+            int32_t S_l[MAX_LANES], C_l[MAX_LANES], N_l[MAX_LANES], a_k[MAX_PASS];
             for (int l = 0; l < LANES && over; l++) {
                 int32_t k0 = 4 * l - (int32_t)skip;
                 if (k0 < 0) k0 = 0;
@@ -205,7 +215,7 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
                 S_l[l] = Ssum; C_l[l] = Cmax;
             }
             /* phase 2: exclusive scan of the lane composites (the kernel: 6 DPP steps) */
-            int32_t bin_l[LANES], jin_l[LANES];
+            int32_t bin_l[MAX_LANES], jin_l[MAX_LANES];
             {
                 int32_t preS = 0, preC = INT32_MIN / 2, jrun = 0;
                 const int32_t b0 = over ? N_l[0] : ((free_mode || C >= 0) ? 1 : 0);

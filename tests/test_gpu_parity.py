@@ -159,7 +159,7 @@ def test_auto_reset_and_second_episode_match_oracle():
     env.close()
 
 
-@pytest.mark.parametrize("knobs", [dict(), dict(heavy_predict=128.0, takeover_lanes=4)])
+@pytest.mark.parametrize("knobs", [dict(), dict(heavy_predict=128.0, takeover_lanes=4), dict(team_predict=300.0)])
 def test_conservation_and_queue_bounds_at_full_size(knobs):
     """Size-independent properties at BASELINE's 65 536 envs: every packet sent is acked, lost
     or still in flight; the queue never exceeds its limit; clocks only move forward.  And the
@@ -236,6 +236,12 @@ def test_old_gym_adapter_drop_in():
     dict(send_waves=32, heavy_predict=64.0),                     # more wavefronts than items
     dict(send_envs_per_wave=64, heavy_predict=256.0, takeover_lanes=8),
     dict(heavy_predict=16.0, round_packets=16),                  # nearly everything by wave passes of every regime
+    dict(heavy_predict=0.0, team_predict=0.0),                   # every env a TEAM item: four wavefronts, 1 024 positions per pass
+    dict(heavy_predict=16.0, team_predict=100.0, round_packets=16),   # lane rounds, wave passes and team passes side by side
+    dict(team_predict=1e18),                                     # no team items: the giants on one wavefront
+    dict(heavy_predict=64.0, team_predict=64.0, send_waves=1),   # more team items than team workgroups
+    dict(heavy_predict=32.0, heavy_item_packets=0.0),            # one env per wave-path item
+    dict(heavy_predict=32.0, heavy_item_packets=1e6, team_predict=1e18),   # eight envs per wave-path item
 ])
 def test_send_paths_are_exact_whatever_the_tuning(knobs):
     """The tuning knobs only choose WHICH exact send path runs (lane-serial rounds, the wave-wide
@@ -302,6 +308,19 @@ def test_wave_path_on_golden_traces():
         env.set_tuning(heavy_predict=0.0)
         env.reset()
         env.set_tuning(heavy_predict=0.0, takeover_lanes=64, round_packets=4)
+        steps, obs, done = run_gpu(env, d["actions"], d["actions"].shape[1])
+        assert np.array_equal(steps, d["steps"]), name
+        env.close()
+
+
+def test_team_path_on_golden_traces():
+    """Trace mode through the team path (a whole workgroup per env, heavy_mi<.., 4>): the reference's own episodes with
+    every env a team item from its first interval on."""
+    for name in ("saturating_0_2", "fixed_deepq", "fixed_lossy", "default_pm1"):
+        d = load(name)
+        env = golden_env(d, history_len=int(d["history_len"]))
+        env.reset()
+        env.set_tuning(heavy_predict=0.0, team_predict=0.0)
         steps, obs, done = run_gpu(env, d["actions"], d["actions"].shape[1])
         assert np.array_equal(steps, d["steps"]), name
         env.close()

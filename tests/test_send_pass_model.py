@@ -22,18 +22,27 @@ def model():
     L.pcc_model_fuzz.restype = ctypes.c_long
     L.pcc_model_fuzz.argtypes = [ctypes.c_long, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     L.pcc_model_episodes.restype = ctypes.c_long
+    L.pcc_model_set_lanes.argtypes = [ctypes.c_int]
     return L
 
 
-def test_fuzzed_link_states(model):
+# lanes of one pass: 64 = one wavefront (heavy_mi<.., 1>), 256 = a team of four wavefronts (heavy_mi<.., 4>)
+LANES = [64, 256]
+
+
+@pytest.mark.parametrize("lanes", LANES)
+def test_fuzzed_link_states(model, lanes):
+    assert model.pcc_model_set_lanes(lanes) == 0
     stats = (ctypes.c_uint64 * 16)()
-    bad = model.pcc_model_fuzz(20000, 12345, stats)
+    bad = model.pcc_model_fuzz(20000, 12345 + lanes, stats)
     assert bad == 0
     s = np.array(list(stats), dtype=np.uint64)
     assert s[:3].sum() > 0          # the closed-form regimes were exercised, not only the serial pass
 
 
-def test_interval_starts_of_real_episodes(model):
+@pytest.mark.parametrize("lanes", LANES)
+def test_interval_starts_of_real_episodes(model, lanes):
+    assert model.pcc_model_set_lanes(lanes) == 0
     model.pcc_model_episodes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                          ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     stats, hist = (ctypes.c_uint64 * 16)(), (ctypes.c_uint64 * 32)()

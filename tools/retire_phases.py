@@ -26,5 +26,10 @@ for t in range(310):
         waves = (N + 3) // 4                        # 16 lanes per env
         rec = {"step": t, "us_per_wavefront": {v: float(bl[:, k].sum()) / 100.0 / waves for k, v in names.items()}}
         rec["us_per_wavefront"]["total"] = sum(rec["us_per_wavefront"].values())
+        # (cumulative since the handle was created) boundary searches, those whose predicted window held the boundary,
+        # wavefronts, wavefronts that needed no descent at all
+        h = [int(bl[:, k].sum()) for k in (12, 13, 14, 15)]
+        rec["search_hints"] = {"searches": h[0], "window_hits": h[1], "hit_rate": h[1] / max(1, h[0]),
+                               "wavefronts": h[2], "wavefronts_without_descent": h[3], "wave_rate": h[3] / max(1, h[2])}
         out.append(rec)
 print(json.dumps(out, indent=1))
