@@ -177,7 +177,10 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_TEAM_PREDICT = 9 /* predicted packets per interval above which an env is sent by a whole workgroup (four
                                     wavefronts, 1 024 packets per pass); default 4096, >= 1e9 = never (one sender only) */,
        PCC_TUNE_HEAVY_ITEM_PACKETS = 10 /* a wave-path work item holds as many envs of one class (1..8) as make up about this
-                                    many predicted packets; default 2048, 0 = one env per item */ };
+                                    many predicted packets; default 2048, 0 = one env per item */,
+       PCC_TUNE_RETIRE_WIDE_PREDICT = 11 /* retire half: an env predicted above this many packets per interval is retired by
+                                    16 lanes (whole-list and half sums side by side), the others by 8; default 1024,
+                                    0 = every env by 16, >= 1e9 = every env by 8 */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* The reference's dormant engine option USE_CWND (ns:54; off in the reference): window-limited

@@ -61,8 +61,7 @@ namespace {
 constexpr int kMaxFeatures = 16;
 constexpr int kMaxSenders = 2;
 constexpr int kWave = 64;
-constexpr int kGroup = 16;            // lanes per env in retire_kernel
-constexpr int kRetireBlock = 128;     // 8 envs per workgroup: 0.118 ms; 16 envs: 0.122 (a workgroup's slots are refilled
+constexpr int kRetireBlock = 128;     // (16 lanes per env:) 8 envs per workgroup: 0.118 ms; 16 envs: 0.122 (a workgroup's slots are refilled
                                       // together); one wavefront per workgroup: 0.212 (the launch then waits for the
                                       // dispatcher, 16 384 workgroups at ~80 per us)
 #ifndef PCC_RETIRE_OCC
@@ -166,6 +165,7 @@ struct Dev {
     double heavy_predict;  // predicted packets per MI above which an env goes to the heavy wave
     double team_predict;   // ... above which a whole workgroup sends it (team pass)
     float heavy_item_packets;  // a heavy work item is as many envs of its class as make up about this many packets (1..8 envs)
+    float retire_wide_predict; // retire half: envs predicted above this many packets per interval get 16 lanes instead of 8
     double lo[5], hi[5];
     int rng_mode;
     const double *trace;
@@ -1483,43 +1483,51 @@ constexpr uint32_t kCursorStride = 32;  // words between shard cursors: one 128-
 // (send_kernel itself follows retire_env below: a restart item runs the env's warm-up intervals through both halves)
 
 // ======================================================================================
-// retire_kernel: 16 lanes per env
+// retire_kernel: G lanes per env -- 8 for most envs, 16 for the few with long RTT lists.  The half is bound by
+// instruction issue, not by memory (1 000 extra VALU instructions per wavefront cost it 18 us of 113,
+// profiles/r03_experiments.json): nearly all of retire_env is per-env control flow that a wavefront executes once for
+// all its groups, so twice the envs per wavefront is nearly half the instructions per env.  What 16 lanes buy -- the
+// whole-list sum and the half sums of an env side by side -- only pays for the envs whose sums are many leaves.
 // ======================================================================================
 struct Group {
-    uint32_t lane;   // 0..15 inside the env's group
+    uint32_t lane;   // 0..G-1 inside the env's group
     uint32_t shift;  // bit position of the group's lane 0 in a wave ballot
 };
 
+template <int G>
 __device__ __forceinline__ uint32_t gballot(const Group &g, bool p) {
-    return (uint32_t)(__ballot(p) >> g.shift) & 0xFFFFu;
+    return (uint32_t)(__ballot(p) >> g.shift) & ((1u << G) - 1u);
 }
 
-__device__ __forceinline__ double gbcast(double v, uint32_t src) { return __shfl(v, (int)src, kGroup); }
-__device__ __forceinline__ uint32_t gbcast(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, kGroup); }
+template <int G>
+__device__ __forceinline__ double gbcast(double v, uint32_t src) { return __shfl(v, (int)src, G); }
+template <int G>
+__device__ __forceinline__ uint32_t gbcast(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, G); }
 
-// First index k in [lo, hi) whose record fails `t1 + add < end` (hi if none), by 16-ary search:
-// every round the 16 lanes sample the ends of 16 equal sub-ranges.  Exact for a monotone
+// First index k in [lo, hi) whose record fails `t1 + add < end` (hi if none), by G-ary search:
+// every round the G lanes sample the ends of G equal sub-ranges.  Exact for a monotone
 // predicate; on the dropped ring the answer can be off inside one near group, which the caller
 // repairs (fix_drop_boundary).
+template <int G>
 __device__ __forceinline__ uint32_t search_boundary(const Group &g, const double2 *ring, uint32_t mask, uint32_t lo,
                                                     uint32_t hi, double add, double end) {
-    while (hi - lo > kGroup) {
-        const uint32_t stride = (hi - lo + kGroup - 1) / kGroup;
+    while (hi - lo > (uint32_t)G) {
+        const uint32_t stride = (hi - lo + G - 1) / G;
         uint32_t sidx = lo + (g.lane + 1) * stride;
         if (sidx > hi) sidx = hi;
         sidx -= 1;
         const bool pass = ld_t1(ring + (sidx & mask)) + add < end;
-        const uint32_t mfail = ~gballot(g, pass) & 0xFFFFu;
+        const uint32_t mfail = ~gballot<G>(g, pass) & ((1u << G) - 1u);
         if (!mfail) return hi;  // the last sample is record hi-1
         const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
-        const uint32_t s_f = gbcast(sidx, f);
-        if (f) lo = gbcast(sidx, f - 1) + 1;
+        const uint32_t s_f = gbcast<G>(sidx, f);
+        if (f) lo = gbcast<G>(sidx, f - 1) + 1;
         hi = s_f;
         if (hi < lo) hi = lo;
     }
     const uint32_t k = lo + g.lane;
     const bool fail = k < hi && !(ld_t1(ring + (k & mask)) + add < end);
-    const uint32_t m = gballot(g, fail);
+    const uint32_t m = gballot<G>(g, fail);
     return m ? lo + (uint32_t)__ffs((int)m) - 1u : hi;
 }
 
@@ -1534,39 +1542,56 @@ struct Bound {
     double t, lat;   // ring[b] (valid when b < hi0)
 };
 
-template <int K>
+template <int K, int G>
 __device__ __forceinline__ void search_many(const Group &g, const double2 *const (&ring)[K], const uint32_t (&mask)[K],
                                             const uint32_t (&lo0)[K], const uint32_t (&hi0)[K], const double (&add)[K],
                                             double end, const uint32_t (&hint)[K], Bound (&out)[K],
                                             unsigned long long *stat = nullptr /* profile build: hit counters */) {
-    static_assert(K == 4 && kGroup == 16, "one search per quad of the 16-lane group");
-    // The window step (first and last): lane l looks at record base + l of the 16 records around [lo, hi], hi - lo <= 12,
-    // base = lo - 2 (clamped to the ring's start).  It finds the transition inside [lo, hi] and tells whether the records
-    // next to it are "near" -- and, from records lo - 1 and hi, whether the transition IS inside: with a good prediction of
-    // the boundary (hint: where it would be if this interval retired what the last one did) the whole search is this one
-    // round trip, 2-3 lines per ring instead of the 12-16 of a descent from the ring's ends.
+    static_assert(K == 4 && (G == 16 || G == 8), "four searches per group of 16 or 8 lanes");
+    constexpr int R = 16 / G;  // records of a 16-record window per lane
+    // The window step (first and last): the group looks at the 16 records base .. base + 15 around [lo, hi], hi - lo <= 12,
+    // base = lo - 2 (clamped to the ring's start); lane l holds records base + l (+ 8 with 8 lanes).  It finds the
+    // transition inside [lo, hi] and tells whether the records next to it are "near" -- and, from records lo - 1 and hi,
+    // whether the transition IS inside: with a good prediction of the boundary (hint: where it would be if this interval
+    // retired what the last one did) the whole search is this one round trip, 2-3 lines per ring instead of the 12-16 of
+    // a descent from the ring's ends.
     uint32_t lo[K], hi[K];
     bool inside[K];
     bool all_inside = true;
     auto window = [&](const bool (&need)[K], const bool last) {
-        double2 r[K];
+        double2 r[K][R];
         uint32_t base[K];
 #pragma unroll
         for (int k = 0; k < K; k++) {
             base[k] = lo[k] - lo0[k] >= 2u ? lo[k] - 2u : lo0[k];
-            const uint32_t idx = base[k] + g.lane;
-            r[k].x = 0.0; r[k].y = 0.0;
-            if (need[k] && idx < hi0[k]) r[k] = ld_rec(ring[k] + (idx & mask[k]));
+#pragma unroll
+            for (int h = 0; h < R; h++) {
+                const uint32_t idx = base[k] + (uint32_t)(h * G) + g.lane;
+                r[k][h].x = 0.0; r[k][h].y = 0.0;
+                if (need[k] && idx < hi0[k]) r[k][h] = ld_rec(ring[k] + (idx & mask[k]));
+            }
         }
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (!need[k]) continue;  // (the same for the 16 lanes of the group)
-            const uint32_t idx = base[k] + g.lane;
-            const bool in = idx < hi0[k];
-            const bool passes = in && (r[k].x + add[k] < end);
-            const uint32_t mpass = gballot(g, passes);
-            const bool fail = in && idx >= lo[k] && idx < hi[k] && !passes;
-            const uint32_t m = gballot(g, fail);
+            if (!need[k]) continue;  // (the same for all lanes of the group)
+            uint32_t mpass = 0, m = 0, mnear = 0;
+#pragma unroll
+            for (int h = 0; h < R; h++) {
+                const uint32_t idx = base[k] + (uint32_t)(h * G) + g.lane;
+                const bool in = idx < hi0[k];
+                const bool passes = in && (r[k][h].x + add[k] < end);
+                mpass |= gballot<G>(g, passes) << (h * G);
+                m |= gballot<G>(g, in && idx >= lo[k] && idx < hi[k] && !passes) << (h * G);
+                // near flag of record idx: records idx and idx + 1 both exist (in the window) and are within rounding distance
+                double tn = __shfl(r[k][h].x, (int)((g.lane + 1u) & (G - 1)), G);
+                if (h + 1 < R) {
+                    const double tw = __shfl(r[k][h + 1 < R ? h + 1 : h].x, 0, G);  // the first record of the next row
+                    if (g.lane == (uint32_t)G - 1u) tn = tw;
+                }
+                const bool has_next = (h + 1 < R) || g.lane + 1 < (uint32_t)G;
+                const bool nr = in && (idx + 1 < hi0[k]) && has_next && near_time(r[k][h].x, tn);
+                mnear |= gballot<G>(g, nr) << (h * G);
+            }
             const uint32_t b = m ? base[k] + (uint32_t)__ffs((int)m) - 1u : hi[k];
             // the transition lies in [lo, hi] iff record lo - 1 passes and record hi fails (where they exist)
             const bool lo_ok = lo[k] == lo0[k] || ((mpass >> (lo[k] - 1u - base[k])) & 1u);
@@ -1577,21 +1602,19 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
                 else { lo[k] = hi[k] + 1u; hi[k] = hi0[k]; }
                 continue;
             }
-            // near flag of lane l: records idx and idx+1 both exist and are within rounding distance
-            const double tn = __shfl_down(r[k].x, 1, kGroup);
-            const bool nr = in && (idx + 1 < hi0[k]) && g.lane + 1 < kGroup && near_time(r[k].x, tn);
-            const uint32_t mnear = gballot(g, nr);
-            // pairs that matter: (b-2,b-1), (b-1,b), (b,b+1) -> lanes (b-2-base), (b-1-base), (b-base)
+            // pairs that matter: (b-2,b-1), (b-1,b), (b,b+1) -> window positions (b-2-base), (b-1-base), (b-base)
             uint32_t want = 0;
             for (int d = 0; d < 3; d++) {
                 const int l = (int)(b - base[k]) - 2 + d;
-                if (l >= 0 && l < kGroup) want |= 1u << l;
+                if (l >= 0 && l < 16) want |= 1u << l;
             }
             out[k].b = b;
             out[k].clean = (mnear & want) == 0u;
-            const uint32_t lb = b - base[k];
-            out[k].t = gbcast(r[k].x, lb < (uint32_t)kGroup ? lb : 0u);
-            out[k].lat = gbcast(r[k].y, lb < (uint32_t)kGroup ? lb : 0u);
+            const uint32_t lb = b - base[k] < 16u ? b - base[k] : 0u;  // (the group's own value)
+            double bx = r[k][0].x, by = r[k][0].y;
+            if (R > 1 && lb >= (uint32_t)G) { bx = r[k][R - 1].x; by = r[k][R - 1].y; }
+            out[k].t = gbcast<G>(bx, lb & (G - 1));
+            out[k].lat = gbcast<G>(by, lb & (G - 1));
         }
     };
     // ---- 1. the predicted windows
@@ -1618,11 +1641,12 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
         }
     }
     if (all_inside) return;
-    // ---- 2. narrowing rounds for the searches whose window missed: search q belongs to lanes 4q..4q+3, which sample the
-    // ends of 4 equal sub-ranges -- all four searches in the same instructions, 16 scattered lines per round instead
-    // of 64 (the retire half is bound by the rate of scattered memory operations), at the price of one or two more
-    // rounds than a 16-way split would need.
-    const uint32_t q = g.lane >> 2, j = g.lane & 3u;
+    // ---- 2. narrowing rounds for the searches whose window missed: search q belongs to G/4 lanes, which sample the
+    // ends of 4 equal sub-ranges (two each with 8 lanes) -- all four searches in the same instructions, 16 scattered
+    // lines per round instead of 64, at the price of one or two more rounds than a 16-way split would need.
+    constexpr int LQ = G / 4;       // lanes per search
+    constexpr int PL = 4 / LQ;      // probes per lane
+    const uint32_t q = g.lane / LQ, j = g.lane % LQ;
     uint32_t lo_m = q == 0 ? lo[0] : q == 1 ? lo[1] : q == 2 ? lo[2] : lo[3];
     uint32_t hi_m = q == 0 ? hi[0] : q == 1 ? hi[1] : q == 2 ? hi[2] : hi[3];
     const bool done_m = q == 0 ? inside[0] : q == 1 ? inside[1] : q == 2 ? inside[2] : inside[3];
@@ -1631,18 +1655,36 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
     const double add_m = q == 0 ? add[0] : q == 1 ? add[1] : q == 2 ? add[2] : add[3];
     for (;;) {
         const bool active = !done_m && hi_m - lo_m > 12u;
-        if (!gballot(g, active)) break;
+        if (!gballot<G>(g, active)) break;
         const uint32_t stride = (hi_m - lo_m + 3u) / 4u;
-        uint32_t x = lo_m + (j + 1u) * stride;
-        if (x > hi_m) x = hi_m;
-        const uint32_t sidx = x - 1u;
-        double tsamp = 0.0;
-        if (active) tsamp = ld_t1(ring_m + (sidx & mask_m));
-        const uint32_t mfail = ~(gballot(g, tsamp + add_m < end) >> (4u * q)) & 0xFu;
-        // samples of my quad's failing probe f and of the probe before it (every lane shuffles)
+        uint32_t sidx[PL];
+        uint32_t passbits = 0;  // bit p: probe p of my search passes (probes j * PL + e of lane j)
+#pragma unroll
+        for (int e = 0; e < PL; e++) {
+            uint32_t x = lo_m + (j * PL + (uint32_t)e + 1u) * stride;
+            if (x > hi_m) x = hi_m;
+            sidx[e] = x - 1u;
+        }
+        double tsamp[PL];
+#pragma unroll
+        for (int e = 0; e < PL; e++) {
+            tsamp[e] = 0.0;
+            if (active) tsamp[e] = ld_t1(ring_m + (sidx[e] & mask_m));
+        }
+#pragma unroll
+        for (int e = 0; e < PL; e++) {
+            const uint32_t bm = gballot<G>(g, tsamp[e] + add_m < end) >> (LQ * q);  // my search's lanes
+#pragma unroll
+            for (int l = 0; l < LQ; l++) passbits |= ((bm >> l) & 1u) << (l * PL + e);
+        }
+        const uint32_t mfail = ~passbits & 0xFu;
+        // samples of my search's failing probe f and of the probe before it (every lane shuffles)
         const uint32_t f = mfail ? (uint32_t)__ffs((int)mfail) - 1u : 0u;
-        const uint32_t s_f = gbcast(sidx, 4u * q + f);
-        const uint32_t s_p = gbcast(sidx, 4u * q + (f ? f - 1u : 0u));
+        const uint32_t fp = f ? f - 1u : 0u;
+        uint32_t mine_f = sidx[0], mine_p = sidx[0];
+        if (PL > 1) { mine_f = (f % PL) ? sidx[PL - 1] : sidx[0]; mine_p = (fp % PL) ? sidx[PL - 1] : sidx[0]; }
+        const uint32_t s_f = gbcast<G>(mine_f, LQ * q + f / PL);
+        const uint32_t s_p = gbcast<G>(mine_p, LQ * q + fp / PL);
         if (active) {
             if (!mfail) {
                 lo_m = hi_m;  // the last sample is record hi-1: everything passes
@@ -1656,7 +1698,7 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
 #pragma unroll
     for (int k = 0; k < K; k++) {
         need[k] = !inside[k];
-        if (need[k]) { lo[k] = gbcast(lo_m, 4u * k); hi[k] = gbcast(hi_m, 4u * k); }
+        if (need[k]) { lo[k] = gbcast<G>(lo_m, LQ * k); hi[k] = gbcast<G>(hi_m, LQ * k); }
     }
     window(need, true);
 }
@@ -1912,50 +1954,79 @@ struct NpSumWalk {
 };
 
 // Means over the RTTs (= forward latency + dl) of the n > 0 acknowledged packets
-// ring[from, from + n) of the accepted ring: the whole list (so:119-122) by lanes 0-7 and, when
-// asked, mean(second half) - mean(first half) (so:138-142) by lanes 8-15.  Every 8-lane subgroup
-// of the wavefront walks its own list(s) but all of them call the leaf code together, one memory
-// round trip per call: n <= 128 -- the usual case -- is a single call (whole list | both halves).
+// ring[from, from + n) of the accepted ring: the whole list (so:119-122) and, when asked,
+// mean(second half) - mean(first half) (so:138-142).  With 16 lanes per env lanes 0-7 walk the whole list while lanes
+// 8-15 walk the two halves; with 8 lanes the three lists are walked one after the other.  Every 8-lane subgroup of the
+// wavefront walks its own list(s) but all of them call the leaf code together, one memory round trip per call: with 16
+// lanes n <= 128 -- the usual case -- is a single call (whole list | both halves), with 8 lanes two.
+template <int G>
 __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, uint32_t mask, uint32_t from,
                                           uint32_t n, double dl, bool need_halves, double &mean_all,
                                           double &lat_inc) {
+    static_assert(G == 16 || G == 8, "one or two 8-lane subgroups per env");
     const uint32_t sub = g.lane >> 3, sl = g.lane & 7u;
     const uint32_t half = n / 2;
     const bool halves = need_halves && half >= 1;
-    // jobs of this subgroup: lanes 0-7 the whole list; lanes 8-15 first half, then second half
-    const uint32_t jb0 = from, jn0 = sub == 0 ? n : (halves ? half : 0u);
-    const uint32_t jb1 = from + half, jn1 = sub == 0 ? 0u : (halves ? n - half : 0u);
-    double res0 = 0.0, res1 = 0.0;
+    // jobs of this subgroup, in order; 16 lanes: {whole} | {first half, second half}; 8 lanes: {whole, first half, second half}
+    constexpr int kJobs = G == 16 ? 2 : 3;
+    uint32_t jb0, jn0, jb1, jn1, jb2, jn2;
+    if (G == 16) {
+        jb0 = from; jn0 = sub == 0 ? n : (halves ? half : 0u);
+        jb1 = from + half; jn1 = sub == 0 ? 0u : (halves ? n - half : 0u);
+        jb2 = from; jn2 = 0u;
+    } else {
+        jb0 = from; jn0 = n;
+        jb1 = from; jn1 = halves ? half : 0u;
+        jb2 = from + half; jn2 = halves ? n - half : 0u;
+    }
+    // (the job that may take its successor along in one call: both halves, when they are single short leaves)
+    constexpr int kPairJob = G == 16 ? 0 : 1;
+    const uint32_t pair_beg = kPairJob == 0 ? jb1 : jb2, pair_n = kPairJob == 0 ? jn1 : jn2;
+    double res0 = 0.0, res1 = 0.0, res2 = 0.0;
     NpSumWalk w;
-    w.start(jb0, jn0);
     int job = 0;
-    if (w.done) { job = 1; w.start(jb1, jn1); if (w.done) job = 2; }
+    // the first job at or after `j` that has samples (kJobs: none); starts the walk over it
+    auto start_from = [&](int j) {
+        if (j == 0 && jn0 == 0u) j = 1;
+        if (j == 1 && jn1 == 0u) j = 2;
+        if (j == 2 && (kJobs < 3 || jn2 == 0u)) j = kJobs;
+        job = j;
+        if (j == 0) w.start(jb0, jn0);
+        else if (j == 1) w.start(jb1, jn1);
+        else if (j == 2 && kJobs == 3) w.start(jb2, jn2);
+    };
+    start_from(0);
     for (;;) {
-        const bool active = job < 2;
+        const bool active = job < kJobs;
         if (!__ballot(active)) break;
         uint32_t begA = from, lenA = 0, begB = from, lenB = 0;
         bool pair = false;
         if (active) {
             w.next(begA, lenA);
-            // both halves are single short leaves: one call does both
-            pair = job == 0 && w.single_leaf() && lenA < 72 && jn1 != 0 && jn1 < 72;
-            if (pair) { begB = jb1; lenB = jn1; }
+            pair = job == kPairJob && w.single_leaf() && lenA < 72 && pair_n != 0 && pair_n < 72;
+            if (pair) { begB = pair_beg; lenB = pair_n; }
         }
         const LeafPair p = leaf_sum2(ring, mask, begA, lenA, begB, lenB, dl, sl);
         if (active) {
             if (pair) {
-                res0 = p.a; res1 = p.b; job = 2;
+                if (kPairJob == 0) { res0 = p.a; res1 = p.b; } else { res1 = p.a; res2 = p.b; }
+                job = kJobs;
             } else {
                 w.feed(p.a);
                 if (w.done) {
-                    if (job == 0) { res0 = w.tot; job = 1; w.start(jb1, jn1); if (w.done) job = 2; }
-                    else { res1 = w.tot; job = 2; }
+                    if (job == 0) res0 = w.tot; else if (job == 1) res1 = w.tot; else res2 = w.tot;
+                    start_from(job + 1);
                 }
             }
         }
     }
-    mean_all = gbcast(res0, 0) / (double)n;
-    lat_inc = halves ? gbcast(res1, 8) / (double)(n - half) - gbcast(res0, 8) / (double)half : 0.0;
+    if (G == 16) {
+        mean_all = gbcast<G>(res0, 0) / (double)n;
+        lat_inc = halves ? gbcast<G>(res1, 8) / (double)(n - half) - gbcast<G>(res0, 8) / (double)half : 0.0;
+    } else {
+        mean_all = gbcast<G>(res0, 0) / (double)n;
+        lat_inc = halves ? gbcast<G>(res2, 0) / (double)(n - half) - gbcast<G>(res1, 0) / (double)half : 0.0;
+    }
 }
 
 // the 12 metrics of one MI (so:110-191) from its counts and RTT means
@@ -2217,7 +2288,7 @@ __device__ __forceinline__ void reset_env(const Dev &D, const int64_t i, float *
 
 // Returns the env's predicted packet count for the next monitor interval (-1: nothing to report; -2: the env finished its
 // episode and was reset here -- restart = 1 -- its warm-up intervals are due in the next send launch).
-template <int NS, bool NOISE>
+template <int NS, bool NOISE, int G>
 __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const Group g, int warm, uint32_t warm_mi,
                                             int last_warm, int restart, float *obs_out, float *reward_out, uint8_t *done_out,
                                             double *steps_out, const void *actions, int actions_f64) {
@@ -2285,9 +2356,9 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         // the RTT samples the lead lane stored are read by all 16 lanes below: same wavefront, same L1 -- a workgroup-scope
         // fence orders them (an agent-scope one writes back and invalidates the XCD's whole L2)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        now = gbcast(o.now, 0); nsend[0] = gbcast(o.nsend, 0);
-        sent[0] = gbcast(o.sent, 0); acked[0] = gbcast(o.acked, 0); lost[0] = gbcast(o.lost, 0);
-        flags |= gbcast(o.flags, 0);
+        now = gbcast<G>(o.now, 0); nsend[0] = gbcast<G>(o.nsend, 0);
+        sent[0] = gbcast<G>(o.sent, 0); acked[0] = gbcast<G>(o.acked, 0); lost[0] = gbcast<G>(o.lost, 0);
+        flags |= gbcast<G>(o.flags, 0);
         ra[0] = D.noise_rtt + (size_t)i * D.noise_cap;
         amask[0] = D.noise_cap - 1u;
         from[0] = 0;
@@ -2311,7 +2382,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             const uint32_t h_pa = ha[s] + (uint32_t)(D.snd[k_s].ack_rate * span), h_pd = hd[s] + (uint32_t)(D.snd[k_s].loss_rate * span);
             const uint32_t hints[4] = {h_pa, h_pa + D.snd[k_s].on_return_a, h_pd, h_pd + D.snd[k_s].on_return_d};
             PCC_TL_STAMP(3)  // state loads
-            search_many<4>(g, rings, masks, los, his, adds, end, hints, bnd,
+            search_many<4, G>(g, rings, masks, los, his, adds, end, hints, bnd,
                            prof_on(D) ? reinterpret_cast<unsigned long long *>(tlw + 12) : nullptr);
             if (lead && run_dur > 0.0) {  // one 16-byte store (the ending event may move a boundary by one more: no matter)
                 const float inv = 1.0f / span;
@@ -2342,7 +2413,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                     pd = fx.p; dk = fx.cand_idx; d2_t = fx.cand_t; d2_l = fx.cand_lat;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                pd = gbcast(pd, 0); dk = gbcast(dk, 0); d2_t = gbcast(d2_t, 0); d2_l = gbcast(d2_l, 0);
+                pd = gbcast<G>(pd, 0); dk = gbcast<G>(dk, 0); d2_t = gbcast<G>(d2_t, 0); d2_l = gbcast<G>(d2_l, 0);
                 rotated = true;  // records may have moved inside the window
             }
             lost[s] = pd - hd[s];                                    // ns:141-143
@@ -2351,13 +2422,13 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             if (!rotated && bnd[3].clean) {
                 if (bnd[3].b < td[s]) { d1_t = bnd[3].t; d1_l = bnd[3].lat; }
             } else if (td[s] != pd) {
-                const uint32_t cd = rotated ? search_boundary(g, rd[s], dmasks[s], pd, td[s], 0.0, end)
+                const uint32_t cd = rotated ? search_boundary<G>(g, rd[s], dmasks[s], pd, td[s], 0.0, end)
                                             : (bnd[3].b < pd ? pd : bnd[3].b);
                 if (lead) {
                     const Cand c1 = drop_hop1_candidate(rd[s], dmasks[s], pd, td[s], cd, end);
                     d1_t = c1.t; d1_l = c1.lat;
                 }
-                d1_t = gbcast(d1_t, 0); d1_l = gbcast(d1_l, 0);
+                d1_t = gbcast<G>(d1_t, 0); d1_l = gbcast<G>(d1_l, 0);
             }
             // ---- best of each kind by the heap key (time, latency, dropped): ns:111,161,178
             t_h1[s] = (d1_t < a1_t || (d1_t == a1_t && d1_l < a1_l)) ? d1_t : a1_t;
@@ -2482,17 +2553,20 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         double lat = 0.0, inc = 0.0;
         PCC_TL_STAMP(7)  // state write-back
         if (acked[s] > 0 && !prof_skip(D, 1))
-            rtt_means(g, ra[s], amask[s], from[s], acked[s], NOISE ? 0.0 : dl, need_halves, lat, inc);  // noise: the samples are whole RTTs
+            rtt_means<G>(g, ra[s], amask[s], from[s], acked[s], NOISE ? 0.0 : dl, need_halves, lat, inc);  // noise: the samples are whole RTTs
         PCC_TL_STAMP(8)  // RTT means
         // everything the rest of the MI reads, in one batch of loads (one round trip, not five)
         float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
         const int keep = D.HF - D.F;
-        const bool small_hist = D.HF <= 2 * kGroup;  // the usual 10 x 3: two passes of 16 lanes
-        float old_row[2] = {0.f, 0.f};                // the history entries this lane rolls down
+        constexpr int kRows = 32 / G;                  // passes of G lanes over the usual 10 x 3 history
+        const bool small_hist = D.HF <= kRows * G;
+        float old_row[kRows];                          // the history entries this lane rolls down
+#pragma unroll
+        for (int b = 0; b < kRows; b++) old_row[b] = 0.f;
         if (small_hist) {
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const int x = b * kGroup + (int)g.lane;
+            for (int b = 0; b < kRows; b++) {
+                const int x = b * G + (int)g.lane;
                 if (x < keep) old_row[b] = hist[x + D.F];
             }
         }
@@ -2508,34 +2582,63 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
              2e3 * m[PCC_M_LOSS_RATIO]) * kRewardScale;
         if (s == 0 && m[PCC_M_AVG_LATENCY] > 0.0) new_run_dur = 0.5 * m[PCC_M_AVG_LATENCY];  // ns:437-438
 
-        // history roll (so:64-66) + observation (ns:400-404, so:68-73), 16 lanes wide
+        // history roll (so:64-66) + observation (ns:400-404, so:68-73), G lanes wide
         float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
-        // the new MI's features: feature f lands in entry keep + f, i.e. in lane (keep + f) % 16 of
-        // one pass.  The ids are wave-uniform (kernel arguments), so each value is picked with scalar
-        // compares and divided only when its scale is not 1 (so:193-206: the two rates)
-        float new_feat = 0.f;
+        // the new MI's features: feature f lands in entry keep + f, i.e. in lane (keep + f) % G of one pass
+        // (features 0..G-1 in nf0, G..2G-1 in nf1: at most 16 features).  The ids are wave-uniform (kernel arguments):
+        // a scalar switch picks each value, divided only when its scale is not 1 (so:193-206: the two rates)
+        float nf0 = 0.f, nf1 = 0.f;
         for (int f = 0; f < D.F; f++) {
             const int id = D.fid[f];
-            double val = m[0];
-#pragma unroll
-            for (int q = 1; q < PCC_N_METRICS; q++) val = (id == q) ? m[q] : val;
-            if (id == PCC_M_SEND_RATE || id == PCC_M_RECV_RATE) val = val / 1e7;
-            if (((keep + f) & (kGroup - 1)) == (int)g.lane) new_feat = (float)val;
+            double val;
+            switch (id) {
+                case 0: val = m[0] / 1e7; break;
+                case 1: val = m[1] / 1e7; break;
+                case 2: val = m[2]; break;
+                case 3: val = m[3]; break;
+                case 4: val = m[4]; break;
+                case 5: val = m[5]; break;
+                case 6: val = m[6]; break;
+                case 7: val = m[7]; break;
+                case 8: val = m[8]; break;
+                case 9: val = m[9]; break;
+                case 10: val = m[10]; break;
+                default: val = m[11]; break;
+            }
+            static_assert(PCC_M_SEND_RATE == 0 && PCC_M_RECV_RATE == 1 && PCC_N_METRICS == 12, "the switch above");
+            if (((keep + f) & (G - 1)) == (int)g.lane) { if (f < G) nf0 = (float)val; else nf1 = (float)val; }
         }
         // an env that finishes its episode here and restarts (see the end of this function) shows the first observation
         // of its next episode: the all-empty history (so:57-62; every metric of an empty MI is 0 but the two ratios)
         const bool restarts = restart && steps + 1 >= D.max_steps;
-        for (int base = 0; base < D.HF && !prof_skip(D, 2); base += kGroup) {
-            const int x = base + (int)g.lane;
-            float v = new_feat;  // x in [keep, HF): F <= 16, so a lane owns at most one feature entry
-            if (x < keep) v = small_hist ? (base ? old_row[1] : old_row[0]) : hist[x + D.F];
-            if (x < D.HF) {
-                hist[x] = v;
-                if (restarts) {
-                    const int id = D.fid[x % D.F];
-                    v = (float)(((id == PCC_M_SEND_RATIO || id == PCC_M_LATENCY_RATIO) ? 1.0 : 0.0) / c_metric_scale[id]);
+        if (small_hist) {
+#pragma unroll
+            for (int b = 0; b < kRows; b++) {
+                const int x = b * G + (int)g.lane;
+                float v = (x - keep) < G ? nf0 : nf1;
+                if (x < keep) v = old_row[b];
+                if (x < D.HF && !prof_skip(D, 2)) {
+                    hist[x] = v;
+                    if (restarts) {
+                        const int id = D.fid[x % D.F];
+                        v = (float)(((id == PCC_M_SEND_RATIO || id == PCC_M_LATENCY_RATIO) ? 1.0 : 0.0) / c_metric_scale[id]);
+                    }
+                    if (obs) obs[x] = v;
                 }
-                if (obs) obs[x] = v;
+            }
+        } else {
+            for (int base = 0; base < D.HF && !prof_skip(D, 2); base += G) {
+                const int x = base + (int)g.lane;
+                float v = (x - keep) < G ? nf0 : nf1;
+                if (x < keep) v = hist[x + D.F];
+                if (x < D.HF) {
+                    hist[x] = v;
+                    if (restarts) {
+                        const int id = D.fid[x % D.F];
+                        v = (float)(((id == PCC_M_SEND_RATIO || id == PCC_M_LATENCY_RATIO) ? 1.0 : 0.0) / c_metric_scale[id]);
+                    }
+                    if (obs) obs[x] = v;
+                }
             }
         }
         PCC_TL_STAMP(10)  // history + observation
@@ -2546,8 +2649,12 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             if (steps + 1 >= D.max_steps) D.snd[k].last_return = ret;
             if (reward_out) reward_out[i * NS + s] = (float)reward;
         }
-        if (steps_out && g.lane < PCC_N_METRICS)
-            steps_out[(i * NS + s) * PCC_STEP_COLS + PCC_COL_METRIC0 + g.lane] = select_metric(m, (int)g.lane);
+        if (steps_out) {
+#pragma unroll
+            for (int mb = 0; mb < PCC_N_METRICS; mb += G)
+                if (mb + (int)g.lane < PCC_N_METRICS)
+                    steps_out[(i * NS + s) * PCC_STEP_COLS + PCC_COL_METRIC0 + mb + g.lane] = select_metric(m, mb + (int)g.lane);
+        }
         if (steps_out && lead) {
             double *row = steps_out + (i * NS + s) * PCC_STEP_COLS;
             row[PCC_COL_SENT] = (double)sent[s];
@@ -2779,11 +2886,11 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // records and state just written are read by other lanes
                     const int64_t i0 = (int64_t)__builtin_amdgcn_readfirstlane((int)i) |
                                        ((int64_t)__builtin_amdgcn_readfirstlane((int)(i >> 32)) << 32);
-                    if (lane < (uint32_t)kGroup) {
+                    if (lane < 8u) {
                         Group g;
                         g.lane = lane; g.shift = 0;
-                        (void)retire_env<NS, false>(D, i0, g, 1, (uint32_t)pass, pass == 1, 0, nullptr, nullptr, nullptr, nullptr,
-                                                    nullptr, 0);
+                        (void)retire_env<NS, false, 8>(D, i0, g, 1, (uint32_t)pass, pass == 1, 0, nullptr, nullptr, nullptr, nullptr,
+                                                       nullptr, 0);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 }
@@ -2797,28 +2904,29 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
 
 // Order: with work lists (read_buf >= 0) the launch walks the classes the send half of this step
 // read, longest first -- the acks an env retires now are about the packets predicted for it -- so
-// that the four envs of a wavefront carry similar work and the launch ends with its shortest envs.
-// Without lists: index order.
+// that the envs of a wavefront carry similar work and the launch ends with its shortest envs.
+// The classes from `cls_wide` up (long RTT lists: the sums are many leaves) go 16 lanes per env, 8 envs per
+// workgroup; everybody else 8 lanes per env, 16 per workgroup (see "retire_kernel" above).  Without lists: index
+// order, 8 lanes per env.
 // Filing: every wavefront leaves its envs' classes in LDS and goes; the last one of the workgroup to
-// arrive files all 16 (one global atomic per class present) -- no barrier at the end, so a wavefront's
+// arrive files all of them (one global atomic per class present) -- no barrier at the end, so a wavefront's
 // registers are free for the next workgroup as soon as ITS envs are done.
+constexpr int kRetireMaxPerBlock = kRetireBlock / 8;  // envs of a workgroup at 8 lanes per env
+
 template <int NS, bool NOISE>
 __global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(Dev D, int read_buf, int fill_buf, int warm,
                                                               uint32_t warm_mi, int last_warm, int gate, int restart, float *obs_out,
                                                               float *reward_out, uint8_t *done_out, double *steps_out,
                                                               const void *actions, int actions_f64) {
     if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-    constexpr int kPerBlock = kRetireBlock / kGroup;
-    __shared__ uint32_t s_env[kPerBlock], s_cls[kPerBlock], s_arrived;
+    __shared__ uint32_t s_env[kRetireMaxPerBlock], s_cls[kRetireMaxPerBlock], s_arrived;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     if (tid == 0) s_arrived = 0u;
+    if (tid < (uint32_t)kRetireMaxPerBlock) s_env[tid] = 0xFFFFFFFFu;
     __syncthreads();  // the workgroup's wavefronts start together: this one is free
-    Group g;
-    g.lane = tid & (kGroup - 1);
-    g.shift = lane & ~(uint32_t)(kGroup - 1);
-    const int64_t pos = (int64_t)blockIdx.x * kPerBlock + (tid / kGroup);
-    int64_t i = pos;
+    int64_t i = D.n;   // (beyond the envs: nothing)
+    bool wide = false;  // this workgroup: 16 lanes per env
     if (read_buf >= 0) {
         // lane l < kClasses looks after class kClasses-1-l, lane kClasses after the restart list (envs that were reset
         // by the retire launch before this one: last); inclusive prefix of the counts in that order
@@ -2830,37 +2938,71 @@ __global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(De
             if (lane >= (uint32_t)o) incl += up;
         }
         const uint32_t total = rl_u32(incl, kClasses);
-        i = D.n;  // beyond the lists: nothing
-#pragma unroll
-        for (uint32_t grp = 0; grp < kWave / kGroup; grp++) {
-            const uint32_t p = (uint32_t)((int64_t)blockIdx.x * kPerBlock + (tid / kWave) * (kWave / kGroup) + grp);
-            const uint64_t above = __ballot(lane <= (uint32_t)kClasses && incl > p);
-            if (p < total) {  // wave-uniform
-                const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
-                const uint32_t row = L < (uint32_t)kClasses ? (uint32_t)(kClasses - 1) - L : (uint32_t)kRestart;
-                const uint32_t off = p - (rl_u32(incl, L) - rl_u32(n_mine, L));
-                const uint32_t e = D.cls_list[((size_t)read_buf * kListRows + row) * (size_t)D.n + off];
-                if (lane / kGroup == grp) i = (int64_t)e;
-            }
+        const int cls_wide = NOISE ? kClasses : (D.retire_wide_predict >= 1e9f ? kClasses : class_of(D.retire_wide_predict));
+        const uint32_t n_top = cls_wide < kClasses ? rl_u32(incl, (uint32_t)(kClasses - 1 - cls_wide)) : 0u;  // envs of the wide classes
+        const uint32_t wg_wide = (n_top + 7u) / 8u;  // workgroups that take them, 8 each
+        wide = blockIdx.x < wg_wide;
+        uint32_t p;  // this lane's position in the walk (the same for the lanes of a group)
+        bool has;
+        if (wide) {
+            p = blockIdx.x * 8u + tid / 16u;
+            has = p < n_top;
+        } else {
+            p = n_top + (blockIdx.x - wg_wide) * 16u + tid / 8u;
+            has = p < total;
         }
+        // the row whose inclusive prefix first exceeds p: binary search over lanes 0..kClasses (33 values)
+        uint32_t lo_l = 0, hi_l = (uint32_t)kClasses;  // answer in [lo_l, hi_l]
+        for (int it = 0; it < 6; it++) {
+            const uint32_t mid = (lo_l + hi_l) >> 1;
+            const uint32_t v = (uint32_t)__shfl((int)incl, (int)mid);
+            if (lo_l < hi_l) { if (v > p) hi_l = mid; else lo_l = mid + 1u; }
+        }
+        const uint32_t L = lo_l;
+        const uint32_t inc_L = (uint32_t)__shfl((int)incl, (int)L), n_L = (uint32_t)__shfl((int)n_mine, (int)L);
+        if (has) {
+            const uint32_t row = L < (uint32_t)kClasses ? (uint32_t)(kClasses - 1) - L : (uint32_t)kRestart;
+            const uint32_t off = p - (inc_L - n_L);
+            i = (int64_t)D.cls_list[((size_t)read_buf * kListRows + row) * (size_t)D.n + off];
+        }
+    } else {
+        i = (int64_t)blockIdx.x * kRetireMaxPerBlock + tid / 8u;
     }
     float pred = -1.0f;
-    if (i < D.n)
-        pred = retire_env<NS, NOISE>(D, i, g, warm, warm_mi, last_warm, restart, obs_out, reward_out, done_out, steps_out,
-                                     actions, actions_f64);
+    Group g;
+    uint32_t slot;  // the env's slot in the workgroup's filing table
+    bool glead;
+    if (wide) {  // (workgroup-uniform)
+        g.lane = tid & 15u;
+        g.shift = lane & ~15u;
+        slot = tid / 16u;
+        glead = g.lane == 0;
+        if (i < D.n)
+            pred = retire_env<NS, NOISE, 16>(D, i, g, warm, warm_mi, last_warm, restart, obs_out, reward_out, done_out, steps_out,
+                                             actions, actions_f64);
+    } else {
+        g.lane = tid & 7u;
+        g.shift = lane & ~7u;
+        slot = tid / 8u;
+        glead = g.lane == 0;
+        if (i < D.n)
+            pred = retire_env<NS, NOISE, 8>(D, i, g, warm, warm_mi, last_warm, restart, obs_out, reward_out, done_out, steps_out,
+                                            actions, actions_f64);
+    }
     if (fill_buf < 0) return;  // warm-up intervals do not file (kernel-uniform)
     // ---- file the workgroup's envs in the class lists of the next send (see "work lists")
-    if (g.lane == 0) {
-        const bool restart = pred == -2.0f;  // reset inside retire_env: its warm-up intervals come first in the next send
+    if (glead) {
+        const bool restarted = pred == -2.0f;  // reset inside retire_env: its warm-up intervals come first in the next send
         // every env that was stepped is filed (-1 = warm-up / no env); a prediction that is not a number goes to class 0
-        s_env[tid / kGroup] = (pred != -1.0f) ? (uint32_t)i : 0xFFFFFFFFu;
-        s_cls[tid / kGroup] = restart ? (uint32_t)kRestart : (uint32_t)class_of(pred);
+        s_env[slot] = (pred != -1.0f) ? (uint32_t)i : 0xFFFFFFFFu;
+        s_cls[slot] = restarted ? (uint32_t)kRestart : (uint32_t)class_of(pred);
     }
     __threadfence_block();
     uint32_t before = 0u;
     if (lane == 0) before = atomicAdd(&s_arrived, 1u);
     before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
     if (before != kRetireBlock / kWave - 1) return;
+    constexpr int kPerBlock = kRetireMaxPerBlock;
     const uint32_t e = lane < (uint32_t)kPerBlock ? s_env[lane & (kPerBlock - 1)] : 0xFFFFFFFFu;
     const uint32_t c = lane < (uint32_t)kPerBlock ? s_cls[lane & (kPerBlock - 1)] : 0xFFFFFFFFu;
     const bool files = e != 0xFFFFFFFFu;
@@ -3013,10 +3155,12 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
 int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, int restart, float *obs_out,
                   float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
     const Dev &d = sim->d;
-    const int64_t per_block = kRetireBlock / kGroup;
-    const dim3 grid((unsigned)((d.n + per_block - 1) / per_block));
-    const int fill = warm ? -1 : sim->fill_buf;
+    // workgroups: 8 envs each at 16 lanes per env, 16 at 8 lanes -- which envs go which way is decided on the device
+    // (class counts), so the grid covers the worst case plus the one workgroup the split can leave partly filled
     const int read = (warm || !d.retire_sorted) ? -1 : sim->read_buf;  // the lists this step's send launch read
+    const int64_t per_block = read >= 0 ? 8 : kRetireMaxPerBlock;
+    const dim3 grid((unsigned)((d.n + per_block - 1) / per_block + (read >= 0 ? 1 : 0)));
+    const int fill = warm ? -1 : sim->fill_buf;
     if (d.ns == 1)
         hipLaunchKernelGGL((retire_kernel<1, false>), grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm,
                            gate, restart, obs_out, reward_out, done_out, steps_out, nullptr, 0);
@@ -3039,7 +3183,7 @@ int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gat
         // the latency-noise option: the whole interval is one launch of the retire kernel's NOISE build (no send half,
         // no work lists)
         const Dev &d = sim->d;
-        const int64_t per_block = kRetireBlock / kGroup;
+        const int64_t per_block = kRetireMaxPerBlock;
         const dim3 grid((unsigned)((d.n + per_block - 1) / per_block));
         hipLaunchKernelGGL((retire_kernel<1, true>), grid, dim3(kRetireBlock), 0, st, d, -1, -1, warm, warm_mi, last_warm, gate,
                            0, obs_out, reward_out, done_out, steps_out, actions, actions_f64);
@@ -3142,6 +3286,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.heavy_predict = 512.0;
     d.team_predict = 4096.0;
     d.heavy_item_packets = 2048.0f;
+    d.retire_wide_predict = 1024.0f;
     d.send_wg_waves = getenv("PCC_SEND_WG_WAVES") ? (uint32_t)atoi(getenv("PCC_SEND_WG_WAVES")) : 4u;
     if (d.send_wg_waves < 1u || d.send_wg_waves > 4u) d.send_wg_waves = 4u;
     d.retire_sorted = getenv("PCC_RETIRE_SORTED") ? (uint32_t)atoi(getenv("PCC_RETIRE_SORTED")) : 1u;
@@ -3240,7 +3385,7 @@ int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words) {
     if (hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(&items, sim->d.pass_stats + 15, sizeof items, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(PCC_EHIP, "reading the debug timeline failed");
-    const int64_t rblocks = (sim->d.n + kRetireBlock / kGroup - 1) / (kRetireBlock / kGroup);
+    const int64_t rblocks = (sim->d.n + 7) / 8 + 1;  // (the largest retire grid)
     const int64_t total = (int64_t)items * 8 + rblocks * 16;
     if (!out || n_words <= 0) return total;
     if (n_words < total) return fail(PCC_EINVAL, "pcc_debug_timeline needs room for %lld words", (long long)total);
@@ -3338,6 +3483,10 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             return PCC_OK;
         case PCC_TUNE_HEAVY_PREDICT: sim->d.heavy_predict = value; return PCC_OK;
         case PCC_TUNE_TEAM_PREDICT: sim->d.team_predict = value; return PCC_OK;
+        case PCC_TUNE_RETIRE_WIDE_PREDICT:
+            if (!(value >= 0.0)) return fail(PCC_EINVAL, "retire_wide_predict out of range");
+            sim->d.retire_wide_predict = value >= 1e9 ? 1e9f : (float)value;
+            return PCC_OK;
         case PCC_TUNE_HEAVY_ITEM_PACKETS:
             if (!(value >= 0.0 && value <= 1e9)) return fail(PCC_EINVAL, "heavy_item_packets out of range");
             sim->d.heavy_item_packets = (float)value;

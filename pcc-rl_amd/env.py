@@ -168,10 +168,10 @@ class BatchedNetworkEnv(object):
         self._trace = t
 
     def set_tuning(self, round_packets=None, takeover_lanes=None, send_envs_per_wave=None, heavy_predict=None,
-                   send_waves=None, team_predict=None, heavy_item_packets=None):
+                   send_waves=None, team_predict=None, heavy_item_packets=None, retire_wide_predict=None):
         """Performance knobs of the send half (results do not depend on them); see pcc_set_tuning."""
         for key, value in ((2, round_packets), (3, takeover_lanes), (4, send_envs_per_wave), (5, heavy_predict),
-                           (8, send_waves), (9, team_predict), (10, heavy_item_packets)):
+                           (8, send_waves), (9, team_predict), (10, heavy_item_packets), (11, retire_wide_predict)):
             if value is not None:
                 check(self._L.pcc_set_tuning(self._h, key, float(value)))
 

@@ -240,6 +240,9 @@ def test_old_gym_adapter_drop_in():
     dict(heavy_predict=16.0, team_predict=100.0, round_packets=16),   # lane rounds, wave passes and team passes side by side
     dict(team_predict=1e18),                                     # no team items: the giants on one wavefront
     dict(heavy_predict=64.0, team_predict=64.0, send_waves=1),   # more team items than team workgroups
+    dict(retire_wide_predict=0.0),                               # retire half: every env by 16 lanes
+    dict(retire_wide_predict=1e18),                              # ... every env by 8 lanes (the giants' three sums in a row)
+    dict(retire_wide_predict=40.0, heavy_predict=64.0),          # ... both kinds of workgroup, many of each
     dict(heavy_predict=32.0, heavy_item_packets=0.0),            # one env per wave-path item
     dict(heavy_predict=32.0, heavy_item_packets=1e6, team_predict=1e18),   # eight envs per wave-path item
 ])
@@ -266,6 +269,8 @@ def test_send_paths_are_exact_whatever_the_tuning(knobs):
     dict(takeover_lanes=64, round_packets=8),            # merge-path wave passes for almost everything
     dict(takeover_lanes=64, round_packets=4, heavy_predict=200.0),
     dict(heavy_predict=100.0, send_waves=2),
+    dict(retire_wide_predict=0.0),
+    dict(retire_wide_predict=1e18),
 ])
 def test_two_sender_philox_batches_match_oracle(knobs):
     """BASELINE.json configs[4] shape (two senders on one link) at a size the oracle finishes in
