@@ -13,8 +13,15 @@ collective inside the step; episode returns are all-gathered over RCCL when epis
 
 Protocol: W warm-up steps, then K timed steps between barrier +
 synchronize, repeated `--repeats` times back to back; the line reports the MEDIAN run, every run's
-ms/step, and which steps of the 400-step episode each run covered (`window`) -- the packet count per
-step grows over an episode, so a short window early in the episode is lighter than the average.
+ms/step, and which steps of the 400-step episode each run covered (`window`).  The packet count per
+step grows over an episode (about 120 early, 180 on average, 230 late), so WHERE a window shorter than
+an episode sits decides what it measures: when K < 400 the script first runs one whole untimed-for-`value`
+episode with per-step HIP events (reported as `whole_episode`: the section-8d metric), then places the K timed
+steps -- after an untimed pre-roll -- on the stretch of the episode whose mean step time is closest to the
+episode's mean, so that `value` estimates the whole-episode rate; `roofline` is computed from the whole episode.
+
+`--config 2|3|5` picks the BASELINE.json configuration (default 3 = the one the metric is quoted on): 2 = 4 096 envs
+on the fixed link (bw 200, 0.03 s, queue 5, no loss, rate0 60), 5 = 32 768 envs x 2 senders.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md section 6 for the fields).
 """
@@ -119,11 +126,19 @@ def cpu_baseline(seconds_budget=15.0):
             outs.append([0, 0, 1])
     wall = time.perf_counter() - t0
     per_core = [o[0] / o[2] for o in outs if o[0] > 0]
+    # ... and ONE process with the machine to itself (every core busy halves what a core does: SMT siblings, memory)
+    try:
+        alone = json.loads(subprocess.run([sys.executable, "-c", code, "7777"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                          timeout=60).stdout.decode() or "[0,0,1]")
+    except (ValueError, subprocess.TimeoutExpired):
+        alone = [0, 0, 1]
     if per_core:
         agg = sum(o[0] for o in outs) / wall
         res["python_port"] = {"value": agg, "unit": "env steps/s", "cores": len(per_core),
                               "per_core": sum(per_core) / len(per_core),
                               "vs_reference_per_core": (sum(per_core) / len(per_core)) / REFERENCE_STEPS_PER_S_PER_CORE,
+                              "one_process_alone": alone[0] / alone[2],
+                              "one_process_alone_vs_reference": (alone[0] / alone[2]) / REFERENCE_STEPS_PER_S_PER_CORE,
                               "sample": "one process per core, %d processes x >= 10 s of 200-step default-parameter episodes "
                                         "(oracle/pcc_oracle_py.py: heapq + numpy, %.1f packets/step), %.1f s wall; the unmodified "
                                         "reference measured %.0f steps/s/core in the build container (SURVEY.md section 6)"
@@ -166,7 +181,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2000, help="timed steps per run (5 episodes by default)")
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=3, help="timed runs, back to back; the line reports the median")
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the configuration's size)")
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 5),
+                    help="BASELINE.json configuration: 3 (default) = 65 536 envs, randomized links, 1 sender; 2 = 4 096 envs on the "
+                         "fixed link; 5 = 32 768 envs x 2 senders on one bottleneck")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
@@ -204,12 +222,20 @@ def main():
         import torch.distributed as dist
         pdist.init_process_group(args.backend, device=dev)   # "nccl" is RCCL on ROCm
 
-    N, K, W, R = args.envs, args.steps, args.warmup, max(1, args.repeats)
-    env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, env_gid_base=pdist.env_gid_base(rank, N),
+    cfg = args.config
+    N = args.envs or {2: 4096, 3: 65536, 5: 32768}[cfg]
+    S = 2 if cfg == 5 else 1
+    K, W, R = args.steps, args.warmup, max(1, args.repeats)
+    env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, env_gid_base=pdist.env_gid_base(rank, N), n_senders=S,
+                                       link_params=(200.0, 0.03, 5.0, 0.0, 60.0) if cfg == 2 else None,   # ns:459-464
                                        auto_reset=True, ring_capacity=args.ring_capacity, max_steps=args.max_steps)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    pool = 64
-    actions = torch.rand((pool, N), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
+    # one action vector per step of an episode (fresh U(-1, 1) actions every step), generated before the timed
+    # region.  (A short pool is not harmless: cycled, it gives every env the same net rate change each cycle, the rates
+    # drift to their limits and the cost of a step depends on the phase of the cycle -- 0.116 to 0.161 ms per send
+    # launch for a pool of 64, profiles/r03_experiments.json.)
+    pool = args.max_steps
+    actions = torch.rand((pool, N, S), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
     env.reset()
     max_steps = env.max_steps
     if args.stagger:
@@ -238,15 +264,60 @@ def main():
             returns_gathered += 1
 
     t_global = 0
+    whole = None
+    if K < max_steps and not args.stagger:
+        # ---- one whole episode first (the section-8d metric), per-step HIP events: where in the episode do K steps
+        # take the episode-mean time per step?  (All ranks do the same work; rank 0's times place the window.)
+        # (episodes differ -- a handful of envs whose queue limit sits just above a power of two send on the slow exact
+        # path and can be a launch's critical path: 0.113 / 0.150 / 0.125 ms per send launch for the first three episodes of
+        # seed 0 -- so the figure is taken over kWhole episodes)
+        kWhole = 3
+        sent0 = env.state("total_sent").sum()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(kWhole * max_steps)]
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for k in range(kWhole * max_steps):
+            one_step(t_global, evs[k])
+            t_global += 1
+        torch.cuda.synchronize()
+        el = time.perf_counter() - c0
+        fold = lambda f: [sum(f(e * max_steps + k) for e in range(kWhole)) / kWhole for k in range(max_steps)]   # mean over the episodes, by step
+        send_t = fold(lambda k: evs[k][0].elapsed_time(evs[k][1]))
+        ret_t = fold(lambda k: evs[k][1].elapsed_time(evs[k][2]))
+        step_t = [a + b for a, b in zip(send_t, ret_t)]
+        mean_t = sum(step_t[:-1]) / (max_steps - 1)            # (the last step also runs the episode-boundary reset)
+        span = W + K
+        best, best_err = 0, None
+        csum = [0.0]
+        for v in step_t:
+            csum.append(csum[-1] + v)
+        for st in range(0, max_steps - span):
+            err = abs((csum[st + span] - csum[st + W]) / K - mean_t)
+            if best_err is None or err < best_err:
+                best, best_err = st, err
+        whole = {"ms_per_step": 1e3 * el / (kWhole * max_steps), "value": world * N * kWhole * max_steps / el, "episodes": kWhole,
+                 "send_ms": sum(send_t) / max_steps, "retire_ms": sum(ret_t[:-1]) / (max_steps - 1),
+                 "packets_per_env_step": float((env.state("total_sent").sum() - sent0).item()) / (N * kWhole * max_steps),
+                 "window_start": best}
+        if world > 1:   # every rank must pre-roll alike
+            b = torch.tensor([best], device=dev)
+            dist.broadcast(b, 0)
+            best = int(b.item())
+        for _ in range(best):                                   # untimed pre-roll to the chosen stretch of the next episode
+            one_step(t_global)
+            t_global += 1
     for _ in range(W):
         one_step(t_global)
         t_global += 1
 
     runs = []
+    # HIP events on the launch stream (torch's current stream IS the stream the library launches on); all of them are
+    # made before the first run and the packet counters stay on the device until the last one is over, so that the GPU
+    # does not sit idle (and clock down) between the warm-up steps and a timed region that may be only a few ms long
+    all_ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)] for _ in range(R)]
+    sent_marks = [env.state("total_sent").sum()]
     for r in range(R):
-        sent0 = env.state("total_sent").sum()
-        # HIP events on the launch stream (torch's current stream IS the stream the library launches on)
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+        ev = all_ev[r]
         first = t_global
         if world > 1:
             dist.barrier()
@@ -258,13 +329,18 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)     # MAX over ranks (bench contract)
-        packets = float((env.state("total_sent").sum() - sent0).item())
+        elapsed = time.perf_counter() - t0
+        sent_marks.append(env.state("total_sent").sum())
+        runs.append({"elapsed": elapsed, "first_step": first})
+    for r in range(R):
+        ev, first = all_ev[r], runs[r]["first_step"]
+        runs[r]["elapsed"] = pdist.max_over_ranks(runs[r]["elapsed"], device=dev)     # MAX over ranks (bench contract)
+        runs[r]["packets"] = float((sent_marks[r + 1] - sent_marks[r]).item())
         # steps that also ran the episode-boundary reset kernels are kept out of the retire average
         plain = [k for k in range(K) if (first + k + 1) % max_steps != 0] if not args.stagger else list(range(K))
-        runs.append({"elapsed": elapsed, "packets": packets, "first_step": first,
-                     "send_ms": sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K,
-                     "retire_ms": sum(ev[k][1].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))})
+        runs[r]["send_ms"] = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
+        runs[r]["retire_ms"] = sum(ev[k][1].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))
+        runs[r]["first_steps_ms"] = [ev[k][0].elapsed_time(ev[k][2]) for k in range(min(K, 6))]
     if not os.environ.get("PCC_BENCH_IGNORE_FLAGS"):   # experiments only: an overflowed ring means invalid results
         env.check_flags()
     env.close()
@@ -274,9 +350,16 @@ def main():
         med = runs[order[R // 2]]
         value = world * N * K / med["elapsed"]
         pk_per_step = med["packets"] / (N * K)
-        send_bytes = N * (B_FIXED_SEND + B_PACKET_HALF * pk_per_step)
-        retire_bytes = N * (B_FIXED_RETIRE + B_PACKET_HALF * pk_per_step)
         send_ms, retire_ms = med["send_ms"], med["retire_ms"]
+        roof_src = "the timed steps"
+        if whole is not None:   # the roofline of a short run is the whole episode's (the timed window is K steps of it)
+            pk_roof, send_ms, retire_ms = whole["packets_per_env_step"], whole["send_ms"], whole["retire_ms"]
+            roof_src = "the whole episodes run before the timed steps (whole_episode)"
+        else:
+            pk_roof = pk_per_step
+        # (two senders: the fixed bytes of section 8d once per sender)
+        send_bytes = N * (B_FIXED_SEND * S + B_PACKET_HALF * pk_roof)
+        retire_bytes = N * (B_FIXED_RETIRE * S + B_PACKET_HALF * pk_roof)
         if args.stagger:
             window = {"episode_steps": "all phases at once (--stagger): every step sees the episode-average load"}
         else:
@@ -285,38 +368,48 @@ def main():
                       "first_step_of_episode": f, "steps": K,
                       "covers_whole_episodes": K % max_steps == 0,
                       "note": None if K >= max_steps else
-                      "steps < one 400-step episode: packets per step grow over an episode (about 120 early, 180 on "
-                      "average), so this window is lighter than the episode average"}
+                      "steps < one 400-step episode: packets per step grow over an episode (about 120 early, 180 on average, "
+                      "230 late); the window was placed (untimed pre-roll) where a whole episode run just before had its mean "
+                      "step time within %d steps -- `whole_episode` is that episode's own figure" % (W + K)}
         out = {
             "metric": "env steps/sec (whole node) at 64k parallel envs",
             "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * med["elapsed"] / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": R, "runs_ms_per_step": [1e3 * r["elapsed"] / K for r in runs],
+            "median_run_kernel_ms": {"send": med["send_ms"], "retire": med["retire_ms"], "first_steps": med["first_steps_ms"]},
             "spread": (max(r["elapsed"] for r in runs) - min(r["elapsed"] for r in runs)) / med["elapsed"],
             "window": window,
-            "config": {"workload": "%d envs/GPU, 1 sender, per-env randomized bw/latency/queue/loss "
-                                   "(ICML'19 ranges), U(-1,1) actions, 400-step episodes, auto-reset%s"
-                                   % (N, ", episode phases staggered" if args.stagger else ""),
-                       "envs_per_gpu": N, "packets_per_env_step": pk_per_step,
+            "config": {"workload": ("BASELINE config %d: %d envs/GPU, %s, U(-1,1) actions, 400-step episodes, auto-reset%s"
+                                    % (cfg, N, {2: "1 sender, fixed link (bw 200 pkt/s, 0.03 s, queue 5, no loss, rate0 60)",
+                                                3: "1 sender, per-env randomized bw/latency/queue/loss (ICML'19 ranges)",
+                                                5: "2 senders on one bottleneck, per-env randomized links (ICML'19 ranges)"}[cfg],
+                                       ", episode phases staggered" if args.stagger else "")),
+                       "baseline_config": cfg, "envs_per_gpu": N, "senders": S, "packets_per_env_step": pk_per_step,
                        "episode_return_allgathers": returns_gathered},
         }
+        if whole is not None:
+            out["whole_episode"] = dict(whole, unit="env steps/s", steps=whole["episodes"] * max_steps,
+                                        note="%d whole %d-step episodes run before the timed steps (per-step HIP events on the "
+                                             "launch stream): the section-8d metric; `value` is the K-step window placed at "
+                                             "episode step window_start + warmup of the next episode" % (whole["episodes"], max_steps))
         send_gbps = send_bytes / (send_ms * 1e-3) / 1e9
         retire_gbps = retire_bytes / (retire_ms * 1e-3) / 1e9
         both = (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "send_kernel<1, false, false>", "achieved": send_gbps,
+        out["roofline"] = {"bound": "hbm", "kernel": "send_kernel<%d, false, false>" % S, "achieved": send_gbps,
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": send_gbps / HBM_PEAK_GBPS,
                            "traffic": None, "kernel_ms": send_ms, "algorithmic_bytes_per_launch": send_bytes,
-                           "other_kernels": [{"kernel": "retire_kernel<1, false>", "achieved": retire_gbps,
+                           "measured_over": roof_src,
+                           "other_kernels": [{"kernel": "retire_kernel<%d, false>" % S, "achieved": retire_gbps,
                                               "frac": retire_gbps / HBM_PEAK_GBPS, "kernel_ms": retire_ms,
                                               "algorithmic_bytes_per_launch": retire_bytes}],
                            "whole_step": {"achieved": both, "frac": both / HBM_PEAK_GBPS}}
         pmc, src = pmc_traffic()
         kname = out["roofline"]["kernel"]
-        if pmc and N == 65536 and kname in pmc and pmc[kname].get("launches", 0) >= 50:
+        if pmc and N == 65536 and cfg == 3 and kname in pmc and pmc[kname].get("launches", 0) >= 50:
             out["roofline"]["traffic"] = pmc[kname].get("hbm_bytes_per_launch", pmc[kname]["hbm_bytes_per_launch_raw"])
             out["roofline"]["traffic_source"] = (src + ": 2 x FETCH_SIZE + WRITE_SIZE (KB units x 1024; the factor 2 is this repo's calibration, profiles/r02_pmc_calibration.json) of a SEPARATE profiled run "
-                                                 "of this script over " + str(pmc.get("_window", "steps 20..120 of an episode")) +
+                                                 "of this script (code at commit " + str(pmc.get("_commit", "?")) + ") over " + str(pmc.get("_window", "steps 20..120 of an episode")) +
                                                  "; compare it with that window's algorithmic bytes (in the profile), not this run's")
             for other in out["roofline"].get("other_kernels", []):
                 if other["kernel"] in pmc and pmc[other["kernel"]].get("launches", 0) >= 50:

@@ -94,7 +94,7 @@ enum {
 #define PCC_FLAG_RING_OVERFLOW 1u  /* more accepted or dropped packets in flight than ring_capacity: results invalid */
 #define PCC_FLAG_TRACE_OVERRUN 2u  /* PCC_RNG_TRACE ran past trace_stride */
 #define PCC_FLAG_POOL_EXHAUSTED 8u /* a sender needed a bigger ring tier and every pool from that tier up was empty (it may
-                                      then also overflow: RING_OVERFLOW); raise the pools with PCC_RING_POOLS */
+                                      then also overflow: RING_OVERFLOW); raise the pools with pcc_set_ring_pools */
 #define PCC_FLAG_INTERNAL 4u       /* reserved (a queue protocol of an earlier build; never set) */
 #define PCC_FLAG_BAD_PARAMS 16u    /* pcc_set_link_params gave this env a link outside what the exact formulation covers
                                       (bw in (0, 1e8], latency > 0, queue >= 1, loss in [0, 1], rate0 > 0 and finite):
@@ -125,8 +125,7 @@ const char *pcc_last_error(void);
  *                   default) and is moved -- at the start of a monitor interval whose packets
  *                   could overflow them -- into rings 4x, 16x, ... as large taken from shared
  *                   pools that by default hold 1/2, 1/8, 1/32 of the senders at once
- *                   (environment variable PCC_RING_POOLS="2,8,32" sets the divisors; 1 =
- *                   worst case).  An empty pool is flagged (PCC_FLAG_POOL_EXHAUSTED), never
+ *                   (pcc_set_ring_pools changes the divisors; 1 = worst case).  An empty pool is flagged (PCC_FLAG_POOL_EXHAUSTED), never
  *                   silent.  Pool rings are held until the env is reset.  The tiers are about
  *                   memory, not speed (a pointer-chase microbenchmark shows TLB reach is not what
  *                   bounds these kernels): 65 536 envs take 6.4 GB instead of 103 GB.
@@ -182,6 +181,12 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     16 lanes (whole-list and half sums side by side), the others by 8; default 1024,
                                     0 = every env by 16, >= 1e9 = every env by 8 */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
+
+/* Sizes of the shared ring pools (see pcc_create): tiers 1, 2, 3 get a slot for one sender in div1, div2, div3 (defaults
+ * 2, 8, 32, measured on U(-1, 1) policies; 1 = a slot for every sender -- what a policy that drives every env to its
+ * rate limit can need: ~100 GB for 65 536 envs at the default ring_capacity).  Reallocates the pools and synchronizes the
+ * device; whatever was in flight is dropped, so pcc_reset must follow.  No reference counterpart (its heap grows). */
+int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t div3);
 
 /* The reference's dormant engine option USE_CWND (ns:54; off in the reference): window-limited
  * sending.  A SEND event launches a packet only while fewer than cwnd packets are unacknowledged

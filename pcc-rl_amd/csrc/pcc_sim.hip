@@ -147,6 +147,7 @@ struct Dev {
     char *tier_base[kMaxTiers];
     uint32_t *tier_free[kMaxTiers];  // [tier_slots[c]] free slot ids (a stack; c >= 1)
     int32_t *tier_top;               // [kMaxTiers] stack heights
+    uint32_t tier_slots[kMaxTiers];  // slots of each pool
     uint32_t key0, key1, gid_base;
     double delta_scale;
     uint32_t max_steps;
@@ -399,6 +400,7 @@ __device__ __forceinline__ uint32_t exponent_bits(double x) { return ((uint32_t)
 struct SendState {  // wave-uniform while an env is processed by the whole wave
     double q, tu, t;
     uint32_t a, d, sent, flags;
+    uint32_t prof_closed, prof_other;  // profile build: committed closed-form passes / chain + serial passes of the env
 };
 
 // ---- pieces of the wave pass ---------------------------------------------------------------
@@ -777,6 +779,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 st.a += j_stop;
                 st.d += ncommit - j_stop;
                 st.sent += ncommit;
+                if (kProfile) st.prof_closed++;
                 serial_len = 8;
                 continue;
             }
@@ -895,6 +898,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
             st.a += (uint32_t)__popcll(am);
             st.d += (uint32_t)__popcll(dm);
             st.sent += nv;
+            if (kProfile) st.prof_other += ok_chain ? 1u : 0x10000u;  // (chain passes low, serial passes high)
             if (prof_counters(D) && lane == 0 && writer) {
                 atomicAdd(&D.pass_stats[3], 1ull);
                 atomicAdd(&D.pass_stats[7], (unsigned long long)nv);
@@ -1065,7 +1069,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
     if (!__ballot(live)) return;
     const int64_t ii = live ? i : 0;
     const uint64_t tl0 = prof_on(D) ? wall_clock64() : 0;
-    uint64_t tl1 = 0, tl_heavy = 0, tl_heavy_pk = 0;
+    uint64_t tl1 = 0, tl_heavy = 0, tl_heavy_pk = 0, tl_closed = 0, tl_other = 0, tl_env = 0;
 
     const double dl = D.env[ii].dl, lr = D.env[ii].lr, maxq = D.env[ii].maxq, ebw = D.env[ii].ebw;
     double q = D.env[ii].q, tu = D.env[ii].tu;
@@ -1292,6 +1296,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
             if (prof_counters(D) && lane == 0 && writer) atomicAdd(&D.pass_stats[heavy_wave ? 11 : 12], 1ull);
             st.q = rl_f64(q, l); st.tu = rl_f64(tu, l); st.t = rl_f64(t, l);
             st.a = rl_u32(a, l); st.d = rl_u32(d, l); st.flags = 0;
+            st.prof_closed = 0; st.prof_other = 0;
             st.sent = (st.a - rl_u32(ta[0], l)) + (st.d - rl_u32(td[0], l));  // packets of this MI already sent by the lane
             heavy_mi<TRACE, W>(D, lane, wv, X, rl_f64(dl, l), rl_f64(lr, l), rl_u32(thr, l), rl_u32(always ? 1u : 0u, l) != 0u,
                             rl_f64(maxq, l), rl_f64(ebw, l), rl_f64(gap[0], l), rl_f64(end, l), rl_u32(episode, l),
@@ -1299,6 +1304,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
                             reinterpret_cast<const double *>(rl_u64(reinterpret_cast<uint64_t>(trace), l)),
                             reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(base), l)), rl_u32(rings[0].cap, l), st);
             if (lane == l) { q = st.q; tu = st.tu; t = st.t; a = st.a; d = st.d; flags |= st.flags; }
+            if (kProfile) { tl_closed += st.prof_closed; tl_other += st.prof_other; tl_env = (uint64_t)rl_u64((uint64_t)ii, l); }
         }
         nsend[0] = t;
         sent[0] = (a - ta[0]) + (d - td[0]);
@@ -1427,7 +1433,8 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
         if (lane == 0 && writer) {
             uint64_t *w = D.timeline + (int64_t)tl_slot * 8;
             w[0] = tl0; w[1] = tl1; w[2] = wall_clock64(); w[3] = tl_heavy; w[4] = sum; w[5] = mx; w[6] = hp;
-            w[7] = (uint64_t)__popcll(__ballot(live));
+            w[7] = (uint64_t)__popcll(__ballot(live)) | (tl_closed << 8) | (tl_other << 24);  // (closed-form | chain | serial passes)
+            w[3] |= tl_env << 16;  // (the last env the wave path sent)
         }
     }
     if (!live || !writer) return;
@@ -2200,14 +2207,14 @@ __device__ __noinline__ NoiseOut noise_engine(const Dev &D, int64_t i, double st
 // The senders' ring-pool slots go back to their free stacks here (nothing is in flight any more) -- pushes
 // happen only in reset and retire launches, pops only in send launches: no stack races.
 template <int NS>
-__device__ __forceinline__ void release_ring_slots(const Dev &D, const int64_t i) {
+__device__ __forceinline__ void release_ring_slots(const Dev &D, const int64_t i, const bool push = true) {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
         for (int c = 1; c < D.n_tiers; c++) {
             const uint32_t held = D.snd[k].ring_held[c];
             if (held) {
-                D.tier_free[c][atomicAdd(&D.tier_top[c], 1)] = held - 1u;
+                if (push) D.tier_free[c][atomicAdd(&D.tier_top[c], 1)] = held - 1u;
                 D.snd[k].ring_held[c] = 0;
             }
         }
@@ -2747,24 +2754,39 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
         if (cls_mine >= cls_team) { n_team_mine = n_mine; items_mine = 0; }
         est = hv ? (float)e_mine * pk * 0.012f : 1000.0f + pk * 0.4f;  // us; the light items, all of them, go first (see below)
     }
+    // Lane kClasses holds a GAP of empty items between the light items and the wave-path envs: the light items fill up
+    // the youngest quarter of the workgroups (see the first item below), and what the ranking puts right behind them
+    // would share those CUs with four lane-round wavefronts each -- the largest wave-path envs, of all items, starved
+    // of their CU's memory pipeline (1 500-2 200-packet envs that took 140-150 us instead of 35: the whole launch).
+    // With the gap they start on the second-youngest quarter; the wavefronts left without a first item claim one.
+    {
+        uint32_t light_items = (lane < (uint32_t)kClasses && cls_mine < cls_heavy) ? items_mine : 0u;
+        for (int o = 32; o; o >>= 1) light_items += (uint32_t)__shfl_xor((int)light_items, o);
+        const uint32_t quarter = n_waves / 4u;
+        if (lane == (uint32_t)kClasses && listed && !RESTART && light_items < quarter) {
+            items_mine = quarter - light_items;
+            est = 500.0f;  // behind every light item (>= 1000), in front of every wave-path env
+        }
+    }
     uint32_t rank = 0;  // classes that go before mine
-    for (uint32_t l = 0; l < (uint32_t)kClasses; l++) {
+    for (uint32_t l = 0; l <= (uint32_t)kClasses; l++) {
         const float other = __shfl(est, (int)l);
         rank += (other > est || (other == est && l < lane)) ? 1u : 0u;
     }
     // the table lives in LDS (one copy per wavefront: no barrier needed), indexed by rank
-    __shared__ uint32_t s_tab[4][4][kClasses];
-    uint32_t (*tab)[kClasses] = s_tab[threadIdx.x / kWave];
-    if (lane < (uint32_t)kClasses) { tab[1][rank] = items_mine; tab[2][rank] = n_mine; tab[3][rank] = (uint32_t)cls_mine | (e_mine << 8); }
-    uint32_t incl = lane < (uint32_t)kClasses ? tab[1][lane] : 0u;  // inclusive prefix in rank order
-    for (int o = 1; o < kClasses; o <<= 1) {
+    constexpr int kRows = kClasses + 1;  // the classes and the gap
+    __shared__ uint32_t s_tab[4][4][kRows];
+    uint32_t (*tab)[kRows] = s_tab[threadIdx.x / kWave];
+    if (lane < (uint32_t)kRows) { tab[1][rank] = items_mine; tab[2][rank] = n_mine; tab[3][rank] = (uint32_t)(lane < (uint32_t)kClasses ? cls_mine : 0) | (e_mine << 8); }
+    uint32_t incl = lane < (uint32_t)kRows ? tab[1][lane] : 0u;  // inclusive prefix in rank order
+    for (int o = 1; o < kRows; o <<= 1) {
         const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
         if (lane >= (uint32_t)o) incl += up;
     }
-    if (lane < (uint32_t)kClasses) tab[0][lane] = incl;
+    if (lane < (uint32_t)kRows) tab[0][lane] = incl;
     // the restart list (envs the last retire launch reset: warm-up intervals first) goes in front, one env per item
     const uint32_t n_restart = (RESTART && listed) ? D.cls_count[read_buf * kClsStride + kRestart * kCntStride] : 0u;
-    const uint32_t n_items = listed ? n_restart + rl_u32(incl, kClasses - 1) : (uint32_t)((D.n + E - 1) / E);
+    const uint32_t n_items = listed ? n_restart + rl_u32(incl, kRows - 1) : (uint32_t)((D.n + E - 1) / E);
     uint32_t *cursors = D.cursors + (uint32_t)(listed ? read_buf : 2) * kShards * kCursorStride;
     // team items: lane l looks after class kClasses-1-l, so the lane order is largest class first
     uint32_t incl_team = n_team_mine;
@@ -2853,7 +2875,7 @@ __global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf,
             i = has ? (int64_t)D.cls_list[((size_t)read_buf * kListRows + kRestart) * (size_t)D.n + t] : 0;
         } else if (listed) {
             const uint32_t tc = t - n_restart;
-            const uint64_t above = __ballot(lane < (uint32_t)kClasses && tab[0][lane & (kClasses - 1)] > tc);
+            const uint64_t above = __ballot(lane < (uint32_t)kRows && tab[0][lane < (uint32_t)kRows ? lane : 0u] > tc);
             const uint32_t L = (uint32_t)__ffsll((unsigned long long)above) - 1u;
             const int cls = (int)(tab[3][L] & 0xFFu);
             const uint32_t e_cls = tab[3][L] >> 8;  // envs per item of this class
@@ -3025,16 +3047,29 @@ __global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(De
 // reset_init_kernel: ns:454-477 -- parameters, fresh link/sender/history state.  The two warm-up
 // MIs (ns:478-479) are run by send_kernel / retire_kernel in warm mode on the marked envs.
 // ======================================================================================
+// all_envs: the host knows that EVERY env is reset by this launch (a full reset, or the episode boundary of a batch in
+// lockstep).  Then nobody keeps a pool slot and the free stacks are simply rebuilt in order (slot 0 on top) instead of
+// being pushed slot by slot in whatever order the atomics land: a batch whose pool rings sit in the order they were
+// handed out runs its send half 15-35 % faster than one whose rings are scattered over the pools (the second episode of
+// a handle took 0.163 ms per send launch against 0.118 for the first; profiles/r03_experiments.json).
 template <int NS>
-__global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t *mask, int use_done, int gate, float *obs_out) {
+__global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t *mask, int use_done, int gate, int all_envs,
+                                                           float *obs_out) {
     if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    if (all_envs) {
+        for (int c = 1; c < D.n_tiers; c++) {
+            const int64_t slots = (int64_t)D.tier_slots[c];
+            for (int64_t j = i; j < slots; j += (int64_t)gridDim.x * kWave) D.tier_free[c][j] = (uint32_t)(slots - 1 - j);
+            if (i == 0) D.tier_top[c] = (int32_t)slots;
+        }
+    }
     if (i >= D.n) return;
     // use_done 1: the envs that finished their episode; 2: the envs a retire launch marked for a restart
     const bool sel = use_done == 2 ? D.env[i].resetting == 2 : (!mask || mask[i]) && (!use_done || D.env[i].done);
     D.env[i].resetting = sel ? 1 : 0;
     if (sel) {
-        release_ring_slots<NS>(D, i);
+        release_ring_slots<NS>(D, i, !all_envs);
         reset_env<NS>(D, i, obs_out);
     }
 }
@@ -3052,6 +3087,7 @@ struct pcc_sim {
     void *tier_blob[kMaxTiers];   // tier 0: one slot per (env, sender); tiers >= 1: pools
     void *tier_free_blob[kMaxTiers];
     uint32_t tier_slots[kMaxTiers];
+    size_t tier_bytes[kMaxTiers];
     size_t ring_bytes;
     void *timeline_blob;
     size_t timeline_bytes;
@@ -3108,6 +3144,16 @@ size_t carve_state(Dev &d, char *base) {
     d.tier_top = c.take<int32_t>(kMaxTiers);
     d.hist = c.take<float>(sn * d.HF);
     return (c.off + 255) & ~(size_t)255;
+}
+
+// pcc_set_ring_pools: every sender back in its own tier-0 rings, holding no pool slot (the pools are being replaced)
+__global__ void forget_ring_slots_kernel(Dev D) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= D.n * D.ns) return;
+    for (int c = 0; c < kMaxTiers; c++) D.snd[k].ring_held[c] = 0;
+    D.snd[k].ring_tier = 0;
+    const int64_t s = k / D.n, i = k % D.n;
+    D.snd[k].ring_base = D.tier_base[0] + (size_t)(i * D.ns + s) * tier_slot_bytes(D, 0);
 }
 
 int check_hip(hipError_t err, const char *what) {
@@ -3199,8 +3245,10 @@ int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gat
 // not in lockstep)
 int launch_reset(pcc_sim_t *sim, const uint8_t *mask, int use_done, int gate, float *obs_out, hipStream_t st) {
     const Dev &d = sim->d;
-    if (d.ns == 1) hipLaunchKernelGGL(reset_init_kernel<1>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, gate, obs_out);
-    else hipLaunchKernelGGL(reset_init_kernel<2>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, gate, obs_out);
+    // every env of the batch is reset: a full reset, or the episode boundary of a batch in lockstep (every env is done)
+    const int all_envs = (!mask && !gate && (use_done == 0 || (use_done == 1 && sim->lockstep))) ? 1 : 0;
+    if (d.ns == 1) hipLaunchKernelGGL(reset_init_kernel<1>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, gate, all_envs, obs_out);
+    else hipLaunchKernelGGL(reset_init_kernel<2>, lane_grid(d), dim3(kWave), 0, st, d, mask, use_done, gate, all_envs, obs_out);
     int rc = check_hip(hipGetLastError(), "reset kernel launch");
     for (uint32_t w = 0; w < 2 && rc == PCC_OK; w++)
         rc = launch_mi(sim, 1, w, w == 1, gate, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, st);
@@ -3221,6 +3269,43 @@ int flush_restarts(pcc_sim_t *sim, hipStream_t st) {
     if (!sim->restarts_pending) return PCC_OK;
     sim->restarts_pending = false;
     return launch_reset(sim, nullptr, 2, 0, nullptr, st);
+}
+
+// (re)allocate tier c: tier 0 is one slot per sender, tiers >= 1 are pools of senders / divisor slots with a free stack
+int alloc_tier(pcc_sim_t *sim, int c, unsigned divisor) {
+    Dev &d = sim->d;
+    const size_t senders = (size_t)d.n * d.ns;
+    size_t slots = senders / (divisor ? divisor : 1);
+    if (slots < 256) slots = senders < 256 ? senders : 256;
+    if (c == 0) slots = senders;
+    if (sim->tier_blob[c]) { (void)hipFree(sim->tier_blob[c]); sim->tier_blob[c] = nullptr; sim->ring_bytes -= sim->tier_bytes[c]; }
+    if (sim->tier_free_blob[c]) { (void)hipFree(sim->tier_free_blob[c]); sim->tier_free_blob[c] = nullptr; }
+    sim->tier_bytes[c] = 0;
+    sim->tier_slots[c] = (uint32_t)slots;
+    d.tier_slots[c] = (uint32_t)slots;
+    const size_t bytes = slots * 3 * ((size_t)d.cap0 << (2 * c)) * sizeof(double2);
+    if (hipMalloc(&sim->tier_blob[c], bytes) != hipSuccess) {
+        sim->tier_blob[c] = nullptr;
+        return fail(PCC_ENOMEM, "hipMalloc(%zu) for the tier-%d in-flight rings failed (%zu slots of 3*%u records)", bytes, c,
+                    slots, d.cap0 << (2 * c));
+    }
+    // touch the rings once now: freshly allocated device memory is markedly slower on first use
+    // (measured 1.8x on the first episode of a new handle), which would land in the caller's steps
+    if (hipMemset(sim->tier_blob[c], 0, bytes) != hipSuccess) return fail(PCC_EHIP, "hipMemset of the tier-%d rings failed", c);
+    size_t total = bytes;
+    d.tier_base[c] = static_cast<char *>(sim->tier_blob[c]);
+    if (c >= 1) {
+        std::vector<uint32_t> ids(slots);
+        for (size_t j = 0; j < slots; j++) ids[j] = (uint32_t)(slots - 1 - j);  // slot 0 is popped first
+        if (hipMalloc(&sim->tier_free_blob[c], slots * sizeof(uint32_t)) != hipSuccess ||
+            hipMemcpy(sim->tier_free_blob[c], ids.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(PCC_ENOMEM, "allocating the tier-%d free list failed", c);
+        total += slots * sizeof(uint32_t);
+        d.tier_free[c] = static_cast<uint32_t *>(sim->tier_free_blob[c]);
+    }
+    sim->tier_bytes[c] = total;
+    sim->ring_bytes += total;
+    return PCC_OK;
 }
 
 }  // namespace
@@ -3303,48 +3388,13 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     }
     carve_state(d, static_cast<char *>(sim->state_blob));
     // pool sizes: by default 1/2, 1/8, 1/32 of the senders can sit in tiers 1, 2, 3 at the same
-    // time (measured need at the ICML'19 ranges: ~25 %, ~2 %, ~0.02 %); PCC_RING_POOLS="a,b,c"
-    // overrides the divisors (1 = every sender could, the worst case)
-    unsigned div[kMaxTiers] = {1, 2, 8, 32};
-    if (const char *e = getenv("PCC_RING_POOLS")) {
-        unsigned a = 0, b = 0, c = 0;
-        const int got = sscanf(e, "%u,%u,%u", &a, &b, &c);
-        if (got >= 1 && a) div[1] = a;
-        if (got >= 2 && b) div[2] = b;
-        if (got >= 3 && c) div[3] = c;
-    }
-    const size_t senders = (size_t)n_envs * n_senders;
+    // time (measured need at the ICML'19 ranges with U(-1, 1) actions: ~25 %, ~2 %, ~0.02 %); pcc_set_ring_pools changes
+    // the divisors (1 = every sender could, the worst case -- what a rate-maximising policy may need)
+    const unsigned div[kMaxTiers] = {1, 2, 8, 32};
     sim->ring_bytes = 0;
     for (int c = 0; c < d.n_tiers; c++) {
-        size_t slots = senders / div[c];
-        if (slots < 256) slots = senders < 256 ? senders : 256;
-        if (c == 0) slots = senders;
-        sim->tier_slots[c] = (uint32_t)slots;
-        const size_t bytes = slots * 3 * ((size_t)d.cap0 << (2 * c)) * sizeof(double2);
-        if (hipMalloc(&sim->tier_blob[c], bytes) != hipSuccess) {
-            pcc_destroy(sim);
-            return fail(PCC_ENOMEM, "hipMalloc(%zu) for the tier-%d in-flight rings failed (%zu slots of 3*%u records)",
-                        bytes, c, slots, d.cap0 << (2 * c));
-        }
-        // touch the rings once now: freshly allocated device memory is markedly slower on first use
-        // (measured 1.8x on the first episode of a new handle), which would land in the caller's steps
-        if (hipMemset(sim->tier_blob[c], 0, bytes) != hipSuccess) {
-            pcc_destroy(sim);
-            return fail(PCC_EHIP, "hipMemset of the tier-%d rings failed", c);
-        }
-        sim->ring_bytes += bytes;
-        d.tier_base[c] = static_cast<char *>(sim->tier_blob[c]);
-        if (c >= 1) {
-            std::vector<uint32_t> ids(slots);
-            for (size_t j = 0; j < slots; j++) ids[j] = (uint32_t)(slots - 1 - j);  // slot 0 is popped first
-            if (hipMalloc(&sim->tier_free_blob[c], slots * sizeof(uint32_t)) != hipSuccess ||
-                hipMemcpy(sim->tier_free_blob[c], ids.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
-                pcc_destroy(sim);
-                return fail(PCC_ENOMEM, "allocating the tier-%d free list failed", c);
-            }
-            sim->ring_bytes += slots * sizeof(uint32_t);
-            d.tier_free[c] = static_cast<uint32_t *>(sim->tier_free_blob[c]);
-        }
+        const int rc = alloc_tier(sim, c, div[c]);
+        if (rc != PCC_OK) { pcc_destroy(sim); return rc; }
     }
     int32_t tops[kMaxTiers] = {0, 0, 0, 0};
     for (int c = 1; c < d.n_tiers; c++) tops[c] = (int32_t)sim->tier_slots[c];
@@ -3501,6 +3551,31 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             return PCC_OK;
         default: return fail(PCC_EINVAL, "unknown tuning key %d", key);
     }
+}
+
+int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t div3) {
+    if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_ring_pools between pcc_step_send and pcc_step_retire");
+    const unsigned div[kMaxTiers] = {1, div1, div2, div3};
+    for (int c = 1; c < kMaxTiers; c++)
+        if (div[c] < 1) return fail(PCC_EINVAL, "pool divisors must be >= 1 (1 = a slot for every sender)");
+    DeviceGuard guard(sim->device);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "hipDeviceSynchronize failed");
+    Dev &d = sim->d;
+    int32_t tops[kMaxTiers] = {0, 0, 0, 0};
+    for (int c = 1; c < d.n_tiers; c++) {
+        const int rc = alloc_tier(sim, c, div[c]);
+        if (rc != PCC_OK) return rc;
+        tops[c] = (int32_t)sim->tier_slots[c];
+    }
+    if (hipMemcpy(d.tier_top, tops, sizeof tops, hipMemcpyHostToDevice) != hipSuccess) return fail(PCC_EHIP, "resetting the pool stacks failed");
+    const int64_t senders = d.n * d.ns;
+    hipLaunchKernelGGL(forget_ring_slots_kernel, dim3((unsigned)((senders + 255) / 256)), dim3(256), 0, nullptr, d);
+    if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "forget_ring_slots_kernel failed");
+    sim->ever_reset = false;  // whatever was in flight lived in the old pools: a reset must follow
+    sim->restarts_pending = false;
+    sim->read_buf = -1;
+    return PCC_OK;
 }
 
 int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable) {

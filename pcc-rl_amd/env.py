@@ -54,7 +54,8 @@ class BatchedNetworkEnv(object):
 
     def __init__(self, n_envs, device="cuda", history_len=None, features=None, seed=0, n_senders=1,
                  link_params=None, env_gid_base=0, ring_capacity=0, auto_reset=True, delta_scale=None,
-                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False, use_cwnd=False, latency_noise=None):
+                 max_steps=MAX_STEPS, record_steps=False, new_tensors=False, use_cwnd=False, latency_noise=None,
+                 ring_pools=None):
         if history_len is None:
             history_len = arg_or_default("--history-len", default=10)
         if features is None:
@@ -83,6 +84,10 @@ class BatchedNetworkEnv(object):
                            self.device.index, ctypes.byref(handle)))
         self._h = handle
         self._L = L
+        if ring_pools is not None:
+            # (div1, div2, div3): tier k of the in-flight ring pools holds a slot for one sender in div_k (defaults 2, 8, 32
+            # fit U(-1, 1) policies; a policy that saturates every link wants smaller divisors -- PCC_FLAG_POOL_EXHAUSTED says so)
+            check(L.pcc_set_ring_pools(self._h, *[int(v) for v in ring_pools]))
         check(L.pcc_set_delta_scale(self._h, float(DELTA_SCALE if delta_scale is None else delta_scale)))
         check(L.pcc_set_max_steps(self._h, self.max_steps))
         # the reference's dormant USE_CWND engine option (ns:54): window-limited sending, actions

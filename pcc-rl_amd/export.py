@@ -4,6 +4,7 @@ the Gaussian head) and "stochastic_act" (a sample).  TensorFlow is not part of t
 container is TorchScript: `torch.jit.load(path)(ob) -> (act, stochastic_act)`; `load_policy` wraps
 that as the `act(obs)` callable the plugin-side controller (shim.PolicyRateController, the
 counterpart of src/udt-plugins/testing/loaded_agent.py) wants."""
+import copy
 import json
 import os
 
@@ -27,7 +28,9 @@ class _Exported(nn.Module):
 def export_policy(policy, export_dir, history_len=10, features=None):
     """Write <export_dir>/policy.pt (TorchScript, CPU) and signature.json naming inputs and outputs."""
     os.makedirs(export_dir, exist_ok=True)
-    mod = _Exported(policy.pi, policy.log_std).to("cpu").eval()
+    # a COPY of the network goes to the CPU: nn.Module.to() moves parameters in place, and the caller's policy (and its
+    # optimizer state) must stay where it is
+    mod = _Exported(copy.deepcopy(policy.pi), policy.log_std).to("cpu").eval()
     scripted = torch.jit.script(mod)
     path = os.path.join(export_dir, "policy.pt")
     scripted.save(path)

@@ -30,7 +30,7 @@ FIELDS = {
 
 # every symbol include/pcc_sim.h declares
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
-           "pcc_set_rng", "pcc_set_seed", "pcc_set_tuning", "pcc_set_cwnd_mode", "pcc_set_latency_noise", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
+           "pcc_set_rng", "pcc_set_seed", "pcc_set_tuning", "pcc_set_ring_pools", "pcc_set_cwnd_mode", "pcc_set_latency_noise", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
            "pcc_step_retire",
            "pcc_get_state", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline", "pcc_debug_pass_stats",
            "pcc_policy_act"]
@@ -75,6 +75,8 @@ def lib():
     L.pcc_set_seed.argtypes = [vp, u64]
     L.pcc_set_tuning.argtypes = [vp, i32, dbl]
     L.pcc_set_tuning.restype = i32
+    L.pcc_set_ring_pools.argtypes = [vp, u32, u32, u32]
+    L.pcc_set_ring_pools.restype = i32
     L.pcc_set_cwnd_mode.argtypes = [vp, i32]
     L.pcc_set_cwnd_mode.restype = i32
     L.pcc_set_latency_noise.argtypes = [vp, i32, dbl]

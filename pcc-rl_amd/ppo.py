@@ -138,7 +138,7 @@ class PPO(object):
         with torch.no_grad():
             last_v = self.policy.value(obs)
         # never train on corrupted rollouts: an overflowed in-flight ring / an empty ring pool (a trained
-        # policy can push many deep-queue envs to MAX_RATE: PCC_RING_POOLS) is flagged, not silent
+        # policy can push many deep-queue envs to MAX_RATE: BatchedNetworkEnv(ring_pools=...)) is flagged, not silent
         env.check_flags()
         adv, ret = gae(rew_b, val_b, done_b, last_v, self.gamma, self.lam)
         return obs_b, act_b, logp_b, adv, ret, rew_b

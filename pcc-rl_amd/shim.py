@@ -126,10 +126,17 @@ class SampleHistory(object):
     """SenderHistory (so:56-73) over decoded samples: the last `length` monitor intervals, oldest
     first; `as_array` is the observation the policy was trained on."""
 
-    def __init__(self, length=10, features=DEFAULT_FEATURES):
+    def __init__(self, length=10, features=DEFAULT_FEATURES, conn_min=None):
+        """conn_min: the connection's minimum of per-interval mean latencies so far.  The reference keeps it in a
+        module-level table keyed by flow id (so:158) that a history reset does not clear, so a history created for
+        a flow that already has one starts with empty intervals evaluated against it ("latency ratio" 0/min = 0.0,
+        not the 1.0 of a first history) -- the empty intervals are evaluated here, before any sample, which is the
+        value the reference's lazy evaluation (oldest interval first) arrives at."""
         self.features = features.split(",") if isinstance(features, str) else list(features)
-        self.conn_min = None
-        self.values = [MonitorInterval(dict(_EMPTY)) for _ in range(length)]
+        self.conn_min = conn_min
+        self.values = [MonitorInterval(dict(_EMPTY), conn_min) for _ in range(length)]
+        for mi in self.values:
+            mi.as_array(self.features)
 
     def step(self, sample):
         mi = MonitorInterval(sample, self.conn_min)
@@ -157,8 +164,8 @@ def apply_rate_delta(rate, action, delta_scale=0.05, min_rate=0.5, max_rate=300.
 class PolicyRateController(object):
     """The plugin-side driver of loaded_client.py:53-137 for ONE flow, with the policy behind a callable
     `act(obs) -> action` (e.g. pcc_rl_amd.export.load_policy(...)): get_rate() / give_sample(...) / reset()
-    are what PCC-Uspace's Python plugin hooks call (module-level init/get_rate/give_sample/reset keyed by flow
-    id are one dict away)."""
+    are what PCC-Uspace's Python plugin hooks call; pcc_rl_amd.udt_plugin holds the module-level
+    init/get_rate/give_sample/reset keyed by flow id that the plugin loader binds."""
 
     def __init__(self, act, history_len=10, features=DEFAULT_FEATURES, start_rate=6.0, delta_scale=0.05,
                  min_rate=0.5, max_rate=300.0):
@@ -167,8 +174,14 @@ class PolicyRateController(object):
         self.reset()
 
     def reset(self):
-        self.rate = self.start_rate
-        self.history = SampleHistory(self.history_len, self.features)
+        """loaded_client.py:94-110: a fresh history; no rate is sent until a new sample arrives.  Two things survive,
+        as in the reference: the flow's latency minimum (so:158-176: the table of connection minima is never cleared)
+        and the RATE -- reset_rate() there draws a new `current_rate` that nothing reads, so get_rate() goes on from
+        the rate the flow had (pinned by tests/golden/udt_plugin.npz)."""
+        prev = getattr(self, "history", None)
+        if prev is None:
+            self.rate = self.start_rate
+        self.history = SampleHistory(self.history_len, self.features, conn_min=prev.conn_min if prev is not None else None)
         self.got_data = False
 
     def give_sample(self, bytes_sent, bytes_acked, bytes_lost, send_start, send_end, recv_start, recv_end,
@@ -181,6 +194,8 @@ class PolicyRateController(object):
 
     def get_rate(self):
         if self.got_data:
-            action = float(np.asarray(self.act(self.history.as_array().astype(np.float32))).reshape(-1)[0])
+            # (the observation goes to the agent as the float64 array the history holds, loaded_client.py:78; an exported
+            # policy casts it itself)
+            action = float(np.asarray(self.act(self.history.as_array())).reshape(-1)[0])
             self.rate = apply_rate_delta(self.rate, action, self.delta_scale, self.min_rate, self.max_rate)
         return self.rate * 1e6

@@ -59,8 +59,6 @@ def golden_env(d, history_len=10, features=None, n_senders=1):
                                   "fixed_q1", "fixed_lossy", "fixed_deepq"])
 def test_golden_vectors_bit_exact(name):
     d = load(name)
-    if name == "two_episodes":
-        pytest.skip("covered separately")
     env = golden_env(d, history_len=int(d["history_len"]))
     obs0 = env.reset().cpu().numpy()
     assert np.array_equal(obs0, d["obs0"].astype(np.float32))
@@ -77,6 +75,33 @@ def test_golden_vectors_bit_exact(name):
     k = d["obs_full"].shape[0]
     assert np.array_equal(obs[:k], d["obs_full"].astype(np.float32))
     assert np.array_equal(done, d["done"])
+    env.close()
+
+
+def test_two_consecutive_episodes_of_the_reference_on_one_handle():
+    """tests/golden/two_episodes.npz: the reference env object ran two episodes back to back (rows i, i + 1 = episodes 0, 1
+    of one env: new links from the same random stream).  Here one handle runs episode 0, is reset with the second
+    episode's links and the stream position the reference had reached, and must reproduce episode 1 bit for bit --
+    rings, tiers, cursors and the connection minimum all start over."""
+    d = load("two_episodes")
+    first = {k: (v[0::2] if getattr(v, "ndim", 0) and v.shape[0] == d["seed"].shape[0] else v) for k, v in d.items()}
+    second = {k: (v[1::2] if getattr(v, "ndim", 0) and v.shape[0] == d["seed"].shape[0] else v) for k, v in d.items()}
+    assert (second["episode"] == 1).all() and (first["seed"] == second["seed"]).all()
+    env = golden_env(first, history_len=int(d["history_len"]))
+    for ep, dd in enumerate((first, second)):
+        if ep:
+            p = dd["params"]
+            env.set_link_params(p[:, 0], p[:, 1], np.round(p[:, 2]), p[:, 3], p[:, 4])
+            k = int((dd["rng"][:, 1] - dd["rng"][:, 0]).max())
+            env.set_loss_trace(np.stack([oracle.mt_uniforms(int(sd), k, skip=int(o)) for sd, o in zip(dd["seed"], dd["rng"][:, 0])]))
+        obs0 = env.reset().cpu().numpy()
+        assert np.array_equal(obs0, dd["obs0"].astype(np.float32))
+        assert np.array_equal(env.state("now").cpu().numpy(), dd["warm"][:, 0])
+        T = dd["actions"].shape[1]
+        steps, obs, done = run_gpu(env, dd["actions"], T)
+        assert np.array_equal(steps, dd["steps"]), "episode %d" % ep
+        assert np.array_equal(obs[..., -3:], dd["obs_tail"].astype(np.float32))
+        assert np.array_equal(done, dd["done"])
     env.close()
 
 
@@ -545,14 +570,12 @@ def test_two_senders_at_full_size():
     env.close()
 
 
-def test_ring_tiers_promote_and_come_back_at_reset(monkeypatch):
+def test_ring_tiers_promote_and_come_back_at_reset():
     """Rings start in the small tier, envs with many packets in flight are moved up (without
     changing a result: the goldens above cover that, fixed_deepq needs the top tier), reset gives the
     pool rings back, and nothing is ever flagged."""
     n = 2048
-    monkeypatch.setenv("PCC_RING_POOLS", "1,1,1")   # every env overloads below: worst-case pools
-    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=3, auto_reset=False)
-    monkeypatch.delenv("PCC_RING_POOLS")
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=3, auto_reset=False, ring_pools=(1, 1, 1))   # every env overloads below: worst-case pools
     env.reset()
     assert int(env.state("ring_tier").max().item()) <= 1      # two warm-up MIs rarely need more than the small rings
     gen = torch.Generator(device=DEV).manual_seed(0)
@@ -571,12 +594,10 @@ def test_ring_tiers_promote_and_come_back_at_reset(monkeypatch):
     env.close()
 
 
-def test_ring_pool_exhaustion_is_flagged(monkeypatch):
+def test_ring_pool_exhaustion_is_flagged():
     """Too few pool rings for the load: flagged (and the overflow that follows), never silent."""
-    monkeypatch.setenv("PCC_RING_POOLS", "1000000,1000000,1000000")   # the minimum: 256 rings per pool
     n = 4096
-    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=3, auto_reset=False)
-    monkeypatch.delenv("PCC_RING_POOLS")
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=3, auto_reset=False, ring_pools=(1000000, 1000000, 1000000))   # the minimum: 256 rings per pool
     env.reset()
     gen = torch.Generator(device=DEV).manual_seed(0)
     for t in range(200):
@@ -794,6 +815,70 @@ def test_grouped_env_is_the_same_envs_on_several_streams():
         assert torch.equal(torch.cat(got_obs[t], 0), ref_obs[t]), t
         assert torch.equal(torch.cat(got_rew[t], 0), ref_rew[t]), t
     one.close(); grp.close()
+
+
+def test_long_episode_matches_oracle():
+    """The near-group tolerance (1e-12 relative) is an assumption about the size of the clock: 20 000-step episodes
+    (clocks up to ~1e5 s, 50 x the default episode) still match the oracle bit for bit, and no env raises
+    PCC_FLAG_TIME_RANGE inside the default parameter ranges."""
+    n_envs, n_steps, seed = 6, 20000, 77
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=False, max_steps=n_steps)
+    env.reset()
+    rs = np.random.RandomState(seed)
+    acts = rs.uniform(-1, 1, (n_envs, n_steps))
+    a = torch.as_tensor(acts, dtype=torch.float64, device=DEV)
+    rows = torch.empty((n_steps, n_envs, 19), dtype=torch.float64, device=DEV)
+    for t in range(n_steps):
+        o, r, d, info = env.step(a[:, t])
+        rows[t] = info["steps"]
+    torch.cuda.synchronize()
+    env.check_flags()
+    ref = oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=seed, want_obs=False)
+    got = rows.permute(1, 0, 2).cpu().numpy()
+    assert np.array_equal(got[..., :3], ref["steps"][..., :3])
+    assert np.array_equal(got, ref["steps"])
+    assert float(got[..., 4].max()) > 2e4      # the clocks did get large
+    env.close()
+
+
+def test_bad_inputs_are_flagged_and_nothing_hangs():
+    """A NaN action is applied as 0 and flagged (PCC_FLAG_BAD_ACTION) -- the env goes on being stepped and filed; a
+    starting rate of 0 or NaN is flagged (PCC_FLAG_BAD_PARAMS) and the env runs on a stand-in link instead of spinning;
+    a clock beyond what the dropped packets' ordering tolerates raises PCC_FLAG_TIME_RANGE."""
+    from pcc_rl_amd import native
+    n = 256
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=5, auto_reset=False, record_steps=True)
+    env.reset()
+    a = torch.zeros(n, dtype=torch.float64, device=DEV)
+    a[7] = float("nan")
+    rate_before = env.state("rate")[0].clone()
+    for t in range(5):
+        o, r, d, info = env.step(a)
+    torch.cuda.synchronize()
+    flags = env.state("flags").cpu().numpy()
+    assert flags[7] == native.PCC_FLAG_BAD_ACTION and (np.delete(flags, 7) == 0).all()
+    assert torch.equal(env.state("rate")[0], rate_before.clamp(40.0, 1000.0))     # zero (and NaN -> zero) actions: only the clamp
+    assert int(env.state("steps")[7].item()) == 5 and bool(torch.isfinite(o).all())
+    env.close()
+    env = pcc_rl_amd.BatchedNetworkEnv(4, device=DEV, seed=5, auto_reset=False)
+    env.set_link_params(200.0, 0.03, 5.0, 0.0, torch.tensor([60.0, 0.0, float("nan"), -3.0], dtype=torch.float64))
+    env.reset()
+    for t in range(3):
+        env.step(torch.zeros(4, device=DEV))
+    torch.cuda.synchronize()
+    flags = env.state("flags").cpu().numpy()
+    assert flags[0] == 0 and (flags[1:] == native.PCC_FLAG_BAD_PARAMS).all()
+    env.close()
+    env = pcc_rl_amd.BatchedNetworkEnv(2, device=DEV, seed=5, auto_reset=False, max_steps=100000)
+    env.set_link_params(1e6, 100.0, 5.0, 0.0, 40.0)       # 1/bw = 1e-6 s, an RTT of 200 s: the clock passes 15 625 s quickly
+    env.reset()
+    for t in range(400):
+        env.step(torch.full((2,), -1.0, device=DEV))
+    torch.cuda.synchronize()
+    flags = env.state("flags").cpu().numpy()
+    assert float(env.state("now").max().item()) > 16000.0
+    assert (flags & native.PCC_FLAG_TIME_RANGE).all()
+    env.close()
 
 
 def test_parameter_ranges_are_validated():

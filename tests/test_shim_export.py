@@ -65,4 +65,45 @@ def test_export_signature_and_controller_round_trip(tmp_path):
     a = float(actf(ctl.history.as_array().astype(np.float32))[0])
     assert r == shim.apply_rate_delta(6.0, a) * 1e6 and 0.5e6 <= r <= 300e6
     ctl.reset()
-    assert ctl.get_rate() == 6.0e6
+    assert ctl.get_rate() == r      # like the reference's reset(): the history is new, the rate stands (loaded_client.py:94-110)
+
+
+def test_udt_plugin_module_equals_the_reference_loaded_client():
+    """The deployment surface: module-level init / get_rate / give_sample / reset keyed by flow id
+    (src/udt-plugins/testing/loaded_client.py:132-173), replayed against what the reference module returned for the
+    same script of calls on two flows -- resets included -- with the same stub agent behind both."""
+    from pcc_rl_amd import udt_plugin
+    with np.load(os.path.join(os.path.dirname(G), "udt_plugin.npz"), allow_pickle=False) as z:
+        d = {k: z[k] for k in z.files}
+    w = d["w"]
+
+    def stub_act(obs):
+        obs = np.asarray(obs, dtype=np.float64).reshape(-1)
+        return float(np.tanh(sum(obs[k] * w[k % 3] * (1.0 + k / 30.0) for k in range(obs.size))))
+
+    udt_plugin.set_policy(stub_act)
+    udt_plugin._flows.clear()
+    k = 0
+    for call in d["script"]:
+        op, *args = ast.literal_eval(str(call))
+        if op == "get_rate":
+            got = getattr(udt_plugin, op)(*args)
+            assert got == d["rates"][k], (k, call)
+            assert np.array_equal(udt_plugin._flows[args[0]].history.as_array(), d["obs"][k]), (k, call)
+            k += 1
+        else:
+            getattr(udt_plugin, op)(*args)
+    assert k == len(d["rates"])
+
+
+def test_export_leaves_the_training_policy_where_it_is(tmp_path):
+    """export_policy works on a copy: the caller's modules keep their device and dtype (nn.Module.to() is in place)."""
+    pol = MlpPolicy(30, 1).to(torch.float64)      # a dtype the export does not use stands in for "another device" on a CPU box
+    before = [(p.device, p.dtype, p.data_ptr()) for p in pol.pi.parameters()]
+    mod = export._Exported(__import__("copy").deepcopy(pol.pi), pol.log_std).to(torch.float32)
+    assert [(p.device, p.dtype, p.data_ptr()) for p in pol.pi.parameters()] == before
+    assert next(mod.pi.parameters()).dtype == torch.float32
+    pol32 = MlpPolicy(30, 1)
+    ptrs = [p.data_ptr() for p in pol32.pi.parameters()]
+    export.export_policy(pol32, str(tmp_path))
+    assert [p.data_ptr() for p in pol32.pi.parameters()] == ptrs

@@ -3,7 +3,7 @@
 
     python tools/pmc_aggregate.py out.json DIR_WITH_FETCH_SIZE DIR_WITH_WRITE_SIZE
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 def short(name):
     for k in ("step_kernel", "send_kernel", "retire_kernel", "reset_init_kernel"):
@@ -53,11 +53,12 @@ for d in sys.argv[2:]:
             if "hbm_bytes_per_launch" in out[name]:
                 out[name]["traffic_over_algorithmic"] = out[name]["hbm_bytes_per_launch"] / k["algorithmic_bytes_per_launch"]
     break
-out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 100 --warmup 20 "
-                "--repeats 1 --no-cpu-baseline` (steps 20..120 of an episode); counters are KB per dispatch.  hbm_bytes_per_launch = "
+out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 400 --warmup 20 "
+                "--repeats 1 --no-cpu-baseline` (one whole episode); counters are KB per dispatch.  hbm_bytes_per_launch = "
                 "2 x FETCH_SIZE + WRITE_SIZE: tools/pmc_calibrate.sh (profiles/r02_pmc_calibration.json) measured FETCH_SIZE at "
                 "exactly half of the fetched 128-byte lines for every read pattern of these kernels and WRITE_SIZE at 1.0 x (dense) "
                 "to 1.12 x (ring appends) of the written bytes; hbm_bytes_per_launch_raw is the uncorrected sum.")
-out["_window"] = "steps 20..120 of an episode"
+out["_window"] = os.environ.get("PCC_PMC_WINDOW", "one whole 400-step episode (after 20 warm-up steps)")
+out["_commit"] = os.environ.get("PCC_COMMIT", "unknown")
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out, indent=1))

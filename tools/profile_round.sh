@@ -2,15 +2,15 @@
 # The round's measurement set, run on the GPU box from the repo root:  bash tools/profile_round.sh TAG
 # bench line (with the CPU baselines), rocprofv3 kernel stats of the same command, HBM PMC passes,
 # send critical path, retire phases.  Results under gpurun_out/TAG/ (copy what is to be kept into profiles/).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python $R/bench.py > $O/bench.log 2> $O/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1
-timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python $R/bench.py --steps 100 --warmup 20 --repeats 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python $R/bench.py --steps 100 --warmup 20 --repeats 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python $R/bench.py --steps 400 --warmup 20 --repeats 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python $R/bench.py --steps 400 --warmup 20 --repeats 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
 python $R/tools/pmc_aggregate.py $O/pmc_hbm.json $O/pmc_fetch $O/pmc_write > /dev/null
 timeout 200 python $R/bench.py --no-cpu-baseline --stagger --steps 800 --repeats 1 > $O/bench_stagger.log 2>&1
 cd $R

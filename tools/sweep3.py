@@ -11,23 +11,26 @@ knob_sets = json.loads(sys.argv[1]) if len(sys.argv) > 1 else [{}]
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 EPS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+AUTO = len(sys.argv) > 5 and sys.argv[5] == "auto"   # later episodes start by the env's own auto-reset, not by reset()
 W = 20
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(1234)
-acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
+POOL = 400   # one action vector per episode step (a short cycled pool makes every env's rate drift: see bench.py)
+acts = torch.rand((POOL, N), generator=gen, device=dev) * 2 - 1
 for knobs in knob_sets:
     kw = {k[4:]: v for k, v in knobs.items() if k.startswith("env_")}
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, **kw)
     env.set_tuning(**{k: v for k, v in knobs.items() if not k.startswith("env_")})
     for ep in range(EPS):
-        env.reset()
-        for t in range(W):
-            env.step(acts[t % 64])
+        if ep == 0 or not AUTO:
+            env.reset()
+            for t in range(W):
+                env.step(acts[t % POOL])
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(K):
-            ev[k][0].record(); env.step_send(acts[(W + k) % 64]); ev[k][1].record(); env.step_retire(); ev[k][2].record()
+            ev[k][0].record(); env.step_send(acts[(W + k) % POOL]); ev[k][1].record(); env.step_retire(); ev[k][2].record()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         send = [e[0].elapsed_time(e[1]) for e in ev]
