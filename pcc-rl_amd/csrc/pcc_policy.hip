@@ -60,6 +60,55 @@ __global__ __launch_bounds__(256) void policy_act_kernel(const float *obs, int64
     if (value_out) value_out[i] = v;
 }
 
+// The reference's own sizes (--arch 32,16) with everything a compile-time constant: the hidden activations stay in
+// registers (the generic kernel above indexes z1[j] with a run-time j: scratch memory), the loops unroll.
+template <int D, int H1, int H2>
+__device__ __forceinline__ float mlp_forward_fixed(const float *p, const float (&x)[D]) {
+    const float *W1 = p, *b1 = W1 + H1 * D, *W2 = b1 + H1, *b2 = W2 + H2 * H1, *W3 = b2 + H2, *b3 = W3 + H2;
+    float z1[H1], z2[H2];
+#pragma unroll
+    for (int j = 0; j < H1; j++) {
+        float s = b1[j];
+#pragma unroll
+        for (int k = 0; k < D; k++) s = fmaf(W1[j * D + k], x[k], s);
+        z1[j] = tanhf(s);
+    }
+#pragma unroll
+    for (int j = 0; j < H2; j++) {
+        float s = b2[j];
+#pragma unroll
+        for (int k = 0; k < H1; k++) s = fmaf(W2[j * H1 + k], z1[k], s);
+        z2[j] = tanhf(s);
+    }
+    float out = b3[0];
+#pragma unroll
+    for (int k = 0; k < H2; k++) out = fmaf(W3[k], z2[k], out);
+    return out;
+}
+
+template <int D, int H1, int H2>
+__global__ __launch_bounds__(256) void policy_act_fixed_kernel(const float *obs, int64_t n, const float *params, int n_params,
+                                                               const float *noise, float *mean_out, float *act_out,
+                                                               float *logp_out, float *value_out) {
+    __shared__ float sp[kMaxParams];
+    for (int k = threadIdx.x; k < n_params; k += blockDim.x) sp[k] = params[k];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) x[k] = obs[i * D + k];
+    constexpr int n_pi = H1 * D + H1 + H2 * H1 + H2 + H2 + 1;   // without log_std
+    const float mu = mlp_forward_fixed<D, H1, H2>(sp, x);
+    const float log_std = sp[n_pi];
+    const float v = mlp_forward_fixed<D, H1, H2>(sp + n_pi + 1, x);
+    const float eps = noise ? noise[i] : 0.0f;
+    if (mean_out) mean_out[i] = mu;
+    if (act_out) act_out[i] = mu + expf(log_std) * eps;
+    if (logp_out) logp_out[i] = -0.5f * eps * eps - log_std - 0.918938533204672742f;
+    if (value_out) value_out[i] = v;
+}
+
 }  // namespace
 
 extern "C" int pcc_policy_act(const float *obs, int64_t n_envs, int obs_dim, const float *params, int h1, int h2,
@@ -72,6 +121,23 @@ extern "C" int pcc_policy_act(const float *obs, int64_t n_envs, int obs_dim, con
     if (n_params > kMaxParams) return -1;
     const dim3 grid((unsigned)((n_envs + 255) / 256)), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (h1 == 32 && h2 == 16) {   // the reference's --arch: the fully unrolled build
+        switch (obs_dim) {
+#define PCC_POLICY_FIXED(DD)                                                                                             \
+    case DD:                                                                                                             \
+        hipLaunchKernelGGL((policy_act_fixed_kernel<DD, 32, 16>), grid, block, 0, st, obs, n_envs, params, n_params, noise, \
+                           mean_out, act_out, logp_out, value_out);                                                     \
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+            PCC_POLICY_FIXED(30)
+            PCC_POLICY_FIXED(36)
+            PCC_POLICY_FIXED(3)
+            PCC_POLICY_FIXED(6)
+            PCC_POLICY_FIXED(12)
+            PCC_POLICY_FIXED(60)
+#undef PCC_POLICY_FIXED
+            default: break;
+        }
+    }
     switch (obs_dim) {   // the observation length is a compile-time constant of the unrolled loads
 #define PCC_POLICY_CASE(DD)                                                                                              \
     case DD:                                                                                                             \

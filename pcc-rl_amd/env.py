@@ -246,6 +246,20 @@ class BatchedNetworkEnv(object):
                                1 if self.auto_reset else 0, self._stream()))
         return self._step_result()
 
+    def step_into(self, actions, obs_out, reward_out, done_out):
+        """step() that writes straight into the caller's tensors -- e.g. rows of a rollout buffer -- instead of the
+        env's own output buffers: obs_out float32 [N, S, H*F] (or [N, H*F] with one sender), reward_out float32 [N, S]
+        ([N]), done_out uint8/bool [N], all contiguous on the env's device.  Returns nothing; no copy is made."""
+        a = self._actions(actions)
+        N, S, D = self.n_envs, self.n_senders, self.obs_dim
+        for t, n, dt in ((obs_out, N * S * D, (torch.float32,)), (reward_out, N * S, (torch.float32,)),
+                         (done_out, N, (torch.uint8, torch.bool))):
+            if t.numel() != n or t.dtype not in dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("step_into: an output tensor has the wrong size, dtype, layout or device")
+        check(self._L.pcc_step(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, _ptr(obs_out), _ptr(reward_out),
+                               _ptr(done_out), _ptr(self._steps), 1 if self.auto_reset else 0, self._stream()))
+        self._t += 1
+
     # ------------------------------------------------------------------ introspection
     def state(self, name):
         """Copy of one internal state field as a tensor (see native.FIELDS)."""

@@ -56,28 +56,42 @@ class MlpPolicy(nn.Module):
             return [p.detach().reshape(-1) for m in seq if isinstance(m, nn.Linear) for p in (m.weight, m.bias)]
         return torch.cat(net(self.pi) + [self.log_std.detach().reshape(-1)] + net(self.vf)).float().contiguous()
 
+    def fused_ok(self, obs):
+        """Whether pcc_policy_act covers this policy and observation batch (two hidden layers, one action, fp32 on the GPU)."""
+        linears = [m for m in self.pi if isinstance(m, nn.Linear)]
+        return len(linears) == 3 and linears[2].out_features == 1 and obs.is_cuda and obs.dtype == torch.float32
+
     @torch.no_grad()
-    def act_fused(self, obs, stochastic=True):
-        """act() as ONE kernel launch of the HIP library (two hidden layers, one action, fp32 observations
-        on the GPU); returns (action [N, 1], log-probability [N], value [N]) like act()."""
+    def act_fused(self, obs, stochastic=True, params=None, noise=None, out=None):
+        """act() as ONE kernel launch of the HIP library; returns (action [N, 1], log-probability [N], value [N]) like act().
+        A rollout loop passes `params` (flat_params(), built once per rollout -- it is a 13-tensor torch.cat), its own
+        `noise` row and `out` = (action, logp, value) rows of its buffers, so that a step adds no framework launch."""
         import ctypes
 
         from .native import lib
-        linears = [m for m in self.pi if isinstance(m, nn.Linear)]
-        if len(linears) != 3 or linears[2].out_features != 1 or not obs.is_cuda or obs.dtype != torch.float32:
+        if not self.fused_ok(obs):
             return self.act(obs, stochastic)
+        linears = [m for m in self.pi if isinstance(m, nn.Linear)]
         n, D = obs.shape
-        params = self.flat_params()
-        noise = torch.randn(n, device=obs.device) if stochastic else None
-        a = torch.empty(n, device=obs.device)
-        logp, v = torch.empty_like(a), torch.empty_like(a)
+        if params is None:
+            params = self.flat_params()
+        if noise is None and stochastic:
+            noise = torch.randn(n, device=obs.device)
+        if out is None:
+            a = torch.empty(n, device=obs.device)
+            logp, v = torch.empty_like(a), torch.empty_like(a)
+        else:
+            a, logp, v = out
         ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         rc = lib().pcc_policy_act(ptr(obs.contiguous()), n, D, ptr(params), linears[0].out_features, linears[1].out_features,
-                                  ptr(noise), None, ptr(a), ptr(logp), ptr(v),
+                                  ptr(noise if stochastic else None), None, ptr(a), ptr(logp), ptr(v),
                                   ctypes.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
-        if rc != 0:
-            return self.act(obs, stochastic)          # e.g. an observation length without a kernel instantiation
-        return a.unsqueeze(-1), logp, v
+        if rc != 0:   # e.g. an observation length without a kernel instantiation
+            a2, logp2, v2 = self.act(obs, stochastic)
+            if out is not None:
+                a.copy_(a2.reshape(-1)); logp.copy_(logp2); v.copy_(v2)
+            return a2, logp2, v2
+        return a.reshape(n, 1), logp, v
 
 
 def gae(rewards, values, dones, last_value, gamma=0.99, lam=0.95):
@@ -110,31 +124,48 @@ def ppo_loss(policy, obs, act, logp_old, adv, ret, clip=0.2, ent_coef=0.01):
 
 class PPO(object):
     def __init__(self, env, arch=(32, 16), gamma=0.99, lam=0.95, clip=0.2, ent_coef=0.01, lr=1e-3,
-                 epochs=4, minibatch=2048, horizon=64, seed=0):
+                 epochs=4, minibatch=None, horizon=64, seed=0):
+        """minibatch None = a quarter of the rollout, at least 2048: the reference's ratio (optim_batchsize 2048 of a
+        timesteps_per_actorbatch of 8192, stable_solve.py:52) -- at 65 536 envs x 64 steps a fixed 2048 would be 2 048
+        optimiser steps per epoch, thousands of launches of a few microseconds of work each."""
         self.env, self.gamma, self.lam, self.clip, self.ent_coef = env, gamma, lam, clip, ent_coef
         self.epochs, self.minibatch, self.horizon = epochs, minibatch, horizon
         torch.manual_seed(seed)
         self.policy = MlpPolicy(env.obs_dim, 1, arch).to(env.device)
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=lr, eps=1e-5)
         self.obs = env.reset().clone()
+        if self.minibatch is None:
+            self.minibatch = max(2048, env.n_envs * horizon // 4)
 
     def collect(self):
+        """One rollout of `horizon` steps of every env.  The policy kernel reads the observation row the env wrote and
+        writes action / log-probability / value into the rollout rows; the env reads that action row and writes the next
+        observation, reward and done rows: two library calls and three kernels per step, no framework launch, no copy."""
         env, T, N = self.env, self.horizon, self.env.n_envs
         dev = env.device
-        obs_b = torch.empty((T, N, env.obs_dim), device=dev)
+        obs_b = torch.empty((T + 1, N, env.obs_dim), device=dev)   # row t: what the policy saw at step t; row T: the last
         act_b = torch.empty((T, N, 1), device=dev)
         logp_b = torch.empty((T, N), device=dev)
         val_b = torch.empty((T, N), device=dev)
         rew_b = torch.empty((T, N), device=dev)
         done_b = torch.empty((T, N), dtype=torch.bool, device=dev)
-        obs = self.obs
-        for t in range(T):
-            a, logp, v = self.policy.act_fused(obs)
-            obs_b[t], act_b[t], logp_b[t], val_b[t] = obs, a, logp, v
-            nobs, r, d, _ = env.step(a)           # tensors in, tensors out, no host round trip
-            rew_b[t], done_b[t] = r, d
-            obs = nobs.clone()
-        self.obs = obs
+        obs_b[0] = self.obs
+        fused = self.policy.fused_ok(obs_b[0]) and env.n_senders == 1
+        if fused:
+            params = self.policy.flat_params()                     # once per rollout, not per step
+            noise = torch.randn((T, N), device=dev)                # the horizon's draws in one launch
+            for t in range(T):
+                self.policy.act_fused(obs_b[t], True, params, noise[t], (act_b[t].reshape(N), logp_b[t], val_b[t]))
+                env.step_into(act_b[t], obs_b[t + 1], rew_b[t], done_b[t])   # tensors in, tensors out, no host round trip
+        else:
+            for t in range(T):
+                a, logp, v = self.policy.act(obs_b[t])
+                act_b[t], logp_b[t], val_b[t] = a, logp, v
+                nobs, r, d, _ = env.step(a)
+                rew_b[t], done_b[t], obs_b[t + 1] = r, d, nobs
+        obs = obs_b[T]
+        self.obs = obs.clone()
+        obs_b = obs_b[:T]
         with torch.no_grad():
             last_v = self.policy.value(obs)
         # never train on corrupted rollouts: an overflowed in-flight ring / an empty ring pool (a trained
