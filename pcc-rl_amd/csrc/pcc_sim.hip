@@ -514,14 +514,55 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
         const double D0 = t0 - st.tu;
         const double x0 = st.q - D0;         // the queue the first packet sees (before max0), ns:66-67
         // ---- regime (wave-uniform)
-        int regime = 0;  // 0 serial, 1 = A, 2 = B
+        int regime = 0;  // 0 serial, 1 = A, 2 = B, 3 = C
         uint32_t e = 0;
         double u = 0.0, R = 0.0;
         int64_t Q0i = 0, D0i = 0, Gi = 0, Ri = 0, Ci = 0;
+        int64_t Mi3 = 0, Bi3 = 0, Ii3 = 0;  // regime C: maxq, the straddled power of two, floor(1/bw) in units of v
+        int cl3 = 0;                        // regime C: [frac(1/bw in units of v) > 1/2]
         bool maxq_above = false, free_mode = false;
         if (ok_t && chain_left == 0u) {
             if (G >= ebw && !(x0 > 0.0)) {
                 regime = 1;
+            } else if (W == 1 && [&]() {
+                // ---- regime C, "full queue straddling a power of two": maxq sits just above B = 2^E (maxq - 1/bw < B <=
+                // maxq), so the full queue lives in two binades -- values below B are multiples of v = ulp(B) / 2, values
+                // from B up multiples of 2 v, and fl(qcur + 1/bw) rounds to the grid its result lands on.  Regime B would
+                // stop every few packets (q leaves its binade) and the accept chain take over at ~95 ns per packet: a few
+                // such envs of 1-2 k packets were the critical path of whole launches (0.150 instead of 0.113 ms; random losses let
+                // the queue dip well below maxq - 1/bw, so the regime is tried up to 64 packets above B).  In
+                // units of v with 1/bw = (I + f) v, 0 < f < 1, f != 1/2: a result below B is n + I + cl (cl = [f > 1/2]),
+                // a result from B up is n + I rounded up to even.  The pass takes decisions and landing sides from the
+                // base trajectory (the constant increment R0 = I + cl: the token scan of regime B in units of v), which
+                // is off the true one by at most j units after j accepts -- a packet whose decision or landing side is
+                // closer than that to its threshold ends the pass -- and then runs the two-state automaton (parity of
+                // the queue) over the accepted packets to get every correction.  tests/models/send_pass_model.c, regime C.
+                const uint32_t eM = exponent_bits(maxq), eq = exponent_bits(st.q), eb = exponent_bits(ebw);
+                const double B = pow2_f64((int)eM - 1023);
+                // (tried when the full queue's band reaches down to B -- losses widen it -- or once regime B was stopped)
+                if (!((st.q > 0.0) && eM > 66u && eM < 1100u && (eq == eM || eq + 1u == eM) && (maxq - 64.0 * ebw < B) && (x0 > 0.0) &&
+                      (st.tu + st.tu >= tend) && exponent_bits(st.tu) >= eM && eb + 2u <= eM))
+                    return false;
+                const double v = pow2_f64((int)eM - 1 - 1023 - 52), inv_v = pow2_f64(-((int)eM - 1 - 1023 - 52));
+                const double probe = pow2_f64((int)eM - 1 - 1023);
+                const double R0 = (probe + ebw) - probe;  // 1/bw on the grid of v
+                const double errv = ebw - R0;
+                const double span = (D0 + (double)kPass * G) * inv_v;
+                if (!(span < 4.0e18 && R0 > 0.0 && errv != 0.0 && fabs(errv) != 0.5 * v)) return false;
+                Q0i = (int64_t)(st.q * inv_v);
+                D0i = (int64_t)(D0 * inv_v);
+                Gi = (int64_t)(G * inv_v);
+                Ri = (int64_t)(R0 * inv_v);
+                if (!(Gi < Ri)) return false;  // the sender is not faster than the link: not this regime
+                Mi3 = (int64_t)(maxq * inv_v);
+                Bi3 = (int64_t)(B * inv_v);
+                cl3 = errv < 0.0 ? 1 : 0;
+                Ii3 = Ri - cl3;
+                Ci = (Mi3 - Ri) - Q0i + D0i;
+                u = v; R = R0; e = eM - 1u;
+                return true;
+            }()) {
+                regime = 3;
             } else {
                 e = exponent_bits(st.q);
                 const uint32_t eb = exponent_bits(ebw);
@@ -591,6 +632,9 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
             // what the lane keeps of its four positions: accepted / flagged bits, and the queue (before
             // max0) and the accepted count at its first position -- the rest is replayed when needed
             uint32_t acc4 = 0, flag4 = 0;
+            uint32_t up4 = 0, cp4 = 0;   // regime C: accepted packets that land from B up; corrections (2 bits each, +1)
+            int c_before = 0;            // regime C: corrections accumulated in front of this lane
+            int64_t xi_base = 0;
             double x_base = 0.0;
             int j_base = 0;
             if (regime == 1) {
@@ -608,7 +652,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                     for (uint32_t w2 = 0; w2 < wv; w2++) j_base += X->cnt[w2];
                 }
             } else {
-                const bool over = !free_mode && Gi < Ri;  // overdriven and close to full: the token scan decides
+                const bool over = regime == 3 || (!free_mode && Gi < Ri);  // overdriven and close to full: the token scan decides
                 const int k0 = kbase < 0 ? 0 : kbase;
                 int b = 0, N = 0;
                 uint32_t a4 = 0;
@@ -671,7 +715,76 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 }
                 // exact base: x = (Q0 + j R - D0 - k0 G) u in integers, one exact conversion
                 const int64_t xi = Q0i + (int64_t)j_base * Ri - D0i - (int64_t)k0 * Gi;
+                xi_base = xi;
                 x_base = (double)xi * u;
+                if (regime == 3) {
+                    // ---- regime C: decisions and landing sides of the base trajectory, in integers, with their margins
+                    int64_t xk = xi;
+                    int jr = j_base;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bool m = (m4 >> i) & 1u;
+                        const bool a = m && b > 0;
+                        acc4 |= (a ? 1u : 0u) << i;
+                        const int64_t slack = (xk + Ri) - Mi3, land = (xk + Ii3) - Bi3, mar = (int64_t)jr + 2;
+                        const bool f = m && ((slack >= -mar && slack <= mar) || (a && land >= -mar && land <= mar) ||
+                                             (xk - mar <= 0) || (xk + Ri - mar < Bi3 / 2 + 2));
+                        flag4 |= (f ? 1u : 0u) << i;
+                        up4 |= ((a && (xk + Ii3 >= Bi3)) ? 1u : 0u) << i;
+                        if (kbase + i >= 0) {
+                            b = (b - (m ? 1 : 0) > 0 ? b - (m ? 1 : 0) : 0) + (int)((a4 >> i) & 1u);
+                            xk = (a ? xk + Ri : xk) - Gi;
+                            jr += a ? 1 : 0;
+                        }
+                    }
+                    // ---- the parity automaton over the accepted packets: an accept that lands from B up leaves an even
+                    // queue (parity 0), one that lands below flips the parity by kappa = (I + cl) mod 2.  A lane's four
+                    // positions compose to one map on {0, 1} (bit 0: constant, bit 1: the constant / the flip), the
+                    // lanes' maps to an exclusive prefix (six DPP steps), and lane 0 starts from the parity of q.
+                    const uint32_t kap = (uint32_t)((Ii3 + cl3) & 1);
+                    uint32_t fn = 0;  // identity
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if ((acc4 >> i) & 1u) {
+                            if ((up4 >> i) & 1u) fn = 1u;          // constant 0
+                            else fn ^= kap << 1;                   // flip (of the constant, or of the flip)
+                        }
+                    }
+                    uint32_t pre = fn;
+                    auto compose = [](uint32_t first, uint32_t then) -> uint32_t {  // `then` after `first`
+                        return (then & 1u) ? then : ((first & 1u) | ((first ^ then) & 2u));
+                    };
+#pragma unroll
+                    for (int o = 1; o < kWave; o <<= 1) {
+                        const uint32_t prev = (uint32_t)__shfl_up((int)pre, o);
+                        if (lane >= (uint32_t)o) pre = compose(prev, pre);
+                    }
+                    uint32_t excl = (uint32_t)__shfl_up((int)pre, 1);
+                    if (lane == 0) excl = 0;  // identity
+                    uint32_t P = (uint32_t)(Q0i & 1);
+                    P = (excl & 1u) ? ((excl >> 1) & 1u) : (P ^ ((excl >> 1) & 1u));  // parity of the queue in front of this lane
+                    // corrections c' = c - cl of the lane's accepted packets, and their sum
+                    int csum = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if ((acc4 >> i) & 1u) {
+                            int c;
+                            if ((up4 >> i) & 1u) { c = (int)((P + (uint32_t)Ii3) & 1u); P = 0; }
+                            else { c = cl3; P ^= kap; }
+                            cp4 |= (uint32_t)((c - cl3) + 1) << (2 * i);  // 0, 1, 2 = -1, 0, +1
+                            csum += c - cl3;
+                        } else {
+                            cp4 |= 1u << (2 * i);
+                        }
+                    }
+                    int cincl = csum;
+#pragma unroll
+                    for (int o = 1; o < kWave; o <<= 1) {
+                        const int prev = __shfl_up(cincl, o);
+                        if (lane >= (uint32_t)o) cincl += prev;
+                    }
+                    c_before = cincl - csum;  // corrections accumulated in front of this lane
+                } else {
                 double x = x_base;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -691,6 +804,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                         if (over) b = (b - (m ? 1 : 0) > 0 ? b - (m ? 1 : 0) : 0) + (int)((a4 >> i) & 1u);
                         x = (a ? sx : x) - G;  // exact: multiples of u below 2^(e+1)
                     }
+                }
                 }
             }
             // ---- the pass stops at the first position that is past the MI end or breaks a precondition
@@ -721,6 +835,8 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
             // q hovering around a power of two (or a queue that keeps running empty) breaks a pass after a
             // few packets every time: send the next stretch by the accept chain, which has no such
             // precondition, then try again
+            // ... unless regime C has not had its chance yet (regime B stopped at the edge of its binade: the next pass
+            // tries the two-binade form)
             if (stopped_by_flag && ncommit < 32u) chain_left = 4u;
             if (ncommit) {
                 if (TRACE && (int64_t)((uint64_t)st.a + st.d + ncommit) > D.trace_stride) st.flags |= PCC_FLAG_TRACE_OVERRUN;
@@ -729,11 +845,14 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 double last_q = 0.0, last_t = 0.0;
                 bool have_last = false;
                 double x = x_base;
+                int64_t xt = xi_base + c_before;  // regime C: the true queue in units of v
                 uint32_t j = (uint32_t)j_base;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const uint32_t p = 4u * glane + (uint32_t)i;
                     const bool a = (acc4 >> i) & 1u;
+                    const int cpr = (int)((cp4 >> (2 * i)) & 3u) - 1;  // regime C: this packet's correction c' (0 elsewhere)
+                    if (regime == 3) x = (double)xt * u;  // exact: even from B up
                     if (p >= skip && p < p_stop) {
                         const uint32_t kk = p - skip;             // packets of the pass before this one
                         const double tki = t0 + (double)kk * G;   // exact
@@ -747,10 +866,12 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                             have_last = true;
                             last_t = tki;
                             last_q = regime == 1 ? ebw + 0.0 : (a ? x + R : x);  // ns:75-82
+                            if (regime == 3) last_q = (double)(a ? xt + Ri + cpr : xt) * u;  // = fl(qcur + 1/bw), exactly
                         }
                     }
                     if (kbase + i >= 0) {
                         x = (a ? x + R : x) - G;
+                        xt = (a ? xt + Ri + cpr : xt) - Gi;
                         j += a ? 1u : 0u;
                     }
                 }
@@ -770,7 +891,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                         if (X->has_last[w2]) { st.q = X->last_q[w2]; st.tu = X->last_t[w2]; break; }
                 }
                 if (prof_counters(D) && lane == 0 && writer) {
-                    const int c = regime == 1 ? 0 : (!free_mode && Gi < Ri) ? 1 : 2;
+                    const int c = regime == 1 ? 0 : (regime == 3 || (!free_mode && Gi < Ri)) ? 1 : 2;
                     atomicAdd(&D.pass_stats[c], 1ull);
                     atomicAdd(&D.pass_stats[4 + c], (unsigned long long)ncommit);
                     atomicAdd(&D.pass_stats[13], (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));

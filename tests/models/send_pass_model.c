@@ -38,7 +38,7 @@ typedef struct {
 } sstate_t;
 
 typedef struct {
-    uint64_t pass_a, pass_b, pass_s, pk_a, pk_b, pk_s, b_empty_commit;
+    uint64_t pass_a, pass_b, pass_s, pk_a, pk_b, pk_s, b_empty_commit, pass_c, pk_c;
     uint64_t why[8];
 } mstats_t;
 
@@ -80,6 +80,8 @@ static int g_lanes = 64;
 #define LANES g_lanes
 #define PASS (g_lanes * PER_LANE)
 #define MAX_PASS (MAX_LANES * PER_LANE)
+static int g_fuzz_straddle = 0;
+void pcc_model_fuzz_straddle(int on) { g_fuzz_straddle = on; }
 int pcc_model_set_lanes(int lanes) {
     if (lanes < 1 || lanes > MAX_LANES) return -1;
     g_lanes = lanes;
@@ -150,6 +152,106 @@ static void model_mi(sstate_t *s, double gap, double end, double dl, double maxq
                 if (ok) regime = 2;
             }
         }
+        /* ---- C: "full queue straddling a power of two".  maxq sits just above B = 2^E (maxq - 1/bw < B <= maxq), so the
+         * full queue lives in TWO binades: values below B are multiples of v = ulp(B) / 2, values from B up multiples of
+         * 2 v, and fl(qcur + 1/bw) rounds to whichever grid its result lands on.  In units of v, with 1/bw = (I + f) v,
+         * 0 < f < 1, f != 1/2:  a result below B is n + I + cl (cl = [f > 1/2]); a result from B up is n + I rounded up
+         * to even.  Against the constant increment R0 = I + cl the accept of packet j is off by c'_j in {-1, 0, +1}, and
+         * c'_j follows from where the result lands and from the parity of the queue before (a two-state automaton).  The
+         * pass takes the accept/drop decisions and the landing sides from the base trajectory (increment R0 everywhere),
+         * which differs from the true one by at most j units of v after j accepts -- a position whose decision or
+         * landing side is closer than that to its threshold ends the pass (flag) -- then runs the automaton over the
+         * accepted packets and adds the accumulated corrections to the queue every packet sees.  */
+        int regime_c = 0;
+        if (ok_t && regime != 1) {
+            const uint32_t eM = exp_bits(maxq), eq = exp_bits(s->q), eb = exp_bits(ebw);
+            const double B = ldexp(1.0, (int)eM - 1023);
+            const double x0 = s->q - D0;
+            int ok = (s->q > 0.0) && eM > 66 && eM < 1100 && (eq == eM || eq + 1 == eM) && (maxq - 64.0 * ebw < B) && (x0 > 0.0) &&
+                     (s->tu + s->tu >= tend) && exp_bits(s->tu) >= eM && eb + 1 <= eM - 1;
+            if (ok) {
+                const double v = ldexp(1.0, (int)eM - 1 - 1023 - 52), inv_v = ldexp(1.0, -((int)eM - 1 - 1023 - 52));
+                const double probe = ldexp(1.0, (int)eM - 1 - 1023);
+                const double R0 = (probe + ebw) - probe;          /* 1/bw on the grid of v */
+                const double errv = ebw - R0;
+                const double span = (D0 + (double)PASS * G) * inv_v;
+                ok = span < 4.0e18 && R0 > 0.0 && errv != 0.0 && fabs(errv) != 0.5 * v;
+                if (ok) {
+                    const int64_t Q0v = (int64_t)(s->q * inv_v), D0v = (int64_t)(D0 * inv_v), Gv = (int64_t)(G * inv_v);
+                    const int64_t Rv = (int64_t)(R0 * inv_v), Mv = (int64_t)(maxq * inv_v), Bv = (int64_t)(B * inv_v);
+                    const int64_t cl = errv < 0.0 ? 1 : 0, Iv = Rv - cl;
+                    if (!(Gv < Rv)) ok = 0;                      /* the sender is not faster than the link: not this regime */
+                    if (ok) {
+                        const int64_t C = (Mv - Rv) - Q0v + D0v;
+                        uint8_t m_k[MAX_PASS], ex_k[MAX_PASS], acc_k[MAX_PASS], flag_k[MAX_PASS], up_k[MAX_PASS];
+                        int64_t xi_k[MAX_PASS];
+                        /* decisions of the base trajectory: the token bucket of regime B, serially here (the kernel: the scan) */
+                        int64_t j = 0;
+                        for (uint32_t p = 0; p < (uint32_t)PASS; p++) {
+                            const int32_t k = (int32_t)p - (int32_t)skip;
+                            const double tk = t0 + (double)(k < 0 ? 0 : k) * G;
+                            ex_k[p] = k >= 0 && tk < lim;
+                            m_k[p] = ex_k[p] && !loss[s->sent + (k < 0 ? 0 : k)];
+                            const int64_t kk = k < 0 ? 0 : k;
+                            const int64_t xi = Q0v + j * Rv - D0v - kk * Gv;   /* base queue this packet sees */
+                            xi_k[p] = xi;
+                            /* tokens: accepted iff j < floor((C + k G) / R) + 1  <=>  xi + R <= M */
+                            const int a = m_k[p] && (xi + Rv <= Mv);
+                            acc_k[p] = (uint8_t)a;
+                            int f = 0;
+                            if (m_k[p]) {
+                                const int64_t slack = (xi + Rv) - Mv, land = (xi + Iv) - Bv;
+                                const int64_t mar = j + 2;
+                                if (slack >= -mar && slack <= mar) f = 1;                      /* decision too close to call */
+                                if (a && land >= -mar && land <= mar) f = 1;                   /* landing side too close to call */
+                                if (xi - mar <= 0) f = 1;                                      /* the queue runs empty */
+                                if (xi + Rv - mar < Bv / 2 + 2) f = 1;                         /* below the lower binade */
+                            }
+                            flag_k[p] = (uint8_t)f;
+                            up_k[p] = (uint8_t)(a && (xi + Iv >= Bv));
+                            if (a && k >= 0) j++;
+                        }
+                        /* commit the prefix before the first flagged packet: the automaton over its accepted packets */
+                        uint32_t ncommit = 0;
+                        int64_t P = Q0v & 1, Cacc = 0;
+                        double last_q = 0, last_t = 0;
+                        int any = 0;
+                        for (uint32_t p = skip; p < (uint32_t)PASS; p++) {
+                            if (!ex_k[p] || flag_k[p]) break;
+                            const uint32_t k = p - skip;
+                            const double tk = t0 + (double)k * G;
+                            const int64_t xt = xi_k[p] + Cacc;                                  /* the true queue this packet sees */
+                            const double qc = py_max0((double)xt * v);
+                            rec_t r;
+                            r.lat = dl + qc;
+                            r.t1 = tk + r.lat;
+                            if (acc_k[p]) {
+                                int64_t c;
+                                if (up_k[p]) { c = (P + Iv) & 1; P = 0; }
+                                else { c = cl; P ^= (Iv + cl) & 1; }
+                                Cacc += c - cl;
+                                acc[s->na++] = r;
+                                last_q = (double)(xi_k[p] + Rv + Cacc) * v;                       /* = xt + I + c */
+                                last_t = tk; any = 1;
+                            } else {
+                                drp[s->nd++] = r;
+                                if (m_k[p]) { last_q = (double)xt * v; last_t = tk; any = 1; }
+                            }
+                            ncommit++;
+                        }
+                        if (ncommit) {
+                            if (any) { s->q = last_q; s->tu = last_t; }
+                            s->t = (t0 + (double)(ncommit - 1) * G) + gap;
+                            s->sent += ncommit;
+                            st->pass_c++; st->pk_c += ncommit;
+                            serial_len = 8;
+                            regime_c = 1;
+                        }
+                    }
+                }
+            }
+        }
+        if (regime_c) continue;
         if (regime == 1) {
             /* ---- A: latency dl, accepted unless lost at random */
             uint32_t n = 0;
@@ -337,18 +439,26 @@ long pcc_model_fuzz(long n_cases, uint64_t seed, uint64_t *stats_out /* [16] */)
     for (long c = 0; c < n_cases; c++) {
         const double bw = 100.0 + 400.0 * fz_unit();
         const double dl = 0.05 + 0.45 * fz_unit();
-        const double queue = (double)(1 + (long)exp(8.0 * fz_unit()));
+        double queue = (double)(1 + (long)exp(8.0 * fz_unit()));
+        const int straddle = g_fuzz_straddle && (fz_next() & 1);
+        if (straddle) {   /* a queue limit just above a power of two: the full queue straddles it */
+            const double B = ldexp(1.0, (int)(fz_next() % 7) - 2);       /* 0.25 .. 16 s */
+            queue = ceil(B * bw + fz_unit() * 0.9);
+            if (queue < 2.0) queue = 2.0;
+        }
         const double lr = (fz_next() & 7) == 0 ? 0.0 : 0.05 * fz_unit();
         const double maxq = queue / bw, ebw = 1.0 / bw;
         double rate = (fz_next() & 3) == 0 ? 1000.0 : 40.0 + 960.0 * fz_unit();
+        if (straddle) rate = bw * (1.02 + 0.9 * fz_unit());            /* overdriven: the queue fills and stays full */
+        if (rate > 1000.0) rate = 1000.0;
         if ((fz_next() & 7) == 0) rate = bw * (0.98 + 0.04 * fz_unit());
         const double gap = 1.0 / rate;
         /* a state as an episode would leave it: run the plain recurrence for a random while first */
         sstate_t s0;
         memset(&s0, 0, sizeof s0);
         s0.t = gap;
-        const double warm_rate = 40.0 + 960.0 * fz_unit();
-        const double warm_end = fz_unit() * fz_unit() * 400.0;
+        const double warm_rate = straddle ? rate : 40.0 + 960.0 * fz_unit();
+        const double warm_end = straddle ? 4.0 * maxq + 2.0 + fz_unit() * 100.0 : fz_unit() * fz_unit() * 400.0;
         double q = 0, tu = 0, t = 1.0 / warm_rate;
         long guard = 0;
         while (t < warm_end && guard++ < 2000000) {
@@ -377,6 +487,7 @@ long pcc_model_fuzz(long n_cases, uint64_t seed, uint64_t *stats_out /* [16] */)
         stats_out[0] = st.pass_a; stats_out[1] = st.pass_b; stats_out[2] = st.pass_s;
         stats_out[3] = st.pk_a; stats_out[4] = st.pk_b; stats_out[5] = st.pk_s; stats_out[6] = st.b_empty_commit;
         for (int i = 0; i < 8; i++) stats_out[7 + i] = st.why[i];
+        stats_out[14] = st.pass_c; stats_out[15] = st.pk_c;
     }
     free(aa); free(ad); free(ba); free(bd); free(loss);
     return bad;

@@ -817,6 +817,32 @@ def test_grouped_env_is_the_same_envs_on_several_streams():
     one.close(); grp.close()
 
 
+def test_queue_limits_just_above_a_power_of_two_match_oracle():
+    """Regime C of the wave passes: envs whose queue limit sits just above a power of two (0.25 .. 16 s) and whose sender
+    overdrives the link -- the full queue straddles the power of two, fl(qcur + 1/bw) rounds on two grids -- against the
+    oracle, every column; half of them sent one env per wavefront from the first interval on."""
+    n_envs, n_steps, seed = 512, 160, 41
+    rs = np.random.RandomState(seed)
+    bw = rs.uniform(100, 500, n_envs)
+    B = 2.0 ** rs.randint(-2, 5, n_envs)
+    queue = np.maximum(2.0, np.ceil(B * bw + rs.uniform(0, 0.9, n_envs)))
+    dl = rs.uniform(0.05, 0.5, n_envs)
+    loss = np.where(rs.rand(n_envs) < 0.2, 0.0, rs.uniform(0, 0.05, n_envs))
+    rate0 = np.minimum(1000.0, bw * rs.uniform(1.05, 1.6, n_envs))
+    acts = rs.uniform(-0.4, 1.0, (n_envs, n_steps))
+    ref = oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=seed, params=np.stack([bw, dl, queue, loss, rate0], 1))
+    for knobs in (dict(), dict(heavy_predict=0.0, team_predict=1e18, heavy_item_packets=0.0)):
+        env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=False,
+                                           link_params=(bw, dl, queue, loss, rate0))
+        env.set_tuning(**knobs)
+        env.reset()
+        steps, obs, done = run_gpu(env, acts, n_steps)
+        assert np.array_equal(steps[..., :3], ref["steps"][..., :3]), knobs
+        assert np.array_equal(steps, ref["steps"]), knobs
+        assert np.array_equal(obs, ref["obs"].astype(np.float32)), knobs
+        env.close()
+
+
 def test_long_episode_matches_oracle():
     """The near-group tolerance (1e-12 relative) is an assumption about the size of the clock: 20 000-step episodes
     (clocks up to ~1e5 s, 50 x the default episode) still match the oracle bit for bit, and no env raises

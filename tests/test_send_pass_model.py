@@ -23,6 +23,7 @@ def model():
     L.pcc_model_fuzz.argtypes = [ctypes.c_long, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     L.pcc_model_episodes.restype = ctypes.c_long
     L.pcc_model_set_lanes.argtypes = [ctypes.c_int]
+    L.pcc_model_fuzz_straddle.argtypes = [ctypes.c_int]
     return L
 
 
@@ -49,3 +50,18 @@ def test_interval_starts_of_real_episodes(model, lanes):
     bad = model.pcc_model_episodes(48, 120, 7, 0, 64, stats, hist)
     assert bad == 0
     assert sum(hist) > 0
+
+
+def test_fuzzed_queue_limits_just_above_a_power_of_two(model):
+    """Regime C (heavy_mi: the full queue straddles a power of two, two rounding grids): half of the fuzzed links get a
+    queue limit just above 0.25 .. 16 s and an overdriving sender; the passes must still equal the plain recurrence, and
+    the regime must carry packets."""
+    assert model.pcc_model_set_lanes(64) == 0
+    model.pcc_model_fuzz_straddle(1)
+    try:
+        stats = (ctypes.c_uint64 * 16)()
+        bad = model.pcc_model_fuzz(20000, 4242, stats)
+    finally:
+        model.pcc_model_fuzz_straddle(0)
+    assert bad == 0
+    assert stats[14] > 1000 and stats[15] > 100 * stats[14]     # regime-C passes, well filled
