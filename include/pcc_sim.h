@@ -179,7 +179,10 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     many predicted packets; default 2048, 0 = one env per item */,
        PCC_TUNE_RETIRE_WIDE_PREDICT = 11 /* retire half: an env predicted above this many packets per interval is retired by
                                     16 lanes (whole-list and half sums side by side), the others by 8; default 1024,
-                                    0 = every env by 16, >= 1e9 = every env by 8 */ };
+                                    0 = every env by 16, >= 1e9 = every env by 8 */,
+       PCC_TUNE_LIST_MIN_ENVS = 12 /* batches of fewer envs are stepped without work lists, the envs in index order (a small
+                                    batch's step is a chain of dependent loads, and the lists add three); default 8192,
+                                    0 = always with lists */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* Sizes of the shared ring pools (see pcc_create): tiers 1, 2, 3 get a slot for one sender in div1, div2, div3 (defaults

@@ -3226,6 +3226,7 @@ struct pcc_sim {
     uint32_t ring_capacity;
     bool restarts_pending;  // a retire launch may have left envs in the restart list (their warm-up intervals are due)
     bool read_has_restarts; // the list buffer read_buf was filed by a retire launch that resets finished envs (restart list)
+    uint32_t list_min_envs; // batches below this size are stepped without work lists (index order)
 };
 
 namespace {
@@ -3290,7 +3291,10 @@ dim3 lane_grid(const Dev &d) { return dim3((unsigned)((d.n + kWave - 1) / kWave)
 int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64, hipStream_t st) {
     const Dev &d = sim->d;
     const bool tr = d.rng_mode == PCC_RNG_TRACE;
-    const int read_buf = warm ? -1 : sim->read_buf;
+    // small batches go without work lists (items = the envs in index order): at 4 096 envs of a few packets each the
+    // launch IS its chain of dependent loads, and the lists put three more in front (counts -> list -> state)
+    const bool lists = sim->d.n >= (int64_t)sim->list_min_envs;
+    const int read_buf = (warm || !lists) ? -1 : sim->read_buf;
     // items <= chunks + heavy envs <= about n; more wavefronts than items would only take a failed claim each
     int64_t waves = (int64_t)sim->cu_count * d.send_waves;
     const int64_t chunks = (d.n + d.send_envs_per_wave - 1) / d.send_envs_per_wave;
@@ -3302,7 +3306,7 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
     // restart items can only be in lists that a retire launch with `restart` filed
     const bool rs = sim->read_has_restarts && read_buf >= 0;
 #define PCC_LAUNCH_SEND(NS_, TR_, RS_)                                                                                      \
-    hipLaunchKernelGGL((send_kernel<NS_, TR_, RS_>), sgrid, sblock, 0, st, d, read_buf, sim->fill_buf, warm, warm_mi, gate, \
+    hipLaunchKernelGGL((send_kernel<NS_, TR_, RS_>), sgrid, sblock, 0, st, d, read_buf, lists ? sim->fill_buf : -1, warm, warm_mi, gate, \
                        actions, actions_f64)
     if (d.ns == 1) {
         if (tr) { if (rs) PCC_LAUNCH_SEND(1, true, true); else PCC_LAUNCH_SEND(1, true, false); }
@@ -3324,10 +3328,11 @@ int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int
     const Dev &d = sim->d;
     // workgroups: 8 envs each at 16 lanes per env, 16 at 8 lanes -- which envs go which way is decided on the device
     // (class counts), so the grid covers the worst case plus the one workgroup the split can leave partly filled
-    const int read = (warm || !d.retire_sorted) ? -1 : sim->read_buf;  // the lists this step's send launch read
+    const bool lists = d.n >= (int64_t)sim->list_min_envs;
+    const int read = (warm || !d.retire_sorted || !lists) ? -1 : sim->read_buf;  // the lists this step's send launch read
     const int64_t per_block = read >= 0 ? 8 : kRetireMaxPerBlock;
     const dim3 grid((unsigned)((d.n + per_block - 1) / per_block + (read >= 0 ? 1 : 0)));
-    const int fill = warm ? -1 : sim->fill_buf;
+    const int fill = (warm || !lists) ? -1 : sim->fill_buf;
     if (d.ns == 1)
         hipLaunchKernelGGL((retire_kernel<1, false>), grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm,
                            gate, restart, obs_out, reward_out, done_out, steps_out, nullptr, 0);
@@ -3335,7 +3340,7 @@ int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int
         hipLaunchKernelGGL((retire_kernel<2, false>), grid, dim3(kRetireBlock), 0, st, d, read, fill, warm, warm_mi, last_warm,
                            gate, restart, obs_out, reward_out, done_out, steps_out, nullptr, 0);
     const int rc = check_hip(hipGetLastError(), "retire kernel launch");
-    if (rc == PCC_OK && !warm) {
+    if (rc == PCC_OK && !warm && lists) {
         sim->read_buf = sim->fill_buf;
         sim->fill_buf ^= 1;
         sim->read_has_restarts = restart != 0;  // the buffer just filed may hold a restart list
@@ -3381,7 +3386,7 @@ int launch_reset(pcc_sim_t *sim, const uint8_t *mask, int use_done, int gate, fl
 // send half can take such items: not with the congestion-window option (no wave path) or the latency-noise
 // option (no send half) -- those keep the gated reset launches after the step.
 bool restarts_in_step(const pcc_sim_t *sim, int auto_reset) {
-    return auto_reset && !sim->lockstep && !sim->d.use_cwnd && !sim->d.use_noise;
+    return auto_reset && !sim->lockstep && !sim->d.use_cwnd && !sim->d.use_noise && sim->d.n >= (int64_t)sim->list_min_envs;
 }
 
 // What is still owed to the envs of the restart list -- new links, fresh state, the two warm-up intervals -- is
@@ -3544,6 +3549,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.cls_list = static_cast<uint32_t *>(sim->list_blob);
     sim->read_buf = -1;
     sim->fill_buf = 0;
+    sim->list_min_envs = 8192;
     sim->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = sim;
     return PCC_OK;
@@ -3654,6 +3660,12 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             return PCC_OK;
         case PCC_TUNE_HEAVY_PREDICT: sim->d.heavy_predict = value; return PCC_OK;
         case PCC_TUNE_TEAM_PREDICT: sim->d.team_predict = value; return PCC_OK;
+        case PCC_TUNE_LIST_MIN_ENVS:
+            if (!(value >= 0.0 && value <= 4e9)) return fail(PCC_EINVAL, "list_min_envs out of range");
+            if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_tuning(LIST_MIN_ENVS) between pcc_step_send and pcc_step_retire");
+            sim->list_min_envs = (uint32_t)value;
+            sim->read_buf = -1;  // (whatever was filed is dropped: the next step walks the envs in index order)
+            return PCC_OK;
         case PCC_TUNE_RETIRE_WIDE_PREDICT:
             if (!(value >= 0.0)) return fail(PCC_EINVAL, "retire_wide_predict out of range");
             sim->d.retire_wide_predict = value >= 1e9 ? 1e9f : (float)value;

@@ -52,6 +52,10 @@ class BatchedNetworkEnv(object):
     overwritten by the next call (pass ``new_tensors=True`` to get fresh ones each call).
     """
 
+    # batches below this many envs are stepped without work lists (None: the library's default, 8192; the GPU tests set
+    # 0 here so that small batches exercise the work-list paths too)
+    DEFAULT_LIST_MIN_ENVS = None
+
     def __init__(self, n_envs, device="cuda", history_len=None, features=None, seed=0, n_senders=1,
                  link_params=None, env_gid_base=0, ring_capacity=0, auto_reset=True, delta_scale=None,
                  max_steps=MAX_STEPS, record_steps=False, new_tensors=False, use_cwnd=False, latency_noise=None,
@@ -88,6 +92,8 @@ class BatchedNetworkEnv(object):
             # (div1, div2, div3): tier k of the in-flight ring pools holds a slot for one sender in div_k (defaults 2, 8, 32
             # fit U(-1, 1) policies; a policy that saturates every link wants smaller divisors -- PCC_FLAG_POOL_EXHAUSTED says so)
             check(L.pcc_set_ring_pools(self._h, *[int(v) for v in ring_pools]))
+        if self.DEFAULT_LIST_MIN_ENVS is not None:
+            check(L.pcc_set_tuning(self._h, 12, float(self.DEFAULT_LIST_MIN_ENVS)))
         check(L.pcc_set_delta_scale(self._h, float(DELTA_SCALE if delta_scale is None else delta_scale)))
         check(L.pcc_set_max_steps(self._h, self.max_steps))
         # the reference's dormant USE_CWND engine option (ns:54): window-limited sending, actions
@@ -173,10 +179,10 @@ class BatchedNetworkEnv(object):
         self._trace = t
 
     def set_tuning(self, round_packets=None, takeover_lanes=None, send_envs_per_wave=None, heavy_predict=None,
-                   send_waves=None, team_predict=None, heavy_item_packets=None, retire_wide_predict=None):
+                   send_waves=None, team_predict=None, heavy_item_packets=None, retire_wide_predict=None, list_min_envs=None):
         """Performance knobs of the send half (results do not depend on them); see pcc_set_tuning."""
         for key, value in ((2, round_packets), (3, takeover_lanes), (4, send_envs_per_wave), (5, heavy_predict),
-                           (8, send_waves), (9, team_predict), (10, heavy_item_packets), (11, retire_wide_predict)):
+                           (8, send_waves), (9, team_predict), (10, heavy_item_packets), (11, retire_wide_predict), (12, list_min_envs)):
             if value is not None:
                 check(self._L.pcc_set_tuning(self._h, key, float(value)))
 

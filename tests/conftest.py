@@ -17,3 +17,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def work_lists_for_small_batches():
+    """The library steps batches below 8192 envs without work lists (index order).  The parity tests run small batches and
+    are there for the work-list machinery -- classes, team items, batched wave-path items, the 8- and 16-lane retire
+    workgroups, restart items -- so they switch the lists on for every batch size; the tests of the small-batch path
+    itself set BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS back to None."""
+    import pcc_rl_amd
+    old = pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS
+    pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = 0
+    yield
+    pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = old

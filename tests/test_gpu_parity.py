@@ -843,6 +843,40 @@ def test_queue_limits_just_above_a_power_of_two_match_oracle():
         env.close()
 
 
+@pytest.mark.parametrize("n_senders", [1, 2])
+def test_small_batch_path_without_work_lists(n_senders):
+    """Batches below 8192 envs are stepped in index order, without work lists (the library's default, which the other
+    tests switch off): two episodes with the auto-reset between them against the oracle, every column; then a masked
+    reset takes the batch out of lockstep and the following auto-resets (gated reset launches here, not restart items)
+    must leave every env in its own episode."""
+    pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = None
+    n_envs, seed, T = 300, 9, 20
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, n_senders=n_senders, record_steps=True, auto_reset=True,
+                                       max_steps=T)
+    env.reset()
+    rs = np.random.RandomState(seed)
+    shape = (n_envs, 2 * T) if n_senders == 1 else (n_envs, 2 * T, 2)
+    acts = rs.uniform(-1, 1.5, shape)
+    steps, obs, done = run_gpu(env, acts, 2 * T)
+    ref1 = oracle.run_batch(acts[:, :T], n_senders=n_senders, rng_mode=oracle.RNG_PHILOX, seed=seed, want_obs=False)
+    ref2 = oracle.run_batch(acts[:, T:], n_senders=n_senders, rng_mode=oracle.RNG_PHILOX, seed=seed, n_episodes=2, want_obs=False)
+    assert np.array_equal(steps[..., :T, :], ref1["steps"])
+    assert np.array_equal(steps[..., T:, :], ref2["steps"])
+    # out of lockstep: every third env restarts now, everybody steps on through two more boundaries
+    mask = torch.arange(n_envs, device=DEV) % 3 == 0
+    env.reset(mask)
+    for t in range(2 * T + 3):
+        env.step(torch.zeros((n_envs, n_senders), device=DEV))
+    torch.cuda.synchronize()
+    env.check_flags()
+    st = env.state("steps").cpu().numpy()
+    ep = env.state("episode").cpu().numpy()
+    m = mask.cpu().numpy()
+    assert (st[m] == 3).all() and (st[~m] == 3).all()          # (2T + 3) steps after a boundary everybody shares modulo T
+    assert (ep[~m] == ep[~m][0]).all() and (ep[m] == ep[~m][0] + 1).all()      # the masked envs are one episode ahead
+    env.close()
+
+
 def test_long_episode_matches_oracle():
     """The near-group tolerance (1e-12 relative) is an assumption about the size of the clock: 20 000-step episodes
     (clocks up to ~1e5 s, 50 x the default episode) still match the oracle bit for bit, and no env raises
