@@ -200,7 +200,7 @@ int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t di
  * second moves the window like the first moves the rate (x (1 + a*delta_scale) or / (1 - a*
  * delta_scale)), truncated to an integer and clamped to [4, 5000] (ns:33-34, 283-289).  One sender
  * per env only; pcc_reset must follow.  This path is lane-serial (no wave path); it is exact like
- * the others. */
+ * the others.  It combines with pcc_set_latency_noise (see there). */
 int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable);
 
 /* The reference's other dormant engine option, USE_LATENCY_NOISE / MAX_LATENCY_NOISE (ns:51-52; off /
@@ -213,8 +213,10 @@ int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable);
  * pcc_step_send / pcc_step_retire split).  Exact like the other paths (golden sets noise_*), and slow:
  * it exists for parity with the reference's flag, not for throughput.  Uniforms: PCC_RNG_TRACE replays
  * the trace in draw order (three draws per packet); PCC_RNG_PHILOX numbers ALL draws of an interval
- * 0, 1, 2, ... in event order (word index of the interval's Philox stream).  One sender per env, not
- * together with pcc_set_cwnd_mode; pcc_reset must follow.  More events in flight than ring_capacity, or
+ * 0, 1, 2, ... in event order (word index of the interval's Philox stream).  One sender per env.  Together with
+ * pcc_set_cwnd_mode (the reference's two flags are module globals and apply together): a SEND goes out only while
+ * fewer than cwnd events are in the heap, a blocked one still takes its noise draw and its loss draw, actions are
+ * [N][2].  pcc_reset must follow.  More events in flight than ring_capacity, or
  * more acknowledgements in one interval, raise PCC_FLAG_RING_OVERFLOW. */
 int pcc_set_latency_noise(pcc_sim_t *sim, int enable, double max_noise);
 

@@ -2253,7 +2253,7 @@ struct NoiseOut {
 
 // one monitor interval of env i, by one lane: ns:123-178 with the option on
 __device__ __noinline__ NoiseOut noise_engine(const Dev &D, int64_t i, double start, double end, double rate, double nsend,
-                                              uint32_t mi) {
+                                              uint32_t mi, uint32_t cwnd /* USE_CWND on as well: the window; else 0xFFFFFFFF */) {
     const double dl = D.env[i].dl, lr = D.env[i].lr, maxq = D.env[i].maxq, ebw = D.env[i].ebw;
     double q = D.env[i].q, tu = D.env[i].tu;
     const uint32_t episode = D.env[i].episode - 1;
@@ -2296,7 +2296,11 @@ __device__ __noinline__ NoiseOut noise_engine(const Dev &D, int64_t i, double st
             }
         } else {  // SEND (ns:155-175)
             now = nsend;
-            o.sent++;
+            // USE_CWND as well (ns:158-160): the packet leaves only while fewer than cwnd are unacknowledged -- every
+            // packet in flight is exactly one event of the heap -- but a blocked SEND still takes its noise draw and
+            // passes through the link's queue and loss draw (ns:170-175 are outside the `if`)
+            const bool can_send = hn < cwnd;
+            o.sent += can_send ? 1u : 0u;
             nsend = now + 1.0 / rate;  // ns:161
             const double qd = max0(q - (now - tu));
             double ll = dl + qd;
@@ -2312,8 +2316,10 @@ __device__ __noinline__ NoiseOut noise_engine(const Dev &D, int64_t i, double st
             double2 nv;
             nv.x = now + ll;
             nv.y = dropped ? -lat : lat;
-            if (hn < D.noise_cap) heap_push(H, hn, nv);
-            else o.flags |= PCC_FLAG_RING_OVERFLOW;
+            if (can_send) {
+                if (hn < D.noise_cap) heap_push(H, hn, nv);
+                else o.flags |= PCC_FLAG_RING_OVERFLOW;
+            }
         }
     }
     D.env[i].heap_n = hn;
@@ -2465,19 +2471,29 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
     if constexpr (NOISE) {
         // the whole interval in the lead lane: rate action (ns:235-241; there is no send half with this option), event loop
         double rate = D.snd[i].rate;
+        uint32_t cw = D.use_cwnd ? D.env[i].cwnd : 0xFFFFFFFFu;
         if (!warm) {
-            double delta = actions_f64 ? ((const double *)actions)[i] : (double)((const float *)actions)[i];
+            const int64_t ar = D.use_cwnd ? 2 * i : i;  // USE_CWND as well: [rate action, cwnd action] per env
+            double delta = actions_f64 ? ((const double *)actions)[ar] : (double)((const float *)actions)[ar];
             if (delta != delta) { delta = 0.0; flags |= PCC_FLAG_BAD_ACTION; }
             delta *= D.delta_scale;
             rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
             if (rate > kMaxRate) rate = kMaxRate;
             if (rate < kMinRate) rate = kMinRate;
+            if (D.use_cwnd) {  // apply_cwnd_delta + set_cwnd: ns:243-249, 283-289
+                double dc = actions_f64 ? ((const double *)actions)[ar + 1] : (double)((const float *)actions)[ar + 1];
+                if (dc != dc) { dc = 0.0; flags |= PCC_FLAG_BAD_ACTION; }
+                dc *= D.delta_scale;
+                const double c = dc >= 0.0 ? (double)cw * (1.0 + dc) : (double)cw / (1.0 - dc);
+                cw = c >= 5000.0 ? 5000u : (c < 4.0 ? 4u : (uint32_t)c);  // int(), then [MIN_CWND, MAX_CWND] (ns:33-34)
+                if (lead) D.env[i].cwnd = cw;
+            }
         }
         noise_rate = rate;
         NoiseOut o;
         o.now = start; o.nsend = nsend[0]; o.q = 0.0; o.tu = 0.0; o.sent = o.acked = o.lost = o.flags = 0;
         if (lead) {
-            o = noise_engine(D, i, start, end, rate, nsend[0], warm ? warm_mi : steps + 2);
+            o = noise_engine(D, i, start, end, rate, nsend[0], warm ? warm_mi : steps + 2, cw);
             D.snd[i].rate = rate;
             D.env[i].q = o.q; D.env[i].tu = o.tu;
         }
@@ -3744,7 +3760,6 @@ int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t di
 int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     if (enable && sim->d.ns != 1) return fail(PCC_EINVAL, "the congestion-window option supports one sender per env");
-    if (enable && sim->d.use_noise) return fail(PCC_EINVAL, "the latency-noise and congestion-window options cannot be combined");
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_cwnd_mode between pcc_step_send and pcc_step_retire");
     sim->d.use_cwnd = enable ? 1 : 0;
     sim->ever_reset = false;  // in-flight accounting differs: a reset must follow
@@ -3756,7 +3771,6 @@ int pcc_set_latency_noise(pcc_sim_t *sim, int enable, double max_noise) {
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_latency_noise between pcc_step_send and pcc_step_retire");
     if (enable) {
         if (sim->d.ns != 1) return fail(PCC_EINVAL, "the latency-noise option supports one sender per env");
-        if (sim->d.use_cwnd) return fail(PCC_EINVAL, "the latency-noise and congestion-window options cannot be combined");
         if (!(max_noise >= 1.0) || !(max_noise <= 16.0)) return fail(PCC_EINVAL, "max_noise must be in [1, 16] (the reference: 1.1)");
         if (!sim->noise_blob) {
             DeviceGuard guard(sim->device);

@@ -341,6 +341,9 @@ def main():
         gen_single(ns, "noise_fixed_lossy", [7], uniform_pm1, fixed=(300, 0.1, 50, 0.5, 400.0), n_steps=200, noise=True)
         gen_single(ns, "noise_fixed_deepq", [8], uniform_0_2, fixed=(100, 0.05, 2981, 0.0, 150.0), n_steps=200,
                    noise=True)
+        # both dormant options at once (module globals: they apply together like they apply alone)
+        gen_single(ns, "cwnd_noise_pm1", range(700, 706), uniform_pm1_pairs, cwnd=True, noise=True)
+        gen_single(ns, "cwnd_noise_grow", range(720, 723), rate_pm1_cwnd_up, n_steps=200, cwnd=True, noise=True)
     finally:
         os.chdir(cwd)
 

@@ -692,6 +692,56 @@ def test_use_latency_noise_goldens_bit_exact(name):
     env.close()
 
 
+@pytest.mark.parametrize("name", ["cwnd_noise_pm1", "cwnd_noise_grow"])
+def test_both_engine_options_together_goldens_bit_exact(name):
+    """USE_CWND and USE_LATENCY_NOISE switched on together in the unmodified reference (module globals, ns:51-54): the
+    event heap of the noise engine with the window test in front of every SEND."""
+    d = load(name)
+    n = d["seed"].shape[0]
+    feats = [str(f) for f in d["features"]]
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, history_len=int(d["history_len"]), features=feats,
+                                       record_steps=True, auto_reset=False, latency_noise=1.1, use_cwnd=True)
+    p = d["params"]
+    env.set_link_params(p[:, 0], p[:, 1], np.round(p[:, 2]), p[:, 3], p[:, 4])
+    k = int((d["rng"][:, 1] - d["rng"][:, 0]).max())
+    trace = np.stack([oracle.mt_uniforms(int(s), k, skip=int(o)) for s, o in zip(d["seed"], d["rng"][:, 0])])
+    env.set_loss_trace(trace)
+    obs0 = env.reset().cpu().numpy()
+    assert np.array_equal(obs0, d["obs0"].astype(np.float32))
+    assert np.array_equal(env.state("now").cpu().numpy(), d["warm"][:, 0])
+    rows = []
+    for t in range(d["actions"].shape[1]):
+        o, r, dn, info = env.step(d["actions"][:, t])
+        rows.append(info["steps"].clone())
+    env.check_flags()
+    steps = torch.stack(rows, 1).cpu().numpy()
+    assert np.array_equal(steps[..., :3], d["steps"][..., :3])
+    assert np.array_equal(steps, d["steps"])
+    assert np.array_equal(env.state("cwnd").cpu().numpy(), d["cwnd"][:, -1])
+    env.close()
+
+
+def test_both_engine_options_together_philox_batch_matches_oracle():
+    n_envs, n_steps, seed = 200, 80, 57
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=False, latency_noise=1.1,
+                                       use_cwnd=True)
+    env.reset()
+    rs = np.random.RandomState(seed)
+    acts = np.stack([rs.uniform(-1, 1, (n_envs, n_steps)), rs.uniform(-1, 3, (n_envs, n_steps))], axis=2)
+    a = torch.as_tensor(acts, dtype=torch.float64, device=DEV)
+    rows = []
+    for t in range(n_steps):
+        o, r, d, info = env.step(a[:, t])
+        rows.append(info["steps"].clone())
+    env.check_flags()
+    steps = torch.stack(rows, 1).cpu().numpy()
+    ref = oracle.run_batch(acts[..., 0], rng_mode=oracle.RNG_PHILOX, seed=seed, cwnd_actions=acts[..., 1], latency_noise=1.1,
+                           want_obs=False)
+    assert np.array_equal(steps[..., :3], ref["steps"][..., :3])
+    assert np.array_equal(steps, ref["steps"])
+    env.close()
+
+
 def test_use_latency_noise_philox_batch_matches_oracle():
     """... and on its own counter-based streams against the oracle with the option on: 200 envs with random links,
     two episodes back to back (auto-reset), every column and the observations."""
@@ -773,10 +823,6 @@ def test_engine_options_out_of_lockstep_match_oracle(option):
 
 def test_latency_noise_refuses_what_it_does_not_cover():
     env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, n_senders=2, auto_reset=False)
-    with pytest.raises(pcc_rl_amd.PccError):
-        pcc_rl_amd.native.check(env._L.pcc_set_latency_noise(env._h, 1, 1.1))
-    env.close()
-    env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, use_cwnd=True, auto_reset=False)
     with pytest.raises(pcc_rl_amd.PccError):
         pcc_rl_amd.native.check(env._L.pcc_set_latency_noise(env._h, 1, 1.1))
     env.close()

@@ -208,3 +208,18 @@ def test_step_before_reset_is_an_error():
     env = oracle.OracleEnv()
     with pytest.raises(TypeError):
         env.step([0.0])
+
+
+@pytest.mark.parametrize("name", ["cwnd_noise_pm1", "cwnd_noise_grow"])
+def test_both_engine_options_together_bit_exact(name):
+    """USE_CWND and USE_LATENCY_NOISE are module globals of the reference engine (ns:51-54): switched on together they
+    apply together -- a SEND the window blocks still takes its latency-noise draw and its loss draw (ns:158-175)."""
+    d = load(name)
+    feats = [str(f) for f in d["features"]]
+    for i in range(d["seed"].shape[0]):
+        env = run_case_mt(d, i, int(d["history_len"]), feats)
+        env.use_cwnd(True)
+        env.use_latency_noise(True, 1.1)
+        check_episode(env, d, i)
+        assert env.rng_draws == int(d["rng"][i][1])
+        env.close()
