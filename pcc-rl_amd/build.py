@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "pcc_sim.hip")
-SRCS = [SRC, os.path.join(HERE, "csrc", "pcc_policy.hip")]
+SRCS = [SRC, os.path.join(HERE, "csrc", "pcc_policy.hip"), os.path.join(HERE, "csrc", "pcc_ppo.hip")]
 INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libpcc_sim.so")

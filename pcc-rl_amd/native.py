@@ -33,7 +33,7 @@ SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params",
            "pcc_set_rng", "pcc_set_seed", "pcc_set_tuning", "pcc_set_ring_pools", "pcc_set_cwnd_mode", "pcc_set_latency_noise", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
            "pcc_step_retire",
            "pcc_get_state", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline", "pcc_debug_pass_stats",
-           "pcc_policy_act"]
+           "pcc_policy_act", "pcc_ppo_scratch_floats", "pcc_ppo_minibatch_step", "pcc_gae"]
 
 
 class PccError(RuntimeError):
@@ -95,6 +95,14 @@ def lib():
     L.pcc_debug_timeline.argtypes = [vp, vp, i64]
     L.pcc_policy_act.restype = i32
     L.pcc_policy_act.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    f32 = ctypes.c_float
+    L.pcc_ppo_scratch_floats.restype = i32
+    L.pcc_ppo_scratch_floats.argtypes = [i32, i32, i32]
+    L.pcc_ppo_minibatch_step.restype = i32
+    L.pcc_ppo_minibatch_step.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, f32, f32, f32, f32,
+                                         f32, f32, vp, vp, vp, vp]
+    L.pcc_gae.restype = i32
+    L.pcc_gae.argtypes = [vp, vp, vp, vp, i32, i64, f32, f32, vp, vp, vp]
     L.pcc_debug_pass_stats.restype = i32
     L.pcc_debug_pass_stats.argtypes = [vp, vp, i32]
     for fn in ("pcc_create", "pcc_set_link_params", "pcc_set_param_ranges", "pcc_set_rng", "pcc_set_seed",

@@ -56,6 +56,22 @@ class MlpPolicy(nn.Module):
             return [p.detach().reshape(-1) for m in seq if isinstance(m, nn.Linear) for p in (m.weight, m.bias)]
         return torch.cat(net(self.pi) + [self.log_std.detach().reshape(-1)] + net(self.vf)).float().contiguous()
 
+    def share_flat(self):
+        """Move every parameter into ONE flat fp32 tensor in flat_params() order -- the module's parameters become views of
+        it -- and return it: the fused optimiser step (pcc_ppo_minibatch_step) then updates the weights the framework
+        path and pcc_policy_act read, with no copy in either direction."""
+        flat = self.flat_params().clone()
+        off = 0
+
+        def net(seq):
+            return [p for m in seq if isinstance(m, nn.Linear) for p in (m.weight, m.bias)]
+        for prm in net(self.pi) + [self.log_std] + net(self.vf):
+            n = prm.numel()
+            prm.data = flat[off:off + n].view(prm.shape)
+            off += n
+        assert off == flat.numel()
+        return flat
+
     def fused_ok(self, obs):
         """Whether pcc_policy_act covers this policy and observation batch (two hidden layers, one action, fp32 on the GPU)."""
         linears = [m for m in self.pi if isinstance(m, nn.Linear)]
@@ -110,6 +126,25 @@ def gae(rewards, values, dones, last_value, gamma=0.99, lam=0.95):
     return adv, adv + values
 
 
+def gae_fused(rewards, values, dones, last_value, gamma=0.99, lam=0.95):
+    """gae() as one launch of the HIP library (pcc_gae: thread = env, T steps backwards) for fp32 [T, N] rows on the GPU."""
+    import ctypes
+
+    from .native import lib
+    if not (rewards.is_cuda and rewards.dtype == torch.float32 and rewards.dim() == 2):
+        return gae(rewards, values, dones, last_value, gamma, lam)
+    T, N = rewards.shape
+    rewards, values, last_value = rewards.contiguous(), values.contiguous(), last_value.contiguous().float()
+    d8 = dones.contiguous().view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8).contiguous()
+    adv, ret = torch.empty_like(rewards), torch.empty_like(rewards)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib().pcc_gae(ptr(rewards), ptr(values), ptr(d8), ptr(last_value), T, N, gamma, lam, ptr(adv), ptr(ret),
+                       ctypes.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("pcc_gae failed (%d)" % rc)
+    return adv, ret
+
+
 def ppo_loss(policy, obs, act, logp_old, adv, ret, clip=0.2, ent_coef=0.01):
     """PPO1's objective on one minibatch: clipped surrogate + 0.5 * value error - ent_coef * entropy.
     Returns (loss, policy term, value term, entropy)."""
@@ -124,7 +159,7 @@ def ppo_loss(policy, obs, act, logp_old, adv, ret, clip=0.2, ent_coef=0.01):
 
 class PPO(object):
     def __init__(self, env, arch=(32, 16), gamma=0.99, lam=0.95, clip=0.2, ent_coef=0.01, lr=1e-3,
-                 epochs=4, minibatch=None, horizon=64, seed=0):
+                 epochs=4, minibatch=None, horizon=64, seed=0, fused_update=True):
         """minibatch None = a quarter of the rollout, at least 2048: the reference's ratio (optim_batchsize 2048 of a
         timesteps_per_actorbatch of 8192, stable_solve.py:52) -- at 65 536 envs x 64 steps a fixed 2048 would be 2 048
         optimiser steps per epoch, thousands of launches of a few microseconds of work each."""
@@ -132,10 +167,26 @@ class PPO(object):
         self.epochs, self.minibatch, self.horizon = epochs, minibatch, horizon
         torch.manual_seed(seed)
         self.policy = MlpPolicy(env.obs_dim, 1, arch).to(env.device)
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=lr, eps=1e-5)
+        self.lr, self.adam_eps = lr, 1e-5
+        # the fused optimiser step (pcc_ppo_minibatch_step: gradient + Adam in two launches) when the library has a kernel
+        # for this shape; the framework path (autograd + torch.optim.Adam, the same arithmetic) otherwise
+        self.fused_update = bool(fused_update) and self._fused_update_ok()
+        if self.fused_update:
+            from .native import lib
+            self.flat = self.policy.share_flat()
+            self.adam_m, self.adam_v, self.adam_t = torch.zeros_like(self.flat), torch.zeros_like(self.flat), 0
+            self.scratch = torch.empty(lib().pcc_ppo_scratch_floats(env.obs_dim, arch[0], arch[1]), device=env.device)
+            self.stats_buf = torch.zeros(4, device=env.device)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=lr, eps=self.adam_eps)
         self.obs = env.reset().clone()
         if self.minibatch is None:
             self.minibatch = max(2048, env.n_envs * horizon // 4)
+
+    def _fused_update_ok(self):
+        env = self.env
+        arch = [m.out_features for m in self.policy.pi if isinstance(m, nn.Linear)]
+        return (torch.device(env.device).type == "cuda" and arch == [32, 16, 1] and env.obs_dim in (30, 12, 6, 3)
+                and env.n_senders == 1)
 
     def collect(self):
         """One rollout of `horizon` steps of every env.  The policy kernel reads the observation row the env wrote and
@@ -171,7 +222,7 @@ class PPO(object):
         # never train on corrupted rollouts: an overflowed in-flight ring / an empty ring pool (a trained
         # policy can push many deep-queue envs to MAX_RATE: BatchedNetworkEnv(ring_pools=...)) is flagged, not silent
         env.check_flags()
-        adv, ret = gae(rew_b, val_b, done_b, last_v, self.gamma, self.lam)
+        adv, ret = (gae_fused if fused else gae)(rew_b, val_b, done_b, last_v, self.gamma, self.lam)
         return obs_b, act_b, logp_b, adv, ret, rew_b
 
     def update(self, obs_b, act_b, logp_b, adv, ret):
@@ -179,6 +230,8 @@ class PPO(object):
         obs_f, act_f = obs_b.reshape(n, -1), act_b.reshape(n, -1)
         logp_f, adv_f, ret_f = logp_b.reshape(n), adv.reshape(n), ret.reshape(n)
         adv_f = (adv_f - adv_f.mean()) / (adv_f.std() + 1e-8)
+        if self.fused_update:
+            return self._update_fused(obs_f, act_f, logp_f, adv_f, ret_f)
         stats = {}
         for _ in range(self.epochs):
             perm = torch.randperm(n, device=obs_f.device)
@@ -191,6 +244,39 @@ class PPO(object):
                 self.opt.step()
                 stats = {"pg": pg.detach(), "vf": vf.detach(), "entropy": ent.detach()}
         return {k: float(v) for k, v in stats.items()}
+
+    def minibatch_step_fused(self, obs_f, act_f, logp_f, adv_f, ret_f, perm, start, count, lr=None, grad_out=None):
+        """One optimiser step on samples perm[start : start + count] of the flattened rollout as two launches of the HIP
+        library (include/pcc_policy.h: pcc_ppo_minibatch_step).  lr=0: gradient only (into grad_out)."""
+        import ctypes
+
+        from .native import lib
+        lr = self.lr if lr is None else lr
+        if start < 0 or count < 1 or start + count > (perm.numel() if perm is not None else obs_f.shape[0]):
+            raise ValueError("minibatch [%d, %d) outside the rollout" % (start, start + count))
+        if lr != 0.0:
+            self.adam_t += 1
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        D = obs_f.shape[1]
+        rc = lib().pcc_ppo_minibatch_step(ptr(obs_f), ptr(act_f), ptr(logp_f), ptr(adv_f), ptr(ret_f), ptr(perm), start, count,
+                                          D, 32, 16, ptr(self.flat), ptr(self.adam_m), ptr(self.adam_v), max(self.adam_t, 1),
+                                          lr, 0.9, 0.999, self.adam_eps, self.clip, self.ent_coef, ptr(self.scratch),
+                                          ptr(grad_out), ptr(self.stats_buf),
+                                          ctypes.c_void_p(torch.cuda.current_stream(obs_f.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("pcc_ppo_minibatch_step failed (%d)" % rc)
+
+    def _update_fused(self, obs_f, act_f, logp_f, adv_f, ret_f):
+        n = obs_f.shape[0]
+        obs_f, act_f = obs_f.contiguous(), act_f.reshape(n).contiguous()
+        logp_f, adv_f, ret_f = logp_f.contiguous(), adv_f.contiguous(), ret_f.contiguous()
+        for _ in range(self.epochs):
+            perm = torch.randperm(n, device=obs_f.device)
+            for i in range(0, n, self.minibatch):
+                self.minibatch_step_fused(obs_f, act_f, logp_f, adv_f, ret_f, perm, i, min(self.minibatch, n - i))
+        st = self.stats_buf.tolist()   # of the last minibatch, like the framework path
+        ent = float(self.policy.log_std.detach().sum()) + 0.5 * (1.0 + math.log(2.0 * math.pi)) * self.policy.log_std.numel()
+        return {"pg": -st[0], "vf": 0.5 * st[1], "entropy": ent, "clip_frac": st[2]}
 
     def iterate(self):
         obs_b, act_b, logp_b, adv, ret, rew = self.collect()

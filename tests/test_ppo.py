@@ -100,3 +100,115 @@ def test_fused_policy_forward_matches_the_framework_path():
     pol7 = MlpPolicy(7, 1, (32, 16)).to(dev)
     a3, _, _ = pol7.act_fused(torch.randn(64, 7, device=dev))                       # no instantiation: framework path
     assert a3.shape == (64, 1)
+
+
+def test_share_flat_makes_the_parameters_views_of_one_tensor():
+    torch.manual_seed(2)
+    pol = MlpPolicy(30, 1, (32, 16))
+    obs = torch.randn(9, 30)
+    before = (pol.pi(obs).detach().clone(), pol.value(obs).detach().clone())
+    flat = pol.share_flat()
+    assert torch.equal(flat, pol.flat_params()) and flat.numel() == 2 * (30 * 32 + 32 + 32 * 16 + 16 + 16 + 1) + 1
+    assert torch.equal(pol.pi(obs).detach(), before[0]) and torch.equal(pol.value(obs).detach(), before[1])
+    with torch.no_grad():
+        flat.mul_(0.5)                                         # an in-place optimiser step on the flat tensor ...
+    assert torch.equal(flat, pol.flat_params())                # ... is a step on the module's parameters
+    assert not torch.equal(pol.pi(obs).detach(), before[0])
+    loss = pol.dist(obs).log_prob(torch.zeros(9, 1)).sum() + pol.value(obs).sum()   # autograd still reaches every parameter
+    loss.backward()
+    assert all(p.grad is not None for p in pol.parameters())
+
+
+def _rollout_like(n, D, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    obs = torch.randn(n, D, generator=g).to(dev)
+    act = (0.5 * torch.randn(n, 1, generator=g)).to(dev)
+    logp = (-1.0 + 0.3 * torch.randn(n, generator=g)).to(dev)
+    adv = torch.randn(n, generator=g).to(dev)
+    adv[::97] = 0.0
+    ret = (2.0 * torch.randn(n, generator=g)).to(dev)
+    return obs, act, logp, adv, ret
+
+
+class _Env(object):   # what PPO.__init__ needs of an env, without a simulator behind it
+    def __init__(self, D, dev):
+        self.obs_dim, self.device, self.n_senders, self.n_envs = D, dev, 1, 8
+
+    def reset(self):
+        return torch.zeros(self.n_envs, self.obs_dim, device=self.device)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,n,count", [(30, 5000, 3333), (30, 70000, 70000), (12, 1000, 64), (3, 777, 700)])
+def test_fused_minibatch_gradient_matches_autograd(D, n, count):
+    """pcc_ppo_minibatch_step's gradient (fp32 FMAs + fp32 MFMA sums over the samples) against torch autograd of ppo_loss in
+    float64 on the same minibatch: within 1e-5 of the gradient's largest entry (fp32 sums of `count` terms)."""
+    from pcc_rl_amd.ppo import PPO, ppo_loss
+    dev = torch.device("cuda:0")
+    agent = PPO(_Env(D, dev), seed=5)
+    assert agent.fused_update
+    with torch.no_grad():
+        agent.policy.log_std.fill_(-0.4)
+    obs, act, logp, adv, ret = _rollout_like(n, D, dev, 11)
+    with torch.no_grad():                                     # log-probabilities near the policy's own: ratios around 1,
+        logp = agent.policy.dist(obs).log_prob(act).sum(-1) + 0.15 * torch.randn(n, device=dev)   # some of them clipped
+    perm = torch.randperm(n, device=dev)
+    g = torch.zeros_like(agent.flat)
+    start = min(5, n - count)
+    agent.minibatch_step_fused(obs, act.reshape(n), logp, adv, ret, perm, start, count, lr=0.0, grad_out=g)
+    stats = agent.stats_buf.tolist()
+    idx = perm[start:start + count]
+    pol64 = MlpPolicy(D, 1, (32, 16)).to(dev).double()
+    pol64.load_state_dict({k: v.double() for k, v in agent.policy.state_dict().items()})
+    loss, pg, vf, ent = ppo_loss(pol64, obs[idx].double(), act[idx].double(), logp[idx].double(), adv[idx].double(),
+                                 ret[idx].double(), agent.clip, agent.ent_coef)
+    loss.backward()
+    def net(seq):
+        return [p.grad.reshape(-1) for m in seq if isinstance(m, torch.nn.Linear) for p in (m.weight, m.bias)]
+    want = torch.cat(net(pol64.pi) + [pol64.log_std.grad.reshape(-1)] + net(pol64.vf))
+    err = (g.double() - want).abs().max().item()
+    assert err <= 1e-5 * want.abs().max().item() + 1e-7, (err, want.abs().max().item())
+    assert abs(-stats[0] - float(pg)) < 1e-4 * max(1.0, abs(float(pg))) and abs(0.5 * stats[1] - float(vf)) < 1e-4 * max(1.0, float(vf))
+    assert 0.0 < stats[2] < 1.0                               # some ratios were clipped, not all
+
+
+@pytest.mark.gpu
+def test_fused_optimiser_steps_match_torch_adam():
+    """Three consecutive fused steps (gradient + Adam on the shared flat parameters) against autograd + torch.optim.Adam from
+    the same start on the same minibatches."""
+    from pcc_rl_amd.ppo import PPO, ppo_loss
+    dev = torch.device("cuda:0")
+    agent = PPO(_Env(30, dev), seed=7)
+    ref = MlpPolicy(30, 1, (32, 16)).to(dev)
+    ref.load_state_dict(agent.policy.state_dict())
+    opt = torch.optim.Adam(ref.parameters(), lr=agent.lr, eps=agent.adam_eps)
+    n = 4096
+    obs, act, logp, adv, ret = _rollout_like(n, 30, dev, 3)
+    with torch.no_grad():
+        logp = ref.dist(obs).log_prob(act).sum(-1) + 0.1 * torch.randn(n, device=dev)
+    for k in range(3):
+        agent.minibatch_step_fused(obs, act.reshape(n), logp, adv, ret, None, 1000 * k, 1500)
+        sl = slice(1000 * k, 1000 * k + 1500)
+        loss = ppo_loss(ref, obs[sl], act[sl], logp[sl], adv[sl], ret[sl], agent.clip, agent.ent_coef)[0]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    assert agent.adam_t == 3
+    assert torch.allclose(agent.flat, ref.flat_params(), atol=2e-5), (agent.flat - ref.flat_params()).abs().max()
+    assert not torch.allclose(agent.flat, MlpPolicy(30, 1, (32, 16)).to(dev).flat_params(), atol=1e-3)
+    o = torch.randn(16, 30, device=dev)                        # the module reads the updated weights (views of the flat tensor)
+    assert torch.allclose(agent.policy.pi(o), ref.pi(o), atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_gae_kernel_matches_the_loop():
+    from pcc_rl_amd.ppo import gae_fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    T, N = 37, 1000
+    r, v = torch.randn(T, N, device=dev), torch.randn(T, N, device=dev)
+    d = torch.rand(T, N, device=dev) < 0.05
+    lv = torch.randn(N, device=dev)
+    a1, r1 = gae(r, v, d, lv, 0.99, 0.95)
+    a2, r2 = gae_fused(r, v, d, lv, 0.99, 0.95)
+    assert torch.allclose(a1, a2, atol=1e-5) and torch.allclose(r1, r2, atol=1e-5)

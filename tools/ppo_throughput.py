@@ -27,11 +27,16 @@ def rollout(): batch["b"] = agent.collect()
 t_roll = timed(rollout, 3)
 def update(): agent.update(*batch["b"][:5])
 t_upd = timed(update, 2)
+# the framework path of the same update (autograd + torch.optim.Adam): what the fused step replaces
+agent_fw = PPO(env, horizon=T, seed=0, minibatch=max(2048, N * T // 4), fused_update=False)
+def update_fw(): agent_fw.update(*batch["b"][:5])
+t_upd_fw = timed(update_fw, 1)
 out = {"n_envs": N, "horizon": T,
        "env_only": {"env_steps_per_s": N * T / t_env, "ms_per_step": 1e3 * t_env / T},
        "rollout": {"env_steps_per_s": N * T / t_roll, "ms_per_step": 1e3 * t_roll / T, "env_share_of_time": t_env / t_roll},
-       "rollout_plus_update": {"env_steps_per_s": N * T / (t_roll + t_upd), "update_s": t_upd,
+       "rollout_plus_update": {"env_steps_per_s": N * T / (t_roll + t_upd), "update_s": t_upd, "fused_update": agent.fused_update,
                                "env_share_of_time": t_env / (t_roll + t_upd)},
+       "framework_update": {"update_s": t_upd_fw, "rollout_plus_update_env_steps_per_s": N * T / (t_roll + t_upd_fw)},
        "note": "PPO with the reference script's policy shape and hyper-parameters (pi/vf MLP 32-16, minibatch 2048, 4 epochs); "
                "minibatch = N*T/4 keeps the reference's 4 minibatches per epoch (8192 samples / 2048) at this batch size"}
 print(json.dumps(out, indent=1))
