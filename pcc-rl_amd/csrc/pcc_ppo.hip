@@ -11,7 +11,7 @@
 //                     they buy here is the cross-lane sum), their operands transposed through LDS (row stride 33 / 17
 //                     floats: conflict-free both ways).  The accumulators stay in registers over all tiles of a
 //                     wavefront; every workgroup writes ONE partial gradient.
-//   ppo_adam_kernel   thread = parameter: sums the partial gradients in a fixed order (deterministic), adds the entropy
+//   ppo_adam_kernel   sums the partial gradients in a fixed order (deterministic), adds the entropy
 //                     term, applies Adam (torch.optim.Adam's arithmetic), writes the parameters in place.
 //
 // Plus the GAE recursion as one launch (thread = env, T steps backwards).  fp32 like the framework path; checked against
@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 2;
-constexpr int kMaxBlocks = 1024;
+constexpr int kMaxBlocks = 1024;  // 2 wavefronts each: two per SIMD of the chip (<= 256 registers, 17 KB of LDS per wavefront)
 
 template <int D, int H1, int H2>
 struct Net {  // offsets inside one network's block of the parameter vector (include/pcc_policy.h)
@@ -42,12 +42,26 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// The weights are scalar operands of the FMAs (uniform loads straight from the parameter vector: no vector register, no
+// LDS bandwidth -- broadcast reads of an LDS copy cost 1 KB of LDS return path per 4 weights and made the kernel LDS-bound).
+// Left alone the compiler hoists these ~3 000 loop-invariant scalar loads out of the tile loop -- or, kept inside, to the
+// top of the iteration -- and spills the scalar registers into vector-register lanes (1 500 - 7 000 v_readlane per tile):
+// p, through an offset the compiler cannot see through (a scalar 0 made by an asm statement) that does not exist before
+// the value `after` does: the loads through the result stay behind whatever produced `after`, and scalar
+__device__ __forceinline__ const float *not_before(const float *p, float after) {
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero) : "v"(after));
+    return p + zero;
+}
+
 template <int D, int H1, int H2>
-__device__ __forceinline__ float net_forward(const float *__restrict__ p, const float (&x)[32], float (&h1)[H1],
+__device__ __forceinline__ float net_forward(const float *__restrict__ p0, const float (&x)[32], float (&h1)[H1],
                                              float (&h2)[H2]) {
     using L = Net<D, H1, H2>;
+    // the loads of unit j may start once unit j - 2 is done: one unit's weights run ahead of the FMAs
 #pragma unroll
     for (int j = 0; j < H1; j++) {
+        const float *p = not_before(p0, j >= 2 ? h1[j - 2] : x[0]);
         float s = p[L::B1 + j];
 #pragma unroll
         for (int k = 0; k < D; k++) s = fmaf(p[L::W1 + j * D + k], x[k], s);
@@ -55,11 +69,13 @@ __device__ __forceinline__ float net_forward(const float *__restrict__ p, const 
     }
 #pragma unroll
     for (int j = 0; j < H2; j++) {
+        const float *p = not_before(p0, j >= 2 ? h2[j - 2] : h1[H1 - 2 + j]);
         float s = p[L::B2 + j];
 #pragma unroll
         for (int k = 0; k < H1; k++) s = fmaf(p[L::W2 + j * H1 + k], h1[k], s);
         h2[j] = tanh_fast(s);
     }
+    const float *p = not_before(p0, h2[H2 - 2]);
     float out = p[L::B3];
 #pragma unroll
     for (int k = 0; k < H2; k++) out = fmaf(p[L::W3 + k], h2[k], out);
@@ -68,18 +84,24 @@ __device__ __forceinline__ float net_forward(const float *__restrict__ p, const 
 
 // gradients of the loss with respect to the pre-activations, given d loss / d output
 template <int D, int H1, int H2>
-__device__ __forceinline__ void net_backward(const float *__restrict__ p, const float (&h1)[H1], const float (&h2)[H2],
+__device__ __forceinline__ void net_backward(const float *__restrict__ p0, const float (&h1)[H1], const float (&h2)[H2],
                                              float dout, float (&dz1)[H1], float (&dz2)[H2]) {
     using L = Net<D, H1, H2>;
+    {
+        const float *p = not_before(p0, dout);
 #pragma unroll
-    for (int j = 0; j < H2; j++) dz2[j] = p[L::W3 + j] * dout * (1.0f - h2[j] * h2[j]);
-#pragma unroll
-    for (int k = 0; k < H1; k++) {
-        float s = 0.0f;
-#pragma unroll
-        for (int j = 0; j < H2; j++) s = fmaf(p[L::W2 + j * H1 + k], dz2[j], s);
-        dz1[k] = s * (1.0f - h1[k] * h1[k]);
+        for (int j = 0; j < H2; j++) dz2[j] = p[L::W3 + j] * dout * (1.0f - h2[j] * h2[j]);
     }
+#pragma unroll
+    for (int k = 0; k < H1; k++) dz1[k] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < H2; j++) {   // row j of W2 at a time (contiguous loads), 32 independent sums
+        const float *p = not_before(p0, j >= 2 ? dz1[H1 - 1] : dz2[H2 - 1]);   // (dz1[H1 - 1] as of row j - 2)
+#pragma unroll
+        for (int k = 0; k < H1; k++) dz1[k] = fmaf(p[L::W2 + j * H1 + k], dz2[j], dz1[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < H1; k++) dz1[k] *= 1.0f - h1[k] * h1[k];
 }
 
 struct NetAcc {   // one network's gradient sums of a wavefront
@@ -99,23 +121,25 @@ __device__ __forceinline__ void acc_zero(NetAcc &a) {
 
 constexpr int kS33 = 33, kS17 = 17;
 constexpr int kBufFloats = kWave * kS33;          // one [64][33] operand buffer
-constexpr int kWaveLds = 3 * kBufFloats;          // x | A operand (dz1, then dz2) | B operand (h1, then h2 and dz3)
+constexpr int kWaveLds = 2 * kBufFloats;          // A operand (dz1, then dz2) | B operand (x, then h1, then h2 and dz3)
 
 // One network's weight-gradient sums over the 64 samples of the tile: the lane's activations go to LDS sample-major and
 // come back as MFMA operands (A[i = unit][k = sample], B[k = sample][j = input]).
 template <int D, int H1, int H2>
-__device__ __forceinline__ void accumulate_tile(NetAcc &acc, float *bufX, float *bufA, float *bufH, const uint32_t lane,
-                                                const float (&h1)[H1], const float (&h2)[H2], const float (&dz1)[H1],
+__device__ __forceinline__ void accumulate_tile(NetAcc &acc, float *bufA, float *bufH, const uint32_t lane,
+                                                const float (&x)[32], const float (&h1)[H1], const float (&h2)[H2], const float (&dz1)[H1],
                                                 const float (&dz2)[H2], const float dout) {
     static_assert(H1 == 32 && H2 == 16, "the MFMA tiles below are the reference's --arch 32,16");
     // ---- layer 1: dW1[i][j] += sum_s dz1[s][i] * x[s][j]   (x[s][D] = 1: db1)
 #pragma unroll
     for (int i = 0; i < H1; i++) bufA[lane * kS33 + i] = dz1[i];
+#pragma unroll
+    for (int j = 0; j < 32; j++) bufH[lane * kS33 + j] = x[j];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 8
     for (int t = 0; t < kWave / 2; t++) {
         const uint32_t s = 2u * t + (lane >> 5);
-        acc.w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bufA[s * kS33 + (lane & 31u)], bufX[s * kS33 + (lane & 31u)], acc.w1, 0, 0, 0);
+        acc.w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bufA[s * kS33 + (lane & 31u)], bufH[s * kS33 + (lane & 31u)], acc.w1, 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
     // ---- layer 2: dW2[i][j] += sum_s dz2[s][i] * h1[s][j]
@@ -193,7 +217,7 @@ __device__ __forceinline__ void acc_store(const NetAcc &acc, float *g, const uin
 // partial[block][n_params + 4]: the block's gradient sums, then its sums of {surrogate, squared value error, |ratio - 1| >
 // clip, 1}.
 template <int D, int H1, int H2>
-__global__ __launch_bounds__(kWavesPerBlock *kWave, 1) void ppo_grad_kernel(
+__global__ __launch_bounds__(kWavesPerBlock *kWave, 2) void ppo_grad_kernel(
     const float *__restrict__ obs, const float *__restrict__ act, const float *__restrict__ logp_old,
     const float *__restrict__ adv, const float *__restrict__ ret, const int64_t *__restrict__ perm, int64_t start,
     int64_t count, const float *__restrict__ params, float clip, float *__restrict__ partial) {
@@ -203,7 +227,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 1) void ppo_grad_kernel(
     static_assert(kParams + 4 <= kWaveLds, "the block's gradient is reduced in a wavefront's LDS buffers");
     __shared__ float lds[kWavesPerBlock * kWaveLds];
     const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    float *bufX = lds + wv * kWaveLds, *bufA = bufX + kBufFloats, *bufH = bufA + kBufFloats;
+    float *bufA = lds + wv * kWaveLds, *bufH = bufA + kBufFloats;
     const float log_std = params[kLogStd];
     const float inv_std = __expf(-log_std);
     const float inv_n = 1.0f / (float)count;
@@ -233,8 +257,6 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 1) void ppo_grad_kernel(
 #pragma unroll
             for (int j = 0; j < 32; j++) x[j] = 0.0f;   // (and every d loss / d output below is 0)
         }
-#pragma unroll
-        for (int j = 0; j < 32; j++) bufX[lane * kS33 + j] = x[j];
         float h1[H1], h2[H2], dz1[H1], dz2[H2];
         // ---- policy network: log-probability of the taken action, clipped surrogate
         {
@@ -256,7 +278,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 1) void ppo_grad_kernel(
                 s_clip += (ratio < lo || ratio > hi) ? 1.0f : 0.0f;
             }
             net_backward<D, H1, H2>(params + kPi, h1, h2, dmu, dz1, dz2);
-            accumulate_tile<D, H1, H2>(pi, bufX, bufA, bufH, lane, h1, h2, dz1, dz2, dmu);
+            accumulate_tile<D, H1, H2>(pi, bufA, bufH, lane, x, h1, h2, dz1, dz2, dmu);
         }
         // ---- value network: 0.5 * mean((v - ret)^2)
         {
@@ -265,7 +287,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 1) void ppo_grad_kernel(
             s_vf += err * err;
             const float dv = err * inv_n;
             net_backward<D, H1, H2>(params + kVf, h1, h2, dv, dz1, dz2);
-            accumulate_tile<D, H1, H2>(vf, bufX, bufA, bufH, lane, h1, h2, dz1, dz2, dv);
+            accumulate_tile<D, H1, H2>(vf, bufA, bufH, lane, x, h1, h2, dz1, dz2, dv);
         }
     }
     // ---- the block's partial gradient: every wavefront's sums -> LDS (wavefront 0's buffers), one after the other
@@ -290,16 +312,27 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, 1) void ppo_grad_kernel(
     for (int k = threadIdx.x; k < kParams + 4; k += blockDim.x) out[k] = g[k];
 }
 
-// thread = parameter: the sum of the blocks' partial gradients in block order, the entropy term (entropy of the diagonal
-// Gaussian = const + log_std: d/d log_std of -ent_coef * entropy is -ent_coef), Adam as torch.optim.Adam computes it.
-__global__ void ppo_adam_kernel(const float *__restrict__ partial, int n_blocks, int n_params, int logstd_index, float ent_coef,
-                                float *__restrict__ params, float *__restrict__ m, float *__restrict__ v, float lr,
-                                float beta1, float beta2, float eps, float bias1, float bias2_sqrt, float inv_count,
-                                float *__restrict__ grad_out, float *__restrict__ stats_out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_params + 4) return;
+// 16 parameters per workgroup: thread (r, c) sums parameter c's partial gradients of the blocks r, r + 16, ..., the 16 row sums
+// are added in order (deterministic: no atomics anywhere); then the entropy term (entropy of the diagonal Gaussian = const +
+// log_std: d/d log_std of -ent_coef * entropy is -ent_coef) and Adam as torch.optim.Adam computes it.
+__global__ __launch_bounds__(256) void ppo_adam_kernel(const float *__restrict__ partial, int n_blocks, int n_params,
+                                                       int logstd_index, float ent_coef, float *__restrict__ params,
+                                                       float *__restrict__ m, float *__restrict__ v, float lr, float beta1,
+                                                       float beta2, float eps, float bias1, float bias2_sqrt, float inv_count,
+                                                       float *__restrict__ grad_out, float *__restrict__ stats_out) {
+    __shared__ float rows[16][17];
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int p = blockIdx.x * 16 + c;
+    const int stride = n_params + 4;
     float g = 0.0f;
-    for (int b = 0; b < n_blocks; b++) g += partial[(int64_t)b * (n_params + 4) + p];
+    if (p < stride)
+        for (int b = r; b < n_blocks; b += 16) g += partial[(int64_t)b * stride + p];
+    rows[r][c] = g;
+    __syncthreads();
+    if (r != 0 || p >= stride) return;
+    g = rows[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; k++) g += rows[k][c];
     if (p >= n_params) {   // {-policy loss, 2 * value loss, clipped fraction, -} as means over the minibatch
         if (stats_out) stats_out[p - n_params] = g * inv_count;
         return;
@@ -373,7 +406,7 @@ extern "C" int pcc_ppo_minibatch_step(const float *obs, const float *act, const 
     if (hipGetLastError() != hipSuccess) return -3;
     const float bias1 = lr != 0.0f ? 1.0f - powf(beta1, (float)adam_step) : 1.0f;
     const float bias2 = lr != 0.0f ? sqrtf(1.0f - powf(beta2, (float)adam_step)) : 1.0f;
-    hipLaunchKernelGGL(ppo_adam_kernel, dim3((unsigned)((n_params + 4 + 255) / 256)), dim3(256), 0, st, scratch, (int)blocks,
+    hipLaunchKernelGGL(ppo_adam_kernel, dim3((unsigned)((n_params + 4 + 15) / 16)), dim3(256), 0, st, scratch, (int)blocks,
                        n_params, n_net, ent_coef, params, adam_m, adam_v, lr, beta1, beta2, eps, bias1, bias2,
                        1.0f / (float)count, grad_out, stats_out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
