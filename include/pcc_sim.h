@@ -87,7 +87,7 @@ enum {
     PCC_F_LAST_RETURN,   /* f64 [S][N]  return of the last finished episode            */
     PCC_F_TOTAL_SENT,    /* u64 [N]     packets sent since create (all episodes, all senders) */
     PCC_F_RING_TIER,     /* u8  [S][N]  tier of the sender's in-flight rings (0 = its own small rings) */
-    PCC_F_CWND,          /* u32 [N]     congestion window, packets (pcc_set_cwnd_mode)    (ns:227) */
+    PCC_F_CWND,          /* u32 [S][N]  congestion window, packets (pcc_set_cwnd_mode)    (ns:227) */
     PCC_N_FIELDS
 };
 
@@ -196,27 +196,29 @@ int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t di
  * (ns:251-255; acknowledgements and loss reports arrive one RTT after the send, ns:264-273); a
  * blocked SEND still passes through the link's queue and loss draw, as in the reference
  * (ns:158-175).  Every new episode starts with cwnd = 25 (ns:209).  With the option on, the actions
- * of pcc_step / pcc_step_send are [N][2] = (rate action, cwnd action) (ns:376-377, 412-414): the
- * second moves the window like the first moves the rate (x (1 + a*delta_scale) or / (1 - a*
- * delta_scale)), truncated to an integer and clamped to [4, 5000] (ns:33-34, 283-289).  One sender
- * per env only; pcc_reset must follow.  This path is lane-serial (no wave path); it is exact like
- * the others.  It combines with pcc_set_latency_noise (see there). */
+ * of pcc_step / pcc_step_send are [N][S][2] = (rate action, cwnd action) per sender (ns:376-377, 412-414):
+ * the second moves the sender's window like the first moves its rate (x (1 + a*delta_scale) or / (1 - a*
+ * delta_scale)), truncated to an integer and clamped to [4, 5000] (ns:33-34, 283-289).  pcc_reset must
+ * follow.  One sender: a lane-serial send path (no wave path).  Two senders: the windows couple both SEND
+ * streams to the notifications, so the interval runs in the event-loop build (see pcc_set_latency_noise:
+ * one lane per env, one launch per interval, no pcc_step_send / pcc_step_retire split; golden sets
+ * two_sender_cwnd*).  Exact like the other paths.  It combines with pcc_set_latency_noise (see there). */
 int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable);
 
 /* The reference's other dormant engine option, USE_LATENCY_NOISE / MAX_LATENCY_NOISE (ns:51-52; off /
  * 1.1 in the reference): every link latency -- forward hop at the SEND (ns:171-172), return hop at the
  * first ACK event (ns:150-151) -- is multiplied by random.uniform(1.0, max_noise), one more draw of the
  * env's stream per hop (at a SEND it precedes the loss draw).  Packets overtake each other, so with the
- * option on an env keeps the reference's own structure -- a binary heap of its events, ring_capacity
- * events per env, allocated by this call (2 x 16 bytes x ring_capacity per env) -- and one lane runs the
- * reference's event loop over it; the whole interval is one kernel launch (pcc_step; there is no
- * pcc_step_send / pcc_step_retire split).  Exact like the other paths (golden sets noise_*), and slow:
+ * option on an env keeps the reference's own structure -- a binary heap of each sender's events, ring_capacity
+ * events per sender, allocated by this call (2 x 16 bytes x ring_capacity per sender) -- and one lane runs the
+ * reference's event loop over it ("event-loop build"); the whole interval is one kernel launch (pcc_step; there is no
+ * pcc_step_send / pcc_step_retire split).  Exact like the other paths (golden sets noise_*, two_sender_noise), and slow:
  * it exists for parity with the reference's flag, not for throughput.  Uniforms: PCC_RNG_TRACE replays
  * the trace in draw order (three draws per packet); PCC_RNG_PHILOX numbers ALL draws of an interval
- * 0, 1, 2, ... in event order (word index of the interval's Philox stream).  One sender per env.  Together with
- * pcc_set_cwnd_mode (the reference's two flags are module globals and apply together): a SEND goes out only while
- * fewer than cwnd events are in the heap, a blocked one still takes its noise draw and its loss draw, actions are
- * [N][2].  pcc_reset must follow.  More events in flight than ring_capacity, or
+ * 0, 1, 2, ... in event order (word index of the interval's Philox stream).  One or two senders per env (events of
+ * equal time: lower sender id first, ns:42-43).  Together with pcc_set_cwnd_mode (the reference's two flags are module
+ * globals and apply together): a SEND goes out only while fewer than cwnd of the sender's events are in its heap, a
+ * blocked one still takes its noise draw and its loss draw, actions are [N][S][2].  pcc_reset must follow.  More events in flight than ring_capacity, or
  * more acknowledgements in one interval, raise PCC_FLAG_RING_OVERFLOW. */
 int pcc_set_latency_noise(pcc_sim_t *sim, int enable, double max_noise);
 

@@ -103,7 +103,7 @@ struct alignas(128) EnvBlk {
     double lr, maxq;  //  16
     double ebw;       //  32
     uint32_t episode;
-    uint32_t cwnd;    //      the reference's dormant USE_CWND option (ns:54): window in packets (ns:227: 25 at reset)
+    uint32_t pad_c;
     double q, tu;     //  48  link queue: send half, and the retire half's MI-ending event
     double now, run_dur;            //  64  retire half
     unsigned long long total_sent;  //  80  retire half
@@ -113,7 +113,7 @@ struct alignas(128) EnvBlk {
     uint32_t mi_draws;  //  96  send half: link-entry draws of the MI (a SEND the window blocks still draws)
     uint32_t ep_draws;  //      ... of the episode: the position in a replayed loss trace
     uint32_t flags;
-    uint32_t heap_n;    //      USE_LATENCY_NOISE option: events in the env's heap
+    uint32_t pad_h;
 };
 struct alignas(128) SndBlk {
     double rate, rate0;          //  0  send half (rate)
@@ -125,7 +125,9 @@ struct alignas(128) SndBlk {
     uint32_t ha, hd, ta, td;     // 64  accepted/dropped ring heads and tails
     uint32_t mi_sent;            // 80
     uint32_t ring_held[kMaxTiers];  // pool slot + 1 the sender holds in tier c (0 = none) until reset
-    uint32_t pad1[3];
+    uint32_t cwnd;     // the reference's dormant USE_CWND option (ns:54): the sender's window in packets (ns:227: 25 at reset)
+    uint32_t heap_n;   // event-loop build (event_engine): the sender's events in its heap = its packets in flight
+    uint32_t pad1;
     // 112  retire half: where the last interval's four ring boundaries fell, as predictions of the next ones (speed only:
     // search_many verifies them) -- acknowledgements and loss reports per second of simulated time, and the packets that were
     // on the return hop at the interval's end (accepted / dropped ring)
@@ -174,15 +176,17 @@ struct Dev {
     const double *p_bw, *p_dl, *p_queue, *p_loss, *p_rate0;
     EnvBlk *env;  // [N] link + env state, one 128-byte block per env
     SndBlk *snd;  // [S][N] per sender, one 128-byte block each
-    // the reference's dormant USE_CWND engine option (ns:54), one sender only
+    // the reference's dormant USE_CWND engine option (ns:54)
     int use_cwnd;
-    // the reference's dormant USE_LATENCY_NOISE engine option (ns:51-52), one sender only: packets overtake each
-    // other, so the in-flight set is a real priority queue per env (see noise_engine)
+    // the reference's dormant USE_LATENCY_NOISE engine option (ns:51-52): packets overtake each other, so the in-flight
+    // set is a real priority queue (see event_engine)
     int use_noise;
+    // the event-loop build runs the interval (event_engine): with USE_LATENCY_NOISE, and with USE_CWND on two senders
+    int engine;
     double noise_span;     // MAX_LATENCY_NOISE - 1.0: random.uniform(1.0, MAX) = 1.0 + span * random()
-    uint32_t noise_cap;    // events / RTT samples per env (a power of two)
-    double2 *noise_heap;   // [N][noise_cap] (+-t, +-latency): sign of t = hop 2, sign of latency = dropped
-    double2 *noise_rtt;    // [N][noise_cap] (-, rtt) of the packets acknowledged in the current MI, in ack order
+    uint32_t noise_cap;    // events / RTT samples per sender (a power of two)
+    double2 *noise_heap;   // [S][N][noise_cap] (+-t, +-latency): sign of t = hop 2, sign of latency = dropped
+    double2 *noise_rtt;    // [S][N][noise_cap] (-, rtt) of the packets acknowledged in the current MI, in ack order
     float *hist;    // [N][S][HF]
     double2 *ring;  // [N][S][2][cap]: accepted ring, dropped ring
 };
@@ -1268,7 +1272,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
             // time, ns:42-43) is no longer in flight.  A blocked SEND still passes through the link's
             // queue and takes its loss draw (ns:170-175 are outside the `if`): it updates (q, tu) and
             // the RNG position, but leaves no record and is not counted as sent.
-            uint32_t cw = D.env[ii].cwnd;
+            uint32_t cw = D.snd[ii].cwnd;
             if (!warm && live) {  // apply_cwnd_delta + set_cwnd: ns:243-249, 283-289
                 const int64_t ai = ii * 2 + 1;
                 double delta = actions_f64 ? ((const double *)actions)[ai] : (double)((const float *)actions)[ai];
@@ -1276,7 +1280,7 @@ __device__ __forceinline__ void send_item(const Dev &D, const uint32_t lane, con
                 delta *= D.delta_scale;
                 const double c = delta >= 0.0 ? (double)cw * (1.0 + delta) : (double)cw / (1.0 - delta);
                 cw = c >= 5000.0 ? 5000u : (c < 4.0 ? 4u : (uint32_t)c);  // int(), then [MIN_CWND, MAX_CWND] (ns:33-34)
-                D.env[ii].cwnd = cw;
+                D.snd[ii].cwnd = cw;
             }
             const double2 *acc = rings[0].accepted(), *drp = rings[0].dropped();
             const uint32_t amask_r = rings[0].mask(), dmask_r = rings[0].dmask();
@@ -2246,22 +2250,40 @@ __device__ __forceinline__ double2 heap_pop(double2 *H, uint32_t &n) {
     return top;
 }
 
-struct NoiseOut {
-    double now, nsend, q, tu;
-    uint32_t sent, acked, lost, flags;
+template <int NS>
+struct EngineOut {
+    double now, q, tu;
+    double nsend[NS];
+    uint32_t sent[NS], acked[NS], lost[NS];
+    uint32_t flags;
 };
 
-// one monitor interval of env i, by one lane: ns:123-178 with the option on
-__device__ __noinline__ NoiseOut noise_engine(const Dev &D, int64_t i, double start, double end, double rate, double nsend,
-                                              uint32_t mi, uint32_t cwnd /* USE_CWND on as well: the window; else 0xFFFFFFFF */) {
+// One monitor interval of env i, by one lane: the reference's event loop (ns:123-178) with its dormant options --
+// USE_LATENCY_NOISE (D.use_noise: one more draw of the stream per hop) and/or USE_CWND (cwnd[s]; 0xFFFFFFFF without) --
+// for NS senders.  Every sender has its own heap of acknowledgement events (= its packets in flight, which is what its
+// window counts); the event order (time, sender id, 'A' < 'S', hop, latency, dropped) (ns:42-43, 111) across the senders
+// is the scan below: lower sender first at equal times, a sender's ACK before its SEND.
+template <int NS>
+__device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, double start, double end, const double (&rate)[NS],
+                                                   const double (&nsend0)[NS], uint32_t mi, const uint32_t (&cwnd)[NS]) {
     const double dl = D.env[i].dl, lr = D.env[i].lr, maxq = D.env[i].maxq, ebw = D.env[i].ebw;
     double q = D.env[i].q, tu = D.env[i].tu;
     const uint32_t episode = D.env[i].episode - 1;
-    uint32_t hn = D.env[i].heap_n, mi_draws = 0, ep_draws = D.env[i].ep_draws;
-    double2 *H = D.noise_heap + (size_t)i * D.noise_cap;
-    double2 *R = D.noise_rtt + (size_t)i * D.noise_cap;
-    NoiseOut o;
-    o.sent = o.acked = o.lost = o.flags = 0;
+    uint32_t mi_draws = 0, ep_draws = D.env[i].ep_draws;
+    uint32_t hn[NS];
+    double2 *H[NS], *R[NS];
+    double nsend[NS];
+    EngineOut<NS> o;
+    o.flags = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int64_t k = (int64_t)s * D.n + i;
+        hn[s] = D.snd[k].heap_n;
+        H[s] = D.noise_heap + (size_t)k * D.noise_cap;
+        R[s] = D.noise_rtt + (size_t)k * D.noise_cap;
+        nsend[s] = nsend0[s];
+        o.sent[s] = o.acked[s] = o.lost[s] = 0;
+    }
     double now = start;
     auto draw = [&]() -> double {
         if (D.rng_mode == PCC_RNG_TRACE) {
@@ -2272,60 +2294,80 @@ __device__ __noinline__ NoiseOut noise_engine(const Dev &D, int64_t i, double st
         ep_draws++;
         return philox_packet_uniform(D, D.gid_base + (uint32_t)i, episode, mi, mi_draws++);
     };
+    auto noisy = [&](double ll) -> double {  // ns:150-151, 171-172
+        if (D.use_noise) ll *= 1.0 + D.noise_span * draw();
+        return ll;
+    };
     while (now < end) {  // ns:128
-        const bool from_heap = hn > 0 && fabs(ld_rec(H).x) <= nsend;  // equal times: the ACK goes first ('A' < 'S')
-        if (from_heap) {
-            const double2 ev = heap_pop(H, hn);
-            now = fabs(ev.x);
-            const double lat = fabs(ev.y);
-            if (sign_of(ev.x)) {  // hop 2 == len(path): the sender hears of it (ns:139-146)
-                if (sign_of(ev.y)) o.lost++;
-                else {
-                    if (o.acked < D.noise_cap) { double2 r; r.x = 0.0; r.y = lat; st_rec(R + o.acked, r); }
+        int bs = 0;
+        bool from_heap = false;
+        double bt = INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (hn[s] > 0) {
+                const double t = fabs(ld_rec(H[s]).x);
+                if (t < bt) { bt = t; bs = s; from_heap = true; }
+            }
+            if (nsend[s] < bt) { bt = nsend[s]; bs = s; from_heap = false; }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (s != bs) continue;
+            if (from_heap) {
+                const double2 ev = heap_pop(H[s], hn[s]);
+                now = fabs(ev.x);
+                const double lat = fabs(ev.y);
+                if (sign_of(ev.x)) {  // hop 2 == len(path): the sender hears of it (ns:139-146)
+                    if (sign_of(ev.y)) o.lost[s]++;
+                    else {
+                        if (o.acked[s] < D.noise_cap) { double2 r; r.x = 0.0; r.y = lat; st_rec(R[s] + o.acked[s], r); }
+                        else o.flags |= PCC_FLAG_RING_OVERFLOW;
+                        o.acked[s]++;
+                    }
+                } else {  // hop 1: over the return link, which never queues (ns:147-153)
+                    const double ll = noisy(dl + max0(0.0 - (now - 0.0)));
+                    double2 nv;
+                    nv.x = -(now + ll);
+                    nv.y = sign_of(ev.y) ? -(lat + ll) : lat + ll;
+                    if (hn[s] < D.noise_cap) heap_push(H[s], hn[s], nv);
                     else o.flags |= PCC_FLAG_RING_OVERFLOW;
-                    o.acked++;
                 }
-            } else {  // hop 1: over the return link, which never queues (ns:147-153)
-                double ll = dl + max0(0.0 - (now - 0.0));
-                ll *= 1.0 + D.noise_span * draw();
+            } else {  // SEND (ns:155-175)
+                now = nsend[s];
+                // USE_CWND (ns:158-160): the packet leaves only while fewer than cwnd of the sender's are unacknowledged
+                // -- every packet in flight is exactly one event of its heap -- but a blocked SEND still takes its noise
+                // draw and passes through the link's queue and loss draw (ns:170-175 are outside the `if`)
+                const bool can_send = hn[s] < cwnd[s];
+                o.sent[s] += can_send ? 1u : 0u;
+                nsend[s] = now + 1.0 / rate[s];  // ns:161
+                const double qd = max0(q - (now - tu));
+                const double ll = noisy(dl + qd);  // drawn before the loss decision (ns:171-175)
+                const double lat = 0.0 + ll;
+                bool dropped;
+                if (draw() < lr) dropped = true;  // ns:73-74
+                else {
+                    q = qd; tu = now;            // ns:75-76
+                    if (ebw + q > maxq) dropped = true;  // ns:78-79
+                    else { q += ebw; dropped = false; }
+                }
                 double2 nv;
-                nv.x = -(now + ll);
-                nv.y = sign_of(ev.y) ? -(lat + ll) : lat + ll;
-                if (hn < D.noise_cap) heap_push(H, hn, nv);
-                else o.flags |= PCC_FLAG_RING_OVERFLOW;
-            }
-        } else {  // SEND (ns:155-175)
-            now = nsend;
-            // USE_CWND as well (ns:158-160): the packet leaves only while fewer than cwnd are unacknowledged -- every
-            // packet in flight is exactly one event of the heap -- but a blocked SEND still takes its noise draw and
-            // passes through the link's queue and loss draw (ns:170-175 are outside the `if`)
-            const bool can_send = hn < cwnd;
-            o.sent += can_send ? 1u : 0u;
-            nsend = now + 1.0 / rate;  // ns:161
-            const double qd = max0(q - (now - tu));
-            double ll = dl + qd;
-            ll *= 1.0 + D.noise_span * draw();  // drawn before the loss decision (ns:171-175)
-            const double lat = 0.0 + ll;
-            bool dropped;
-            if (draw() < lr) dropped = true;  // ns:73-74
-            else {
-                q = qd; tu = now;            // ns:75-76
-                if (ebw + q > maxq) dropped = true;  // ns:78-79
-                else { q += ebw; dropped = false; }
-            }
-            double2 nv;
-            nv.x = now + ll;
-            nv.y = dropped ? -lat : lat;
-            if (can_send) {
-                if (hn < D.noise_cap) heap_push(H, hn, nv);
-                else o.flags |= PCC_FLAG_RING_OVERFLOW;
+                nv.x = now + ll;
+                nv.y = dropped ? -lat : lat;
+                if (can_send) {
+                    if (hn[s] < D.noise_cap) heap_push(H[s], hn[s], nv);
+                    else o.flags |= PCC_FLAG_RING_OVERFLOW;
+                }
             }
         }
     }
-    D.env[i].heap_n = hn;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        D.snd[(int64_t)s * D.n + i].heap_n = hn[s];
+        o.nsend[s] = nsend[s];
+    }
     D.env[i].ep_draws = ep_draws;
     D.env[i].mi_draws = mi_draws;
-    o.now = now; o.nsend = nsend; o.q = q; o.tu = tu;
+    o.now = now; o.q = q; o.tu = tu;
     return o;
 }
 
@@ -2393,9 +2435,7 @@ __device__ __forceinline__ void reset_env(const Dev &D, const int64_t i, float *
     D.env[i].run_dur = 3 * lat;   // ns:467
     D.env[i].steps = 0;
     D.env[i].done = 0;
-    D.env[i].cwnd = 25;       // ns:209, 227
     D.env[i].mi_draws = 0; D.env[i].ep_draws = 0;
-    D.env[i].heap_n = 0;      // latency-noise option: nothing in flight (the first SEND is next_send)
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;
@@ -2403,6 +2443,8 @@ __device__ __forceinline__ void reset_env(const Dev &D, const int64_t i, float *
         D.snd[k].rate0 = rate0[s];
         D.snd[k].next_send = 1.0 / rate0[s];  // ns:111
         D.snd[k].ha = 0; D.snd[k].hd = 0; D.snd[k].ta = 0; D.snd[k].td = 0; D.snd[k].mi_sent = 0;
+        D.snd[k].cwnd = 25;     // ns:209, 227
+        D.snd[k].heap_n = 0;    // event-loop build: nothing in flight (the first SEND is next_send)
         D.snd[k].min_lat = 0.0;   // fresh sender id => no connection minimum yet (ns:229-233, so:158)
         D.snd[k].ack_rate = 0.f; D.snd[k].loss_rate = 0.f; D.snd[k].on_return_a = 0; D.snd[k].on_return_d = 0;
         D.snd[k].ep_return = 0.0;
@@ -2426,7 +2468,6 @@ template <int NS, bool NOISE, int G>
 __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const Group g, int warm, uint32_t warm_mi,
                                             int last_warm, int restart, float *obs_out, float *reward_out, uint8_t *done_out,
                                             double *steps_out, const void *actions, int actions_f64) {
-    static_assert(!NOISE || NS == 1, "the latency-noise option is built for one sender");
     if (warm && !D.env[i].resetting) return -1.0f;
     const bool lead = g.lane == 0;
     // profiling only: where a wavefront's retire time goes (lane 0's view), summed per workgroup
@@ -2466,46 +2507,62 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         amask[s] = rr.mask(); dmasks[s] = rr.dmask();
     }
     uint32_t flags = 0;
-    double noise_rate = 0.0;
+    double noise_rate[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) noise_rate[s] = 0.0;
 
     if constexpr (NOISE) {
-        // the whole interval in the lead lane: rate action (ns:235-241; there is no send half with this option), event loop
-        double rate = D.snd[i].rate;
-        uint32_t cw = D.use_cwnd ? D.env[i].cwnd : 0xFFFFFFFFu;
-        if (!warm) {
-            const int64_t ar = D.use_cwnd ? 2 * i : i;  // USE_CWND as well: [rate action, cwnd action] per env
-            double delta = actions_f64 ? ((const double *)actions)[ar] : (double)((const float *)actions)[ar];
-            if (delta != delta) { delta = 0.0; flags |= PCC_FLAG_BAD_ACTION; }
-            delta *= D.delta_scale;
-            rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
-            if (rate > kMaxRate) rate = kMaxRate;
-            if (rate < kMinRate) rate = kMinRate;
-            if (D.use_cwnd) {  // apply_cwnd_delta + set_cwnd: ns:243-249, 283-289
-                double dc = actions_f64 ? ((const double *)actions)[ar + 1] : (double)((const float *)actions)[ar + 1];
-                if (dc != dc) { dc = 0.0; flags |= PCC_FLAG_BAD_ACTION; }
-                dc *= D.delta_scale;
-                const double c = dc >= 0.0 ? (double)cw * (1.0 + dc) : (double)cw / (1.0 - dc);
-                cw = c >= 5000.0 ? 5000u : (c < 4.0 ? 4u : (uint32_t)c);  // int(), then [MIN_CWND, MAX_CWND] (ns:33-34)
-                if (lead) D.env[i].cwnd = cw;
+        // the event-loop build: the whole interval in the lead lane -- rate (and window) actions (ns:235-249; there is no
+        // send half in this build), then the reference's event loop
+        double rate[NS];
+        uint32_t cw[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int64_t k = (int64_t)s * D.n + i;
+            rate[s] = D.snd[k].rate;
+            cw[s] = D.use_cwnd ? D.snd[k].cwnd : 0xFFFFFFFFu;
+            if (!warm) {
+                const int64_t ar = D.use_cwnd ? 2 * (i * NS + s) : i * NS + s;  // USE_CWND: [rate action, cwnd action] per sender
+                double delta = actions_f64 ? ((const double *)actions)[ar] : (double)((const float *)actions)[ar];
+                if (delta != delta) { delta = 0.0; flags |= PCC_FLAG_BAD_ACTION; }
+                delta *= D.delta_scale;
+                rate[s] = delta >= 0.0 ? rate[s] * (1.0 + delta) : rate[s] / (1.0 - delta);
+                if (rate[s] > kMaxRate) rate[s] = kMaxRate;
+                if (rate[s] < kMinRate) rate[s] = kMinRate;
+                if (D.use_cwnd) {  // apply_cwnd_delta + set_cwnd: ns:243-249, 283-289
+                    double dc = actions_f64 ? ((const double *)actions)[ar + 1] : (double)((const float *)actions)[ar + 1];
+                    if (dc != dc) { dc = 0.0; flags |= PCC_FLAG_BAD_ACTION; }
+                    dc *= D.delta_scale;
+                    const double c = dc >= 0.0 ? (double)cw[s] * (1.0 + dc) : (double)cw[s] / (1.0 - dc);
+                    cw[s] = c >= 5000.0 ? 5000u : (c < 4.0 ? 4u : (uint32_t)c);  // int(), then [MIN_CWND, MAX_CWND] (ns:33-34)
+                    if (lead) D.snd[k].cwnd = cw[s];
+                }
             }
+            noise_rate[s] = rate[s];
         }
-        noise_rate = rate;
-        NoiseOut o;
-        o.now = start; o.nsend = nsend[0]; o.q = 0.0; o.tu = 0.0; o.sent = o.acked = o.lost = o.flags = 0;
+        EngineOut<NS> o;
+        o.now = start; o.q = 0.0; o.tu = 0.0; o.flags = 0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) { o.nsend[s] = nsend[s]; o.sent[s] = o.acked[s] = o.lost[s] = 0; }
         if (lead) {
-            o = noise_engine(D, i, start, end, rate, nsend[0], warm ? warm_mi : steps + 2, cw);
-            D.snd[i].rate = rate;
+            o = event_engine<NS>(D, i, start, end, rate, nsend, warm ? warm_mi : steps + 2, cw);
+#pragma unroll
+            for (int s = 0; s < NS; s++) D.snd[(int64_t)s * D.n + i].rate = rate[s];
             D.env[i].q = o.q; D.env[i].tu = o.tu;
         }
-        // the RTT samples the lead lane stored are read by all 16 lanes below: same wavefront, same L1 -- a workgroup-scope
-        // fence orders them (an agent-scope one writes back and invalidates the XCD's whole L2)
+        // the RTT samples the lead lane stored are read by all lanes of the group below: same wavefront, same L1 -- a
+        // workgroup-scope fence orders them (an agent-scope one writes back and invalidates the XCD's whole L2)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        now = gbcast<G>(o.now, 0); nsend[0] = gbcast<G>(o.nsend, 0);
-        sent[0] = gbcast<G>(o.sent, 0); acked[0] = gbcast<G>(o.acked, 0); lost[0] = gbcast<G>(o.lost, 0);
+        now = gbcast<G>(o.now, 0);
         flags |= gbcast<G>(o.flags, 0);
-        ra[0] = D.noise_rtt + (size_t)i * D.noise_cap;
-        amask[0] = D.noise_cap - 1u;
-        from[0] = 0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            nsend[s] = gbcast<G>(o.nsend[s], 0);
+            sent[s] = gbcast<G>(o.sent[s], 0); acked[s] = gbcast<G>(o.acked[s], 0); lost[s] = gbcast<G>(o.lost[s], 0);
+            ra[s] = D.noise_rtt + ((size_t)s * D.n + i) * D.noise_cap;
+            amask[s] = D.noise_cap - 1u;
+            from[s] = 0;
+        }
     } else if (start < end) {  // ns:128: otherwise the loop body never runs
         // candidates for the MI-ending event per sender: hop-1, hop-2 (with the ring it sits in)
         double t_h1[NS], t_h2[NS], l_h2[NS];
@@ -2632,7 +2689,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                 }
                 // USE_CWND (ns:251-255): everything due before this event is retired, so what is in
                 // flight is exactly what the rings still hold
-                const bool can_send = !D.use_cwnd || (ta[s] - ha[s]) + (td[s] - hd[s]) < D.env[i].cwnd;
+                const bool can_send = !D.use_cwnd || (ta[s] - ha[s]) + (td[s] - hd[s]) < D.snd[(int64_t)s * D.n + i].cwnd;
                 if (D.use_cwnd && lead) D.env[i].ep_draws += 1u;
                 const double rate = D.snd[(int64_t)s * D.n + i].rate;
                 sent[s] += can_send ? 1u : 0u;
@@ -2716,7 +2773,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         }
         double min_lat = D.snd[k].min_lat;
         const double ep_before = D.snd[k].ep_return;
-        const double rate_now = NOISE ? noise_rate : D.snd[k].rate;
+        const double rate_now = NOISE ? noise_rate[s] : D.snd[k].rate;
         rate_sum += rate_now;
         double m[PCC_N_METRICS];
         mi_metrics(sent[s], acked[s], lost[s], dur, lat, inc, min_lat, m);
@@ -3397,15 +3454,19 @@ int launch_retire(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int
 
 int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, int restart, const void *actions,
               int actions_f64, float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out, hipStream_t st) {
-    if (sim->d.use_noise) {
-        // the latency-noise option: the whole interval is one launch of the retire kernel's NOISE build (no send half,
-        // no work lists)
+    if (sim->d.engine) {
+        // the event-loop build (latency noise; the congestion window with two senders): the whole interval is one launch of
+        // the retire kernel's NOISE build (no send half, no work lists)
         const Dev &d = sim->d;
         const int64_t per_block = kRetireMaxPerBlock;
         const dim3 grid((unsigned)((d.n + per_block - 1) / per_block));
-        hipLaunchKernelGGL((retire_kernel<1, true>), grid, dim3(kRetireBlock), 0, st, d, -1, -1, warm, warm_mi, last_warm, gate,
-                           0, obs_out, reward_out, done_out, steps_out, actions, actions_f64);
-        return check_hip(hipGetLastError(), "noise kernel launch");
+        if (d.ns == 1)
+            hipLaunchKernelGGL((retire_kernel<1, true>), grid, dim3(kRetireBlock), 0, st, d, -1, -1, warm, warm_mi, last_warm, gate,
+                               0, obs_out, reward_out, done_out, steps_out, actions, actions_f64);
+        else
+            hipLaunchKernelGGL((retire_kernel<2, true>), grid, dim3(kRetireBlock), 0, st, d, -1, -1, warm, warm_mi, last_warm, gate,
+                               0, obs_out, reward_out, done_out, steps_out, actions, actions_f64);
+        return check_hip(hipGetLastError(), "event-loop kernel launch");
     }
     const int rc = launch_send(sim, warm, warm_mi, gate, actions, actions_f64, st);
     if (rc != PCC_OK) return rc;
@@ -3432,7 +3493,7 @@ int launch_reset(pcc_sim_t *sim, const uint8_t *mask, int use_done, int gate, fl
 // send half can take such items: not with the congestion-window option (no wave path) or the latency-noise
 // option (no send half) -- those keep the gated reset launches after the step.
 bool restarts_in_step(const pcc_sim_t *sim, int auto_reset) {
-    return auto_reset && !sim->lockstep && !sim->d.use_cwnd && !sim->d.use_noise && sim->d.n >= (int64_t)sim->list_min_envs;
+    return auto_reset && !sim->lockstep && !sim->d.use_cwnd && !sim->d.engine && sim->d.n >= (int64_t)sim->list_min_envs;
 }
 
 // What is still owed to the envs of the restart list -- new links, fresh state, the two warm-up intervals -- is
@@ -3757,38 +3818,47 @@ int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t di
     return PCC_OK;
 }
 
+// The event-loop build (event_engine) runs the interval when packets can overtake each other (latency noise) and when
+// windows couple two senders' SEND streams to their notifications; it needs a heap and an RTT list per sender.
+int update_engine(pcc_sim_t *sim) {
+    const int engine = (sim->d.use_noise || (sim->d.use_cwnd && sim->d.ns > 1)) ? 1 : 0;
+    if (engine && !sim->noise_blob) {
+        DeviceGuard guard(sim->device);
+        const size_t per = (size_t)sim->d.n * sim->d.ns * sim->ring_capacity * sizeof(double2);
+        void *p = nullptr;
+        if (hipMalloc(&p, 2 * per) != hipSuccess)
+            return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the event heaps failed", 2 * per);
+        sim->noise_blob = p;
+        sim->noise_bytes = 2 * per;
+        sim->d.noise_heap = static_cast<double2 *>(p);
+        sim->d.noise_rtt = sim->d.noise_heap + (size_t)sim->d.n * sim->d.ns * sim->ring_capacity;
+        sim->d.noise_cap = sim->ring_capacity;
+    }
+    sim->d.engine = engine;
+    sim->ever_reset = false;  // in-flight accounting differs / lives in another structure: a reset must follow
+    sim->read_buf = -1;
+    return PCC_OK;
+}
+
 int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
-    if (enable && sim->d.ns != 1) return fail(PCC_EINVAL, "the congestion-window option supports one sender per env");
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_cwnd_mode between pcc_step_send and pcc_step_retire");
+    const int before = sim->d.use_cwnd;
     sim->d.use_cwnd = enable ? 1 : 0;
-    sim->ever_reset = false;  // in-flight accounting differs: a reset must follow
-    return PCC_OK;
+    const int rc = update_engine(sim);
+    if (rc != PCC_OK) sim->d.use_cwnd = before;
+    return rc;
 }
 
 int pcc_set_latency_noise(pcc_sim_t *sim, int enable, double max_noise) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_latency_noise between pcc_step_send and pcc_step_retire");
-    if (enable) {
-        if (sim->d.ns != 1) return fail(PCC_EINVAL, "the latency-noise option supports one sender per env");
-        if (!(max_noise >= 1.0) || !(max_noise <= 16.0)) return fail(PCC_EINVAL, "max_noise must be in [1, 16] (the reference: 1.1)");
-        if (!sim->noise_blob) {
-            DeviceGuard guard(sim->device);
-            const size_t per = (size_t)sim->d.n * sim->ring_capacity * sizeof(double2);
-            void *p = nullptr;
-            if (hipMalloc(&p, 2 * per) != hipSuccess)
-                return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the latency-noise event heaps failed", 2 * per);
-            sim->noise_blob = p;
-            sim->noise_bytes = 2 * per;
-            sim->d.noise_heap = static_cast<double2 *>(p);
-            sim->d.noise_rtt = sim->d.noise_heap + (size_t)sim->d.n * sim->ring_capacity;
-            sim->d.noise_cap = sim->ring_capacity;
-        }
-        sim->d.noise_span = max_noise - 1.0;  // random.uniform(a, b) = a + (b - a) * random()
-    }
+    if (enable && (!(max_noise >= 1.0) || !(max_noise <= 16.0))) return fail(PCC_EINVAL, "max_noise must be in [1, 16] (the reference: 1.1)");
+    const int before = sim->d.use_noise;
     sim->d.use_noise = enable ? 1 : 0;
-    sim->ever_reset = false;  // the in-flight packets live in another structure: a reset must follow
-    sim->read_buf = -1;
+    const int rc = update_engine(sim);
+    if (rc != PCC_OK) { sim->d.use_noise = before; return rc; }
+    if (enable) sim->d.noise_span = max_noise - 1.0;  // random.uniform(a, b) = a + (b - a) * random()
     return PCC_OK;
 }
 
@@ -3848,7 +3918,7 @@ int pcc_step_send(pcc_sim_t *sim, const void *actions, int actions_f64, void *st
     if (!sim || !actions) return fail(PCC_EINVAL, "NULL argument");
     if (!sim->ever_reset) return fail(PCC_ESTATE, "pcc_step before pcc_reset (the reference raises TypeError: run_dur is None)");
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_step_send called twice without pcc_step_retire");
-    if (sim->d.use_noise) return fail(PCC_ESTATE, "the latency-noise option has no separate send half: use pcc_step");
+    if (sim->d.engine) return fail(PCC_ESTATE, "the event-loop build (latency noise; congestion window with two senders) has no separate send half: use pcc_step");
     DeviceGuard guard(sim->device);
     const int rc = launch_send(sim, 0, 0, 0, actions, actions_f64, static_cast<hipStream_t>(stream));
     if (rc == PCC_OK) sim->send_pending = true;
@@ -3876,7 +3946,7 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Dev &d = sim->d;
-    if (d.n < (int64_t)sim->list_min_envs && !d.use_noise) {
+    if (d.n < (int64_t)sim->list_min_envs && !d.engine) {
         // a small batch: both halves in one launch (step_small_kernel)
         const dim3 grid((unsigned)((d.n + kWave - 1) / kWave)), block(4 * kWave);
         const bool tr = d.rng_mode == PCC_RNG_TRACE;
@@ -3928,7 +3998,7 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {
         case PCC_F_LAST_RETURN: PCC_SND_FIELD(last_return);
         case PCC_F_TOTAL_SENT: PCC_ENV_FIELD(total_sent);
         case PCC_F_RING_TIER: PCC_SND_FIELD(ring_tier);
-        case PCC_F_CWND: PCC_ENV_FIELD(cwnd);
+        case PCC_F_CWND: PCC_SND_FIELD(cwnd);
         default: return fail(PCC_EINVAL, "unknown field %d", field);
     }
 #undef PCC_ENV_FIELD

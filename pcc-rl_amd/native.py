@@ -25,7 +25,7 @@ FIELDS = {
     "rate0": (12, "float64", True), "next_send": (13, "float64", True), "min_lat": (14, "float64", True),
     "acc_head": (15, "int32", True), "acc_tail": (16, "int32", True), "drop_head": (17, "int32", True),
     "drop_tail": (18, "int32", True), "ep_return": (19, "float64", True), "last_return": (20, "float64", True),
-    "total_sent": (21, "int64", False), "ring_tier": (22, "uint8", True), "cwnd": (23, "int32", False),
+    "total_sent": (21, "int64", False), "ring_tier": (22, "uint8", True), "cwnd": (23, "int32", True),
 }
 
 # every symbol include/pcc_sim.h declares

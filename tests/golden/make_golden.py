@@ -232,15 +232,21 @@ def gen_single(ns, name, seeds, action_fn, n_steps=400, **kw):
         name, len(cases), n_steps, os.path.basename(path), os.path.getsize(path) / 1024.0))
 
 
-def gen_two_sender(ns, name, seeds, n_steps=200):
+def gen_two_sender(ns, name, seeds, n_steps=200, cwnd=False, noise=False):
     """Engine-level two-sender cases.
 
     SimulatedNetworkEnv never builds a second sender, so the harness drives the
     reference Link/Sender/Network classes directly with the env's own step
     protocol applied to both senders, and adds the lower-id-first tie-break
     (Sender.__lt__) the engine needs when two senders' events collide.
+
+    cwnd / noise switch the engine's dormant USE_CWND / USE_LATENCY_NOISE module flags on (ns:51-54: they are read by
+    Network.run_for_dur for whatever senders it holds); with cwnd every sender gets its own [rate action, cwnd action]
+    per step, applied like the env applies sender 0's (ns:412-414).
     """
     ns.Sender.__lt__ = lambda a, b: a.id < b.id
+    ns.USE_CWND = bool(cwnd)
+    ns.USE_LATENCY_NOISE = bool(noise)
     feats = DEFAULT_FEATURES.split(",")
     all_cases = []
     for seed in seeds:
@@ -262,11 +268,16 @@ def gen_two_sender(ns, name, seeds, n_steps=200):
         warm = [net.cur_time, len(net.q)]
         rs = np.random.RandomState(seed)
         actions = rs.uniform(-1.0, 1.0, (n_steps, 2))
+        cwnd_actions = rs.uniform(-1.0, 3.0, (n_steps, 2)) if cwnd else np.zeros((n_steps, 2))
         rows = [[], []]
         obs_tail = [[], []]
+        cwnds = []
         for t in range(n_steps):
             for i in range(2):
                 senders[i].apply_rate_delta(actions[t, i])
+                if cwnd:
+                    senders[i].apply_cwnd_delta(cwnd_actions[t, i])
+            cwnds.append([senders[0].cwnd, senders[1].cwnd])
             net.run_for_dur(run_dur)
             for s in senders:
                 s.record_run()
@@ -287,13 +298,16 @@ def gen_two_sender(ns, name, seeds, n_steps=200):
                 rows[i][-1][5] = run_dur
         all_cases.append(dict(seed=seed, params=[bw, lat, queue, loss, r0, r1, 3 * lat], warm=warm,
                               rng=[6, rng.n],
-                              actions=actions, steps=np.array(rows, dtype=np.float64),
+                              actions=actions, cwnd_actions=cwnd_actions, cwnd=np.array(cwnds, dtype=np.int64),
+                              steps=np.array(rows, dtype=np.float64),
                               obs_tail=np.array(obs_tail, dtype=np.float64)))
     d = dict(seed=np.array([c["seed"] for c in all_cases], dtype=np.int64),
              params=np.array([c["params"] for c in all_cases], dtype=np.float64),
              warm=np.array([c["warm"] for c in all_cases], dtype=np.float64),
              rng=np.array([c["rng"] for c in all_cases], dtype=np.int64),
              actions=np.stack([c["actions"] for c in all_cases]),
+             cwnd_actions=np.stack([c["cwnd_actions"] for c in all_cases]),   # [case, step, sender] (zeros without cwnd)
+             cwnd=np.stack([c["cwnd"] for c in all_cases]),            # [case, step, sender] window after the step's action
              steps=np.stack([c["steps"] for c in all_cases]),          # [case, sender, step, 19]
              obs_tail=np.stack([c["obs_tail"] for c in all_cases]),    # [case, sender, step, 3]
              columns=np.array(["sent", "acked", "lost", "rate", "cur_time", "run_dur",
@@ -303,6 +317,8 @@ def gen_two_sender(ns, name, seeds, n_steps=200):
     print("%-28s %3d cases x %d steps  -> %s (%.0f KiB)" % (
         name, len(all_cases), n_steps, os.path.basename(path), os.path.getsize(path) / 1024.0))
     del ns.Sender.__lt__
+    ns.USE_CWND = False
+    ns.USE_LATENCY_NOISE = False
 
 
 def main():
@@ -344,6 +360,10 @@ def main():
         # both dormant options at once (module globals: they apply together like they apply alone)
         gen_single(ns, "cwnd_noise_pm1", range(700, 706), uniform_pm1_pairs, cwnd=True, noise=True)
         gen_single(ns, "cwnd_noise_grow", range(720, 723), rate_pm1_cwnd_up, n_steps=200, cwnd=True, noise=True)
+        # ... and with two senders on the bottleneck (the flags apply to whatever senders the engine holds)
+        gen_two_sender(ns, "two_sender_cwnd", range(800, 804), cwnd=True)
+        gen_two_sender(ns, "two_sender_noise", range(820, 824), noise=True)
+        gen_two_sender(ns, "two_sender_cwnd_noise", range(840, 843), cwnd=True, noise=True)
     finally:
         os.chdir(cwd)
 

@@ -632,7 +632,7 @@ def test_use_cwnd_goldens_bit_exact(name):
     for t in range(T):
         o, r, dn, info = env.step(d["actions"][:, t])          # [n, 2]
         rows.append(info["steps"].clone())
-        cw.append(env.state("cwnd").clone())
+        cw.append(env.state("cwnd")[0].clone())
     env.check_flags()
     steps = torch.stack(rows, 1).cpu().numpy()
     assert np.array_equal(torch.stack(cw, 1).cpu().numpy(), d["cwnd"])
@@ -717,7 +717,7 @@ def test_both_engine_options_together_goldens_bit_exact(name):
     steps = torch.stack(rows, 1).cpu().numpy()
     assert np.array_equal(steps[..., :3], d["steps"][..., :3])
     assert np.array_equal(steps, d["steps"])
-    assert np.array_equal(env.state("cwnd").cpu().numpy(), d["cwnd"][:, -1])
+    assert np.array_equal(env.state("cwnd")[0].cpu().numpy(), d["cwnd"][:, -1])
     env.close()
 
 
@@ -821,10 +821,76 @@ def test_engine_options_out_of_lockstep_match_oracle(option):
     env.close()
 
 
-def test_latency_noise_refuses_what_it_does_not_cover():
-    env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, n_senders=2, auto_reset=False)
+@pytest.mark.parametrize("name,cwnd,noise", [("two_sender_cwnd", True, False), ("two_sender_noise", False, True),
+                                             ("two_sender_cwnd_noise", True, True)])
+def test_engine_options_with_two_senders_goldens_bit_exact(name, cwnd, noise):
+    """The reference's dormant flags with two senders on the bottleneck (the flags are module globals the engine reads for
+    whatever senders it holds, ns:51-54): every sender its own window and [rate action, cwnd action]; events of equal time
+    in (sender id, ACK before SEND) order.  The event-loop build, replaying the reference's own uniform stream."""
+    d = load(name)
+    d["features"] = np.array(pcc_rl_amd.DEFAULT_FEATURES.split(","))
+    n = d["seed"].shape[0]
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, n_senders=2, record_steps=True, auto_reset=False, use_cwnd=cwnd,
+                                       latency_noise=1.1 if noise else None)
+    p = d["params"]
+    env.set_link_params(p[:, 0], p[:, 1], np.round(p[:, 2]), p[:, 3], p[:, 4:6])
+    k = int((d["rng"][:, 1] - d["rng"][:, 0]).max())
+    env.set_loss_trace(np.stack([oracle.mt_uniforms(int(sd), k, skip=int(o)) for sd, o in zip(d["seed"], d["rng"][:, 0])]))
+    env.reset()
+    assert np.array_equal(env.state("now").cpu().numpy(), d["warm"][:, 0])
+    acts = np.stack([d["actions"], d["cwnd_actions"]], axis=3) if cwnd else d["actions"]      # [case, step, sender(, 2)]
+    a = torch.as_tensor(acts, dtype=torch.float64, device=DEV)
+    rows, obs, cw = [], [], []
+    for t in range(acts.shape[1]):
+        o, r, dn, info = env.step(a[:, t])
+        rows.append(info["steps"].clone()); obs.append(o.clone())
+        cw.append(env.state("cwnd").clone())
+    env.check_flags()
+    steps = torch.stack(rows, 2).cpu().numpy()
+    assert np.array_equal(steps[..., :3], d["steps"][..., :3])
+    assert np.array_equal(steps, d["steps"])
+    assert np.array_equal(torch.stack(obs, 2).cpu().numpy()[..., -3:], d["obs_tail"].astype(np.float32))
+    if cwnd:
+        assert np.array_equal(torch.stack(cw, 0).permute(2, 0, 1).cpu().numpy(), d["cwnd"])      # [case, step, sender]
+    env.close()
+
+
+@pytest.mark.parametrize("cwnd,noise", [(True, False), (False, True), (True, True)])
+def test_engine_options_with_two_senders_philox_batches_match_oracle(cwnd, noise):
+    """... and on the device's own Philox stream against the oracle, over an episode boundary (auto-reset out of lockstep:
+    the gated reset launches of the event-loop build)."""
+    n_envs, n_steps, seed = 150, 60, 91
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, n_senders=2, record_steps=True, use_cwnd=cwnd,
+                                       latency_noise=1.1 if noise else None, max_steps=n_steps // 2)
+    env.reset()
+    rs = np.random.RandomState(seed)
+    rate_a, cwnd_a = rs.uniform(-1, 1, (n_envs, n_steps, 2)), rs.uniform(-1, 3, (n_envs, n_steps, 2))
+    acts = np.stack([rate_a, cwnd_a], axis=3) if cwnd else rate_a
+    a = torch.as_tensor(acts, dtype=torch.float64, device=DEV)
+    rows = []
+    for t in range(n_steps):
+        o, r, dn, info = env.step(a[:, t])
+        rows.append(info["steps"].clone())
+        assert bool(dn.all()) == (t % (n_steps // 2) == n_steps // 2 - 1)
+    env.check_flags()
+    steps = torch.stack(rows, 2).cpu().numpy()
+    half = n_steps // 2
+    kw = dict(n_senders=2, rng_mode=oracle.RNG_PHILOX, seed=seed, latency_noise=1.1 if noise else None, want_obs=False)
+    ref1 = oracle.run_batch(rate_a[:, :half], cwnd_actions=cwnd_a[:, :half] if cwnd else None, **kw)
+    assert np.array_equal(steps[:, :, :half, :3], ref1["steps"][..., :3])
+    assert np.array_equal(steps[:, :, :half], ref1["steps"])
+    ref2 = oracle.run_batch(rate_a[:, half:], cwnd_actions=cwnd_a[:, half:] if cwnd else None, n_episodes=2, **kw)
+    assert np.array_equal(steps[:, :, half:], ref2["steps"])
+    plain = oracle.run_batch(rate_a[:, :half], n_senders=2, rng_mode=oracle.RNG_PHILOX, seed=seed, want_obs=False)
+    assert not np.array_equal(plain["steps"], ref1["steps"])       # the options really are on
+    env.close()
+
+
+def test_event_loop_build_has_no_send_half():
+    env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, n_senders=2, use_cwnd=True, auto_reset=False)
+    env.reset()
     with pytest.raises(pcc_rl_amd.PccError):
-        pcc_rl_amd.native.check(env._L.pcc_set_latency_noise(env._h, 1, 1.1))
+        env.step_send(torch.zeros(8, 2, 2, device=DEV))
     env.close()
     env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, latency_noise=1.1, auto_reset=False)
     env.reset()

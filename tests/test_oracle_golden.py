@@ -223,3 +223,34 @@ def test_both_engine_options_together_bit_exact(name):
         check_episode(env, d, i)
         assert env.rng_draws == int(d["rng"][i][1])
         env.close()
+
+
+@pytest.mark.parametrize("name,cwnd,noise", [("two_sender_cwnd", True, False), ("two_sender_noise", False, True),
+                                             ("two_sender_cwnd_noise", True, True)])
+def test_engine_options_with_two_senders_bit_exact(name, cwnd, noise):
+    """The dormant options are module globals the engine reads for whatever senders it holds (ns:51-54, 150-175): two
+    senders on the bottleneck, every sender with its own window and its own [rate action, cwnd action]."""
+    d = load(name)
+    for i in range(d["seed"].shape[0]):
+        bw, lat, queue, loss, r0, r1, run_dur0 = d["params"][i]
+        env = oracle.OracleEnv(2, 10, oracle.DEFAULT_FEATURES)
+        env.rng_mt(int(d["seed"][i]), skip=6)
+        env.set_params(bw, lat, queue, loss, [r0, r1])
+        if cwnd:
+            env.use_cwnd(True)
+        if noise:
+            env.use_latency_noise(True, 1.1)
+        env.reset()
+        assert env.cur_time == d["warm"][i][0] and env.heap_len == int(d["warm"][i][1])
+        for t in range(d["actions"].shape[1]):
+            a = np.stack([d["actions"][i, t], d["cwnd_actions"][i, t]], axis=1) if cwnd else d["actions"][i, t]
+            obs, rew, done, _ = env.step(a)
+            for s in range(2):
+                assert np.array_equal(env.last_row[s], d["steps"][i, s, t]), (i, s, t)
+                assert np.array_equal(obs[s][-3:], d["obs_tail"][i, s, t])
+                if cwnd:
+                    assert env.cwnd(s) == int(d["cwnd"][i, t, s])
+        assert env.rng_draws == int(d["rng"][i][1])
+        env.close()
+    if cwnd:   # the windows did limit the senders: fewer packets than the same links carry without the option
+        assert (d["cwnd"] != 25).any()

@@ -76,3 +76,20 @@ def test_use_latency_noise_option():
         check(PyOracleEnv(seed=int(d["seed"][i]), latency_noise=1.1), d, i)
     d = load("noise_fixed_lossy")
     check(PyOracleEnv(seed=int(d["seed"][0]), fixed=tuple(d["fixed"]), latency_noise=1.1), d, 0)
+
+
+def test_engine_options_with_two_senders():
+    for name, cwnd, noise in (("two_sender_cwnd", True, False), ("two_sender_noise", False, True),
+                              ("two_sender_cwnd_noise", True, True)):
+        d = load(name)
+        i = 1
+        bw, lat, queue, loss, r0, r1, _ = d["params"][i]
+        env = PyOracleEnv(seed=int(d["seed"][i]), n_senders=2, fixed=(bw, lat, queue, loss, r0, r1), ctor_draws=6,
+                          use_cwnd=cwnd, latency_noise=1.1 if noise else None)
+        env.reset()
+        assert env.now == d["warm"][i][0]
+        for t in range(d["actions"].shape[1]):
+            a = np.stack([d["actions"][i, t], d["cwnd_actions"][i, t]], axis=1) if cwnd else d["actions"][i, t]
+            obs, rew, done, _ = env.step(a)
+            for s in range(2):
+                assert np.array_equal(np.array(env.last_rows[s], dtype=np.float64), d["steps"][i, s, t]), (name, s, t)
