@@ -61,15 +61,54 @@ def spawn_ranks(args):
 
 
 def pmc_traffic():
-    """HBM bytes per launch from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, separate passes over this same script; see profiles/README.md).  Counters cannot be
-    read from inside the process, so the figure is the profile's, labelled with its source and window."""
+    """HBM bytes per launch from the newest committed PMC summary (profiles/*_pmc_hbm.json): the fallback when the
+    counter passes of this run (pmc_passes) are switched off or fail; labelled with its source and window."""
     pdir = os.path.join(ROOT, "profiles")
     names = sorted((n for n in os.listdir(pdir) if n.endswith("_pmc_hbm.json")), reverse=True) if os.path.isdir(pdir) else []
     for name in names:
         with open(os.path.join(pdir, name)) as f:
             return json.load(f), "profiles/" + name
     return None, None
+
+
+def pmc_passes(config, timeout_s=150):
+    """HBM traffic of this run's code on this run's GPU: two more runs of this script -- one whole episode each, no CPU
+    baseline, nothing timed -- under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes with
+    --kernel-trace only, as MI355X_MICROARCH.md prescribes), aggregated per kernel by tools/pmc_aggregate.py.  Returns
+    (summary, None) or (None, why not)."""
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_aggregate
+    except ImportError as e:
+        return None, "tools/pmc_aggregate.py: %s" % e
+    tmp = tempfile.mkdtemp(prefix="pcc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    dirs, line = [], None
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter.lower())
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--config", str(config), "--steps", "400", "--warmup", "20", "--repeats", "1",
+                   "--no-cpu-baseline", "--no-pmc"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "the %s pass took more than %d s" % (counter, timeout_s)
+            lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return None, "the %s pass failed (exit code %d)" % (counter, r.returncode)
+            line = lines[-1]
+            dirs.append(d)
+        return pmc_aggregate.aggregate(dirs, bench_line=line), None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(seconds_budget=15.0):
@@ -190,6 +229,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself")
     ap.add_argument("--ring-capacity", type=int, default=0, help="records per accepted ring (0 = library default)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 counter passes that measure roofline.traffic (HBM bytes per launch)")
     ap.add_argument("--groups", type=int, default=0,
                     help="also measure the same envs as this many independent groups on their own streams "
                          "(supplementary field async_groups)")
@@ -415,16 +456,36 @@ def main():
                                               "frac": retire_gbps / HBM_PEAK_GBPS, "kernel_ms": retire_ms,
                                               "algorithmic_bytes_per_launch": retire_bytes}],
                            "whole_step": {"achieved": both, "frac": both / HBM_PEAK_GBPS}}
-        pmc, src = pmc_traffic()
+        # HBM traffic from the counters: measured now, by two profiled runs of this script (unless --no-pmc / not one GPU);
+        # else the newest committed summary, labelled as such
         kname = out["roofline"]["kernel"]
-        if pmc and N == 65536 and cfg == 3 and kname in pmc and pmc[kname].get("launches", 0) >= 50:
-            out["roofline"]["traffic"] = pmc[kname].get("hbm_bytes_per_launch", pmc[kname]["hbm_bytes_per_launch_raw"])
-            out["roofline"]["traffic_source"] = (src + ": 2 x FETCH_SIZE + WRITE_SIZE (KB units x 1024; the factor 2 is this repo's calibration, profiles/r02_pmc_calibration.json) of a SEPARATE profiled run "
-                                                 "of this script (code at commit " + str(pmc.get("_commit", "?")) + ") over " + str(pmc.get("_window", "steps 20..120 of an episode")) +
-                                                 "; compare it with that window's algorithmic bytes (in the profile), not this run's")
+        pmc, src, why = None, None, "--no-pmc"
+        if not args.no_pmc and world == 1:
+            pmc, why = pmc_passes(cfg)
+            src = "measured by this run"
+        live = pmc is not None
+        if pmc is None and N == 65536 and cfg == 3:
+            pmc, src = pmc_traffic()
+        if pmc and kname in pmc and pmc[kname].get("launches", 0) >= 50 and "hbm_bytes_per_launch" in pmc[kname]:
+            out["roofline"]["traffic"] = pmc[kname]["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_over_algorithmic"] = pmc[kname].get("traffic_over_algorithmic")
+            what = ("2 x FETCH_SIZE + WRITE_SIZE (KB units x 1024; the factor 2 is this repo's calibration, "
+                    "profiles/r02_pmc_calibration.json), rocprofv3 --pmc in separate passes")
+            if live:
+                out["roofline"]["traffic_source"] = (src + ": " + what + " over two more runs of this script on this GPU, one whole "
+                                                     "episode each (after 20 warm-up steps); traffic_over_algorithmic compares it with "
+                                                     "THAT window's algorithmic bytes")
+            else:
+                out["roofline"]["traffic_source"] = (src + " (the counter passes of this run: " + str(why) + "): " + what + " of a SEPARATE "
+                                                     "profiled run of this script (code at commit " + str(pmc.get("_commit", "?")) + ") over " +
+                                                     str(pmc.get("_window", "steps 20..120 of an episode")) + "; compare it with that "
+                                                     "window's algorithmic bytes (in the profile), not this run's")
             for other in out["roofline"].get("other_kernels", []):
-                if other["kernel"] in pmc and pmc[other["kernel"]].get("launches", 0) >= 50:
-                    other["traffic"] = pmc[other["kernel"]].get("hbm_bytes_per_launch", pmc[other["kernel"]]["hbm_bytes_per_launch_raw"])
+                if other["kernel"] in pmc and pmc[other["kernel"]].get("launches", 0) >= 50 and "hbm_bytes_per_launch" in pmc[other["kernel"]]:
+                    other["traffic"] = pmc[other["kernel"]]["hbm_bytes_per_launch"]
+                    other["traffic_over_algorithmic"] = pmc[other["kernel"]].get("traffic_over_algorithmic")
+        elif why:
+            out["roofline"]["traffic_source"] = "none: " + str(why)
         if world == 1 and args.groups > 1:
             out["async_groups"] = async_groups(pcc_rl_amd, torch, N, dev, K, W, args.groups)
         if not args.no_cpu_baseline and world == 1:
