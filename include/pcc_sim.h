@@ -171,7 +171,7 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
 enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_SEND_ENVS_PER_WAVE = 4 /* envs per light work item, 1..64 */,
        PCC_TUNE_HEAVY_PREDICT = 5 /* predicted packets per interval above which an env is a work item of
-                                    its own (wave path); default 512, 0 = every env, >= 1e9 = none */,
+                                    its own (wave path); default 512 (two senders: 1024), 0 = every env, >= 1e9 = none */,
        PCC_TUNE_SEND_WAVES = 8 /* persistent send wavefronts per compute unit, 1..32 (default 16) */,
        PCC_TUNE_TEAM_PREDICT = 9 /* predicted packets per interval above which an env is sent by a whole workgroup (four
                                     wavefronts, 1 024 packets per pass); default 4096, >= 1e9 = never (one sender only) */,

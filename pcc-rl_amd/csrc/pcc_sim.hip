@@ -1049,6 +1049,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
     const uint32_t caps[2] = {cap0, cap1};
     const uint64_t lt = (1ull << lane) - 1ull;
     const double gap[2] = {gap0, gap1};
+    uint32_t chain_left = 0;  // passes to send by the accept chain before the token pass is tried again
     while ((st.t[0] < st.t[1] ? st.t[0] : st.t[1]) < end) {
         // ---- loss decisions of the next 64 packets of the merged stream
         uint64_t rm;
@@ -1115,6 +1116,104 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             const uint64_t vmask = __ballot(valid);
             nv = (uint32_t)__popcll(vmask);  // merged times increase: valid lanes are a prefix
             const uint64_t rmask = rm;
+            // ---- token pass: the queue stays backlogged in one binade (heavy_mi's regime B, here for the merged stream).
+            // Every quantity is a multiple of u = ulp(q): the queue in front of merged position p is
+            // x_p = Q0 + j_p R - D_p (j_p packets accepted before it, D_p = t_p - tu), it is accepted iff it is not lost at
+            // random and x_p + R <= maxq, i.e. iff tokens are left: b_p = N_p - j_p > 0 with N_p = floor((M - Q0 + D_p) / R).
+            // b_{p+1} = max(b_p - m_p, 0) + (N_{p+1} - N_p) is a Lindley map per position -- uneven token arrivals, because the
+            // two senders' send times interleave unevenly -- and the maps compose by one prefix scan (lind_exclusive_scan).
+            // A position whose queue runs empty or leaves the binade ends the pass in front of it; the accept chain below
+            // (no precondition) takes over from there.
+            bool committed = false;
+            if (chain_left) {
+                chain_left--;
+            } else {
+                const uint32_t e = exponent_bits(st.q), eb = exponent_bits(ebw);
+                const double T0 = rl_f64(tk, 0);
+                const double x0 = st.q - (T0 - st.tu);
+                bool okb = (st.q > 0.0) && e > 64u && e < 1100u && (x0 > 0.0) && eb <= e && exponent_bits(st.tu) >= e &&
+                           exponent_bits(maxq) >= e;
+                double u = 0.0, R = 0.0;
+                int64_t Q0i = 0, Ri = 1, Mi = 0, Dsi[2] = {0, 0}, Gsi[2] = {0, 0};
+                bool free_mode = false, maxq_above = false;
+                if (okb) {
+                    u = pow2_f64((int)e - 1023 - 52);
+                    const double inv_u = pow2_f64(-((int)e - 1023 - 52));
+                    const double probe = pow2_f64((int)e - 1023);
+                    R = (eb == e) ? ebw : (probe + ebw) - probe;   // 1/bw on the grid of u (ns:82 rounds x + 1/bw to it)
+                    const double err = ebw - R;
+                    const bool tie = fabs(err) == 0.5 * u;
+                    okb = (tend_max - st.tu) * inv_u < 4.0e18 && R > 0.0;
+                    if (okb) {
+                        Q0i = (int64_t)(st.q * inv_u);
+                        Ri = (int64_t)(R * inv_u);
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; s2++) {
+                            Dsi[s2] = (int64_t)((st.t[s2] - st.tu) * inv_u);   // exact: tu <= t <= 2 tu, multiples of u
+                            Gsi[s2] = (int64_t)(G[s2] * inv_u);
+                        }
+                        const double room = ((maxq - R) - x0) / R;   // packets of room in the queue (estimate)
+                        free_mode = room >= 64.0 + 44.0;              // nothing of this pass can be tail-dropped
+                        Mi = free_mode ? 0 : (int64_t)(maxq * inv_u);
+                        // a tie rounds to even: x + R holds only while every x is an even multiple of u
+                        if (tie && ((Q0i | Dsi[0] | Dsi[1] | Gsi[0] | Gsi[1]) & 1)) okb = false;
+                        maxq_above = exponent_bits(maxq) > e;
+                    }
+                }
+                if (okb) {
+                    const uint32_t cme = my_s ? c1 : c0;   // this packet is its sender's cme-th of the pass
+                    const int64_t Dp = (my_s ? Dsi[1] : Dsi[0]) + (int64_t)cme * (my_s ? Gsi[1] : Gsi[0]);
+                    const bool m = valid && !((rmask >> lane) & 1ull);   // reaches the queue
+                    bool acc;
+                    int jb;   // packets accepted before this position
+                    if (free_mode) {
+                        acc = m;
+                        jb = (int)__popcll(__ballot(acc) & lt);
+                    } else {
+                        // tokens up to this position: one division, double estimate + exact correction
+                        const int64_t num = (Mi - Q0i) + Dp;   // >= 0
+                        int N = (int)((double)num * (1.0 / (double)Ri));
+                        int64_t rem = num - (int64_t)N * Ri;
+                        if (rem < 0) { N--; rem += Ri; }
+                        if (rem >= Ri) { N++; rem -= Ri; }
+                        int a = __shfl_down(N, 1) - N;   // tokens that arrive between this position and the next
+                        if (lane == kWave - 1u) a = 0;
+                        int ssum = a - (m ? 1 : 0), cmax = a, tot_s, tot_c;
+                        lind_exclusive_scan(ssum, cmax, tot_s, tot_c);
+                        const int b0 = __builtin_amdgcn_readfirstlane(N);
+                        const int b = b0 + ssum > cmax ? b0 + ssum : cmax;
+                        acc = m && b > 0;
+                        jb = N - b;
+                    }
+                    const int64_t xi = Q0i + (int64_t)jb * Ri - Dp;
+                    const double x = (double)xi * u;   // exact
+                    const double sx = x + R;           // the queue behind this packet if it is accepted (ns:82)
+                    const uint32_t es = exponent_bits(sx);
+                    const bool flag = m && (!(x > 0.0) || es < e || (es > e && maxq_above));
+                    const uint64_t stop = __ballot(!valid || flag);
+                    const uint32_t ncommit = stop ? (uint32_t)__ffsll((unsigned long long)stop) - 1u : (uint32_t)kWave;
+                    if (ncommit < nv && ncommit < 16u) chain_left = 2u;   // (stopped early by a flag: q hovers around a binade edge or runs empty)
+                    if (ncommit) {
+                        const bool mine = lane < ncommit;
+                        const double qc = max0(x);   // ns:66-67
+                        my_lat = dl + qc;
+                        my_t = tk + my_lat;
+                        my_drop = !acc;
+                        const uint64_t touch = __ballot(mine && m);
+                        if (touch) {
+                            const uint32_t kl = 63u - (uint32_t)__clzll((long long)touch);
+                            st.q = rl_f64(acc ? sx : x, kl);
+                            st.tu = rl_f64(tk, kl);
+                        }
+                        const uint32_t n1 = (uint32_t)__popcll(__ballot(mine && my_s == 1u)), n0 = ncommit - n1;
+                        st.t[0] = st.t[0] + (double)n0 * G[0];   // exact
+                        st.t[1] = st.t[1] + (double)n1 * G[1];
+                        nv = ncommit;
+                        committed = true;
+                    }
+                }
+            }
+            if (!committed) {
             // phase 1: accepted packet to accepted packet
             double qm = st.q, tm = st.tu;
             uint64_t open = vmask & ~rmask, amask = 0;
@@ -1152,6 +1251,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             const uint32_t n1 = (uint32_t)__popcll(__ballot(valid && my_s == 1u)), n0 = nv - n1;
             st.t[0] = st.t[0] + (double)n0 * G[0];   // exact
             st.t[1] = st.t[1] + (double)n1 * G[1];
+            }  // !committed
         }
         // ---- records: four dense runs (sender x accepted/dropped)
         const bool valid = lane < nv;
@@ -3601,7 +3701,8 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.takeover_lanes = 1;  // the last lane of a light item goes to the wave path (more lanes handed over measured slower)
     d.send_waves = 16;  // persistent send wavefronts per compute unit (4 per SIMD at <= 128 VGPRs)
     d.send_envs_per_wave = 64;
-    d.heavy_predict = 512.0;
+    // (two senders: the lane rounds cost about the same per packet as with one, the wave passes more -- 64 positions per pass)
+    d.heavy_predict = n_senders == 2 ? 1024.0 : 512.0;
     d.team_predict = 4096.0;
     d.heavy_item_packets = 2048.0f;
     d.retire_wide_predict = 1024.0f;

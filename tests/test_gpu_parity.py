@@ -955,6 +955,42 @@ def test_queue_limits_just_above_a_power_of_two_match_oracle():
         env.close()
 
 
+@pytest.mark.parametrize("case", ["overdriven", "edges", "mixed"])
+def test_two_sender_token_pass_matches_oracle(case):
+    """The closed-form pass of the two-sender wave path (heavy_mi2: backlogged queue in one binade, accept decisions by a
+    token scan over the merged stream with uneven token arrivals) against the oracle, every env sent by the wave path
+    from its first packet: two senders that together overdrive the link (the pass's home ground), queue limits around
+    powers of two and 1/bw on both sides of the queue's binade (its preconditions break and hold by turns), and the
+    default parameter ranges."""
+    n_envs, n_steps, seed = 768, 120, {"overdriven": 61, "edges": 62, "mixed": 63}[case]
+    rs = np.random.RandomState(seed)
+    bw = rs.uniform(100, 500, n_envs)
+    dl = rs.uniform(0.05, 0.5, n_envs)
+    loss = np.where(rs.rand(n_envs) < 0.25, 0.0, rs.uniform(0, 0.05, n_envs))
+    if case == "edges":
+        B = 2.0 ** rs.randint(-3, 5, n_envs)
+        queue = np.maximum(2.0, np.ceil(B * bw + rs.uniform(-3.0, 3.0, n_envs)))
+    else:
+        queue = 1.0 + np.floor(np.exp(rs.uniform(0, 8, n_envs)))
+    share = rs.uniform(0.2, 0.8, n_envs)
+    load = rs.uniform(1.02, 1.8, n_envs) if case != "mixed" else rs.uniform(0.4, 1.6, n_envs)
+    rate0 = np.clip(np.stack([bw * load * share, bw * load * (1.0 - share)], 1), 40.0, 1000.0)
+    acts = rs.uniform(-0.5, 0.8, (n_envs, n_steps, 2))
+    ref = oracle.run_batch(acts, n_senders=2, rng_mode=oracle.RNG_PHILOX, seed=seed,
+                           params=np.concatenate([np.stack([bw, dl, queue, loss], 1), rate0], 1))
+    for knobs in (dict(heavy_predict=0.0), dict(takeover_lanes=64, round_packets=8)):
+        env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, n_senders=2, record_steps=True, auto_reset=False,
+                                           link_params=(bw, dl, queue, loss, rate0))
+        env.set_tuning(**knobs)
+        env.reset()
+        steps, obs, done = run_gpu(env, acts, n_steps)
+        bad = np.argwhere((steps[..., :3] != ref["steps"][..., :3]).any(axis=(1, 2, 3)))
+        assert bad.size == 0, (knobs, "envs with count mismatches: %s" % bad[:10].ravel())
+        assert np.array_equal(steps, ref["steps"]), knobs
+        assert np.array_equal(obs, ref["obs"].astype(np.float32)), knobs
+        env.close()
+
+
 @pytest.mark.parametrize("n_senders", [1, 2])
 def test_small_batch_path_without_work_lists(n_senders):
     """Batches below 8192 envs are stepped in index order, without work lists (the library's default, which the other

@@ -16,9 +16,10 @@ W = 20
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(1234)
 POOL = 400   # one action vector per episode step (a short cycled pool makes every env's rate drift: see bench.py)
-acts = torch.rand((POOL, N), generator=gen, device=dev) * 2 - 1
 for knobs in knob_sets:
     kw = {k[4:]: v for k, v in knobs.items() if k.startswith("env_")}
+    gen.manual_seed(1234)
+    acts = torch.rand((POOL, N, kw.get("n_senders", 1)), generator=gen, device=dev) * 2 - 1
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, **kw)
     env.set_tuning(**{k: v for k, v in knobs.items() if not k.startswith("env_")})
     for ep in range(EPS):
