@@ -95,7 +95,9 @@ enum {
 #define PCC_FLAG_TRACE_OVERRUN 2u  /* PCC_RNG_TRACE ran past trace_stride */
 #define PCC_FLAG_POOL_EXHAUSTED 8u /* a sender needed a bigger ring tier and every pool from that tier up was empty (it may
                                       then also overflow: RING_OVERFLOW); raise the pools with pcc_set_ring_pools */
-#define PCC_FLAG_INTERNAL 4u       /* reserved (a queue protocol of an earlier build; never set) */
+#define PCC_FLAG_INTERNAL 4u       /* an internal error: a wave-path loop of the send half did not finish an interval within
+                                      4 M passes (every pass sends at least one packet) and gave up instead of spinning;
+                                      results invalid */
 #define PCC_FLAG_BAD_PARAMS 16u    /* pcc_set_link_params gave this env a link outside what the exact formulation covers
                                       (bw in (0, 1e8], latency > 0, queue >= 1, loss in [0, 1], rate0 > 0 and finite):
                                       results invalid; the env runs on a harmless stand-in link so that no kernel spins */

@@ -412,6 +412,7 @@ struct SendState {  // wave-uniform while an env is processed by the whole wave
 // (s2, c2) after (s1, c1) = (s1 + s2, max(c1 + s2, c2)), so the tokens every lane starts with come
 // from one prefix scan of the lanes' composites: six DPP steps, no LDS.
 constexpr int kLindNone = -(1 << 28);  // "-inf" with room for every shift a pass can add
+constexpr uint32_t kMaxPasses = 1u << 22;  // passes of one env and interval before the wave path gives up (PCC_FLAG_INTERNAL)
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void lind_step(int &s, int &c) {
@@ -501,7 +502,9 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
     const bool writer = W == 1 || wv == 0u;  // who stores what every wavefront of the team computes alike
     uint32_t serial_len = 8;
     uint32_t chain_left = 0;  // passes to send by the accept chain before the closed forms are tried again
+    uint32_t guard = 0;  // every pass commits at least one packet; a loop that does not end is a bug, not a reason to hang the GPU
     while (st.t < end) {
+        if (++guard > kMaxPasses) { st.flags |= PCC_FLAG_INTERNAL; break; }
         const uint64_t dbg_c0 = prof_counters(D) ? __builtin_readcyclecounter() : 0;
         const double t0 = st.t;
         const double t1s = t0 + gap;
@@ -1050,7 +1053,9 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
     const uint64_t lt = (1ull << lane) - 1ull;
     const double gap[2] = {gap0, gap1};
     uint32_t chain_left = 0;  // passes to send by the accept chain before the token pass is tried again
+    uint32_t guard = 0;
     while ((st.t[0] < st.t[1] ? st.t[0] : st.t[1]) < end) {
+        if (++guard > kMaxPasses) { st.flags |= PCC_FLAG_INTERNAL; break; }
         // ---- loss decisions of the next 64 packets of the merged stream
         uint64_t rm;
         if (TRACE) {

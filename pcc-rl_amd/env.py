@@ -289,10 +289,11 @@ class BatchedNetworkEnv(object):
             count = lambda bit: int(((flags & bit) != 0).sum().item())
             raise PccError(-6, "%d envs overflowed the in-flight ring, %d ran past the loss trace, %d found the ring pools "
                                "empty (ring_pools), %d have link parameters out of range, %d were given a NaN action, "
-                               "%d ran their clock out of the supported range"
+                               "%d ran their clock out of the supported range, %d hit an internal error"
                            % (count(native.PCC_FLAG_RING_OVERFLOW), count(native.PCC_FLAG_TRACE_OVERRUN),
                               count(native.PCC_FLAG_POOL_EXHAUSTED), count(native.PCC_FLAG_BAD_PARAMS),
-                              count(native.PCC_FLAG_BAD_ACTION), count(native.PCC_FLAG_TIME_RANGE)))
+                              count(native.PCC_FLAG_BAD_ACTION), count(native.PCC_FLAG_TIME_RANGE),
+                              count(native.PCC_FLAG_INTERNAL)))
 
     @property
     def device_bytes(self):

@@ -12,6 +12,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test time limit (pytest-timeout, when it is installed)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that does not come back (a kernel that spins) must fail, not hold the box until somebody's limit kills it:
+    ten minutes per test, enforced from a watchdog thread (the main thread may sit in a blocking HIP call)."""
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
 
 
 @pytest.fixture(scope="session")
