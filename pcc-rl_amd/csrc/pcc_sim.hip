@@ -328,7 +328,7 @@ __device__ __forceinline__ uint32_t tier_for(const Dev &D, uint32_t need_a, uint
 // send_kernel: apply_rate_delta (ns:235-241, 275-281) + every SEND event with time < end of the
 // coming MI (ns:155-178).  One lane per env for the serial recurrence; envs with many packets in
 // the MI ("heavy": deep queue, overloaded) are then processed one at a time by the whole wave,
-// 64 packets per pass (heavy_mi below).
+// up to 256 packets per pass (heavy_mi below), the largest by the four wavefronts of a workgroup together.
 // ======================================================================================
 
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t l) {

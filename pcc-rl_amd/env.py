@@ -346,10 +346,10 @@ class GroupedNetworkEnv(object):
     the pattern of double-buffered sampling, where the policy runs on one group's observations
     while the other groups simulate.  Results are the same numbers as one ``BatchedNetworkEnv`` of
     ``n_envs`` envs (group g holds the global env ids ``g * n_envs / G ...``); only the schedule
-    differs.  65 536 envs on one MI355X: 1 group 1.14e8, 2 groups 1.34e8, 4 groups 1.36e8
-    env-steps/s (``tools/async_groups.py``) -- when HIP maps the groups' streams to different hardware
-    queues; streams that share a queue serialize (measured 0.77e8 for 4 groups in that case), and
-    the mapping is not under the caller's control.
+    differs.  65 536 envs on one MI355X (round 3, ``bench.py --groups 2``): one batch 2.92e8, 2 groups 3.13e8
+    env-steps/s; more groups are slower (a half-size launch is as long as a full one: the gain is only what one
+    group's tail leaves to the other) -- and only when HIP maps the groups' streams to different hardware queues;
+    streams that share a queue serialize, and the mapping is not under the caller's control.
 
     ``step_group(g, actions)`` enqueues group g's step on its stream and returns its (obs, reward,
     done, info) tensors, valid on that stream (``self.streams[g]``); ``synchronize()`` waits for all.
