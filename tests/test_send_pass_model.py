@@ -65,3 +65,32 @@ def test_fuzzed_queue_limits_just_above_a_power_of_two(model):
         model.pcc_model_fuzz_straddle(0)
     assert bad == 0
     assert stats[14] > 1000 and stats[15] > 100 * stats[14]     # regime-C passes, well filled
+
+
+SRC2 = os.path.join(HERE, "models", "send_pass2_model.c")
+LIB2 = os.path.join(HERE, "models", "libsend_pass2_model.so")
+
+
+@pytest.fixture(scope="module")
+def model2():
+    if not os.path.exists(LIB2) or os.path.getmtime(LIB2) < os.path.getmtime(SRC2):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", SRC2, "-o", LIB2, "-lm"])
+    L = ctypes.CDLL(LIB2)
+    L.pcc_model2_fuzz.restype = ctypes.c_long
+    L.pcc_model2_fuzz.argtypes = [ctypes.c_long, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    L.pcc_model2_set_shape.argtypes = [ctypes.c_int, ctypes.c_int]
+    return L
+
+
+@pytest.mark.parametrize("lanes,per_lane", [(64, 1), (64, 4)])
+def test_two_sender_token_pass_model(model2, lanes, per_lane):
+    """The token pass of the two-sender wave path (heavy_mi2: a backlogged queue in one binade, accept decisions by a
+    token bucket with uneven arrivals over the merged stream) against the plain merged recurrence on fuzzed link states:
+    pairs that overdrive the link, queue limits around powers of two, young and old clocks, equal send times.  64 x 1
+    is the kernel's pass; 64 x 4 the variant with one Philox block per lane."""
+    assert model2.pcc_model2_set_shape(lanes, per_lane) == 0
+    stats = (ctypes.c_uint64 * 4)()
+    bad = model2.pcc_model2_fuzz(6000, 777 + per_lane, stats)
+    assert bad == 0
+    passes, committed, plain = int(stats[0]), int(stats[1]), int(stats[2])
+    assert passes > 1000 and committed > 5 * plain // 10      # the pass carried a good part of the packets
