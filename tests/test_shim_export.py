@@ -107,3 +107,20 @@ def test_export_leaves_the_training_policy_where_it_is(tmp_path):
     ptrs = [p.data_ptr() for p in pol32.pi.parameters()]
     export.export_policy(pol32, str(tmp_path))
     assert [p.data_ptr() for p in pol32.pi.parameters()] == ptrs
+
+
+def test_top_level_plugin_file_loads_like_the_reference_one():
+    """examples/loaded_client.py: what `-pyhelper=loaded_client -pypath=.../examples` imports -- a top-level module (no
+    package context) with the four functions of src/udt-plugins/testing/loaded_client.py:132-173."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "loaded_client.py")
+    spec = importlib.util.spec_from_file_location("loaded_client", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.set_policy(lambda obs: 0.5)
+    mod.init(7)
+    assert mod.get_rate(7) == 6.0e6                       # no sample yet: the reset rate stands
+    mod.give_sample(7, 30000, 27000, 1500, 0.0, 0.1, 0.03, 0.13, [0.03, 0.031], 1500, 1.0)
+    assert mod.get_rate(7) == shim.apply_rate_delta(6.0, 0.5) * 1e6
+    mod.reset(7)
+    assert mod.get_rate(7) == shim.apply_rate_delta(6.0, 0.5) * 1e6
