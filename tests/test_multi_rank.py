@@ -149,3 +149,37 @@ def test_bench_refuses_a_rank_count_mismatch():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode != 0 and "--gpus 8" in res.stdout
+
+
+RCCL_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)     # torch's "nccl" backend is RCCL on ROCm
+    n = 65536
+    mine = torch.arange(n, dtype=torch.float32, device=dev)
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, mine)             # the episode-return exchange of bench.py / distributed.py
+    t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)           # the bench's max-over-ranks
+    dist.barrier()
+    torch.cuda.synchronize()
+    assert torch.equal(out, mine) and float(t.item()) == 3.5
+    dist.destroy_process_group()
+    print("rccl ok")
+""") % ROOT
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_rccl_backend_runs_the_exchange_on_one_rank():
+    """A node with several GPUs is not available to the tests; this at least executes the RCCL backend on the GPU box --
+    communicator set-up and the two collectives of the multi-GPU path (all-gather of episode returns, MAX all-reduce of the
+    bench clock) -- with a world of one rank."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-c", RCCL_WORKER], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "rccl ok" in res.stdout, res.stderr[-2000:]
