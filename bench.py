@@ -388,6 +388,19 @@ def main():
         runs[r]["send_ms"] = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
         runs[r]["retire_ms"] = sum(ev[k][1].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))
         runs[r]["first_steps_ms"] = [ev[k][0].elapsed_time(ev[k][2]) for k in range(min(K, 6))]
+    many = None
+    if fused and world == 1 and not args.stagger:
+        # a small batch: one step is a 25 us launch, less than a trip around the Python loop above.  Supplementary: the same K
+        # steps queued by ONE library call (pcc_step_many: the loop runs in C); `value` stays the one-call-per-step figure
+        acts_many = torch.stack([actions[(t_global + k) % pool] for k in range(K)])
+        env.step_many(acts_many[:8])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        env.step_many(acts_many)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        many = {"value": N * K / el, "unit": "env steps/s", "us_per_step": 1e6 * el / K, "steps": K,
+                "note": "the same steps queued from C by one pcc_step_many call (open loop: actions pre-computed); supplementary"}
     if not os.environ.get("PCC_BENCH_IGNORE_FLAGS"):   # experiments only: an overflowed ring means invalid results
         env.check_flags()
     env.close()
@@ -486,6 +499,8 @@ def main():
                     other["traffic_over_algorithmic"] = pmc[other["kernel"]].get("traffic_over_algorithmic")
         elif why:
             out["roofline"]["traffic_source"] = "none: " + str(why)
+        if many is not None:
+            out["many_steps_per_call"] = many
         if world == 1 and args.groups > 1:
             out["async_groups"] = async_groups(pcc_rl_amd, torch, N, dev, K, W, args.groups)
         if not args.no_cpu_baseline and world == 1:

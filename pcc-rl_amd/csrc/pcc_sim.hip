@@ -4071,6 +4071,21 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
     return after_mi(sim, obs_out, auto_reset, st);
 }
 
+int pcc_step_many(pcc_sim_t *sim, const void *actions, int actions_f64, int n_steps, float *obs_out, float *reward_out,
+                  uint8_t *done_out, int auto_reset, void *stream) {
+    if (!sim || !actions || n_steps < 1) return fail(PCC_EINVAL, "NULL argument or n_steps < 1");
+    const Dev &d = sim->d;
+    const size_t row = (size_t)d.n * d.ns;
+    const size_t act_row = row * (d.use_cwnd ? 2u : 1u) * (actions_f64 ? sizeof(double) : sizeof(float));
+    for (int t = 0; t < n_steps; t++) {
+        const int rc = pcc_step(sim, static_cast<const char *>(actions) + (size_t)t * act_row, actions_f64,
+                                obs_out ? obs_out + (size_t)t * row * d.HF : nullptr, reward_out ? reward_out + (size_t)t * row : nullptr,
+                                done_out ? done_out + (size_t)t * d.n : nullptr, nullptr, auto_reset, stream);
+        if (rc != PCC_OK) return rc;
+    }
+    return PCC_OK;
+}
+
 int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {
     if (!sim || !out) return fail(PCC_EINVAL, "NULL argument");
     const Dev &d = sim->d;

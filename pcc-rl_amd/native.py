@@ -30,7 +30,7 @@ FIELDS = {
 
 # every symbol include/pcc_sim.h declares
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
-           "pcc_set_rng", "pcc_set_seed", "pcc_set_tuning", "pcc_set_ring_pools", "pcc_set_cwnd_mode", "pcc_set_latency_noise", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
+           "pcc_set_rng", "pcc_set_seed", "pcc_set_tuning", "pcc_set_ring_pools", "pcc_set_cwnd_mode", "pcc_set_latency_noise", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_many", "pcc_step_send",
            "pcc_step_retire",
            "pcc_get_state", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline", "pcc_debug_pass_stats",
            "pcc_policy_act", "pcc_ppo_scratch_floats", "pcc_ppo_minibatch_step", "pcc_gae"]
@@ -85,6 +85,7 @@ def lib():
     L.pcc_set_max_steps.argtypes = [vp, i32]
     L.pcc_reset.argtypes = [vp, vp, vp, vp]
     L.pcc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
+    L.pcc_step_many.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, vp]
     L.pcc_step_send.argtypes = [vp, vp, i32, vp]
     L.pcc_step_retire.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     L.pcc_get_state.argtypes = [vp, i32, vp, vp]
@@ -106,7 +107,7 @@ def lib():
     L.pcc_debug_pass_stats.restype = i32
     L.pcc_debug_pass_stats.argtypes = [vp, vp, i32]
     for fn in ("pcc_create", "pcc_set_link_params", "pcc_set_param_ranges", "pcc_set_rng", "pcc_set_seed",
-               "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_send",
+               "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_many", "pcc_step_send",
                "pcc_step_retire", "pcc_get_state", "pcc_metric_info"):
         getattr(L, fn).restype = i32
     _lib = L

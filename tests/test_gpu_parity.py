@@ -1111,3 +1111,27 @@ def test_parameter_ranges_are_validated():
     with pytest.raises(pcc_rl_amd.PccError):
         env.check_flags()
     env.close()
+
+
+@pytest.mark.parametrize("n_envs,lists", [(512, False), (512, True)])
+def test_step_many_equals_single_steps(n_envs, lists):
+    """pcc_step_many (the loop over the steps in C) gives the rows of the same number of pcc_step calls, episode boundary
+    and auto-reset included, on the small-batch path (one launch per step) and with work lists."""
+    if not lists:
+        pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = None
+    T, seed = 50, 17
+    acts = torch.as_tensor(np.random.RandomState(seed).uniform(-1, 1.5, (T, n_envs)), dtype=torch.float32, device=DEV)
+    one = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, max_steps=20)
+    many = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, max_steps=20)
+    assert torch.equal(one.reset(), many.reset())
+    obs = torch.empty((T, n_envs, one.obs_dim), device=DEV)
+    rew = torch.empty((T, n_envs), device=DEV)
+    done = torch.empty((T, n_envs), dtype=torch.uint8, device=DEV)
+    many.step_many(acts, obs, rew, done)
+    for t in range(T):
+        o, r, d, _ = one.step(acts[t])
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(d, done[t].view(torch.bool)), t
+    assert int(done.sum().item()) == 2 * n_envs
+    one.check_flags(); many.check_flags()
+    assert torch.equal(one.state("now"), many.state("now"))
+    one.close(); many.close()
