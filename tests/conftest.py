@@ -20,7 +20,7 @@ def pytest_collection_modifyitems(config, items):
     ten minutes per test, enforced from a watchdog thread (the main thread may sit in a blocking HIP call)."""
     for item in items:
         if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(600, method="thread"))
+            item.add_marker(pytest.mark.timeout(int(os.environ.get("PCC_TEST_TIMEOUT", "600")), method="thread"))
 
 
 @pytest.fixture(scope="session")
