@@ -1056,6 +1056,243 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
     uint32_t guard = 0;
     while ((st.t[0] < st.t[1] ? st.t[0] : st.t[1]) < end) {
         if (++guard > kMaxPasses) { st.flags |= PCC_FLAG_INTERNAL; break; }
+        // ---- token pass, up to 256 packets: the queue stays backlogged in one binade (heavy_mi's regime B, here for the
+        // merged stream; lane l owns the positions 4 l .. 4 l + 3 = one Philox block).  Every quantity is a multiple of
+        // u = ulp(q): the queue in front of merged position p is x_p = Q0 + j_p R - D_p (j_p packets accepted before it,
+        // D_p = t_p - tu); it is accepted iff it is not lost at random and x_p + R <= maxq, i.e. iff tokens are left:
+        // b_p = N_p - j_p > 0 with N_p = floor((M - Q0 + D_p) / R).  b_{p+1} = max(b_p - m_p, 0) + (N_{p+1} - N_p) is a Lindley
+        // map per position -- uneven token arrivals, because the two senders' send times interleave unevenly -- and the maps
+        // compose by one prefix scan (lind_exclusive_scan).  A position whose queue runs empty or leaves the binade ends the
+        // pass in front of it; the accept chain below (no such precondition, 64 packets) takes over from there.
+        if (chain_left) {
+            chain_left--;
+        } else {
+            constexpr uint32_t kPass = 4u * kWave;
+            double G2[2];
+            bool okb = true;
+            double tend_max = 0.0;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const double t0 = st.t[s], t1s = t0 + gap[s];
+                G2[s] = t1s - t0;
+                const double t2s = t1s + gap[s], tend = t0 + (double)kPass * G2[s];
+                // (t0 + c G is exact for c <= 256, and stays in t0's binade)
+                okb = okb && (t2s - t1s == G2[s]) && (G2[s] > 0.0) && (t0 >= ((double)kPass + 4.0) * gap[s]) &&
+                      (exponent_bits(t0) == exponent_bits(tend));
+                tend_max = tend > tend_max ? tend : tend_max;
+            }
+            const uint32_t e = exponent_bits(st.q), eb = exponent_bits(ebw);
+            const double T0 = st.t[0] <= st.t[1] ? st.t[0] : st.t[1];
+            const double x0 = st.q - (T0 - st.tu);
+            okb = okb && (st.tu + st.tu >= tend_max) && (st.q > 0.0) && e > 64u && e < 1100u && (x0 > 0.0) && eb <= e &&
+                  exponent_bits(st.tu) >= e && exponent_bits(maxq) >= e;
+            double u = 0.0, R = 0.0;
+            int64_t Q0i = 0, Ri = 1, Mi = 0, Dsi[2] = {0, 0}, Gsi[2] = {0, 0};
+            bool free_mode = false, maxq_above = false;
+            if (okb) {
+                u = pow2_f64((int)e - 1023 - 52);
+                const double inv_u = pow2_f64(-((int)e - 1023 - 52));
+                const double probe = pow2_f64((int)e - 1023);
+                R = (eb == e) ? ebw : (probe + ebw) - probe;   // 1/bw on the grid of u (ns:82 rounds x + 1/bw to it)
+                const double err = ebw - R;
+                const bool tie = fabs(err) == 0.5 * u;
+                okb = (tend_max - st.tu) * inv_u < 4.0e18 && R > 0.0;
+                if (okb) {
+                    Q0i = (int64_t)(st.q * inv_u);
+                    Ri = (int64_t)(R * inv_u);
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        Dsi[s] = (int64_t)((st.t[s] - st.tu) * inv_u);   // exact: tu <= t <= 2 tu, multiples of u
+                        Gsi[s] = (int64_t)(G2[s] * inv_u);
+                    }
+                    const double room = ((maxq - R) - x0) / R;   // packets of room in the queue (estimate)
+                    free_mode = room >= (double)kPass + 44.0;     // nothing of this pass can be tail-dropped
+                    Mi = free_mode ? 0 : (int64_t)(maxq * inv_u);
+                    // a tie rounds to even: x + R holds only while every x is an even multiple of u
+                    if (tie && ((Q0i | Dsi[0] | Dsi[1] | Gsi[0] | Gsi[1]) & 1)) okb = false;
+                    maxq_above = exponent_bits(maxq) > e;
+                }
+            }
+            if (okb) {
+                const uint32_t sent_all = st.sent[0] + st.sent[1];
+                const uint32_t skip = sent_all & 3u;   // positions of lane 0's Philox block that were sent before this pass
+                const int kbase = 4 * (int)lane - (int)skip;   // packet index (within the pass) of this lane's position 0
+                // ---- loss decisions of the lane's four positions
+                uint32_t rnd4 = 0;
+                if (TRACE) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int k = kbase + i;
+                        const int64_t pos = (int64_t)((uint64_t)st.a[0] + st.d[0] + st.a[1] + st.d[1]) + k;
+                        double uu = 1.0;
+                        if (k >= 0 && pos < D.trace_stride) uu = trace[pos];
+                        rnd4 |= (uu < lr ? 1u : 0u) << i;
+                    }
+                } else {
+                    uint32_t w[4];
+                    philox4x32_10((sent_all >> 2) + lane, mi, episode, gid, D.key0, D.key1, w);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rnd4 |= ((always || w[i] < thr) ? 1u : 0u) << i;
+                }
+                // ---- merge path: c0 = how many of sender 0's packets precede the lane's first packet (sender 0 first on
+                // equal times): smallest c with B[kf - c - 1] < A[c]; then the lane's packets one by one
+                const uint32_t kf = kbase < 0 ? 0u : (uint32_t)kbase;
+                uint32_t lo = 0, hi = kf;
+                while (__ballot(lo < hi)) {
+                    if (lo < hi) {
+                        const uint32_t c = (lo + hi) >> 1;
+                        const double Ac = st.t[0] + (double)c * G2[0];
+                        const double Bp = st.t[1] + (double)(kf - c - 1u) * G2[1];
+                        if (Bp < Ac) hi = c;
+                        else lo = c + 1u;
+                    }
+                }
+                uint32_t c0 = lo, c1 = kf - lo;
+                uint32_t s4 = 0, ex4 = 0, m4 = 0;   // bit i: sender of position i; it holds a packet of this MI; ... that reaches the queue
+                double tk[4];
+                int64_t Dp[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double A = st.t[0] + (double)c0 * G2[0], B = st.t[1] + (double)c1 * G2[1];
+                    const bool is1 = !(A <= B);
+                    tk[i] = is1 ? B : A;
+                    Dp[i] = is1 ? Dsi[1] + (int64_t)c1 * Gsi[1] : Dsi[0] + (int64_t)c0 * Gsi[0];
+                    const bool there = kbase + i >= 0;
+                    const bool ex = there && tk[i] < end;
+                    s4 |= (is1 ? 1u : 0u) << i;
+                    ex4 |= (ex ? 1u : 0u) << i;
+                    m4 |= ((ex && !((rnd4 >> i) & 1u)) ? 1u : 0u) << i;
+                    if (there) { c0 += is1 ? 0u : 1u; c1 += is1 ? 1u : 0u; }   // (positions before `skip` all stand for the first packet)
+                }
+                // ---- accept decisions
+                uint32_t acc4 = 0;
+                int jb = 0;   // packets accepted before the lane's first position
+                if (free_mode) {
+                    acc4 = m4;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) jb += (int)__popcll(__ballot((acc4 >> i) & 1u) & lt);
+                } else {
+                    int N[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {   // tokens up to each position: a division, double estimate + exact correction
+                        const int64_t num = (Mi - Q0i) + Dp[i];   // >= 0
+                        int n = (int)((double)num * (1.0 / (double)Ri));
+                        int64_t rem = num - (int64_t)n * Ri;
+                        if (rem < 0) { n--; rem += Ri; }
+                        if (rem >= Ri) { n++; }
+                        N[i] = n;
+                    }
+                    int Nnext = __shfl_down(N[0], 1);
+                    if (lane == kWave - 1u) Nnext = N[3];
+                    int ssum = 0, cmax = kLindNone;
+                    int a_[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        a_[i] = (i < 3 ? N[i + 1 < 4 ? i + 1 : 3] : Nnext) - N[i];   // tokens that arrive before the next position
+                        const int sft = a_[i] - (int)((m4 >> i) & 1u);
+                        cmax = cmax + sft > a_[i] ? cmax + sft : a_[i];
+                        ssum += sft;
+                    }
+                    const int b0 = __builtin_amdgcn_readfirstlane(N[0]);
+                    int tot_s, tot_c;
+                    lind_exclusive_scan(ssum, cmax, tot_s, tot_c);
+                    int b = b0 + ssum > cmax ? b0 + ssum : cmax;
+                    jb = N[0] - b;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bool m = (m4 >> i) & 1u;
+                        acc4 |= ((m && b > 0) ? 1u : 0u) << i;
+                        b = (b - (m ? 1 : 0) > 0 ? b - (m ? 1 : 0) : 0) + a_[i];
+                    }
+                }
+                // ---- the queue in front of every position, exactly; positions that break a precondition
+                uint32_t flag4 = 0;
+                {
+                    int j = jb;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int64_t xi = Q0i + (int64_t)j * Ri - Dp[i];
+                        const double x = (double)xi * u;   // exact
+                        const double sx = x + R;           // the queue behind this packet if it is accepted (ns:82)
+                        const uint32_t es = exponent_bits(sx);
+                        const bool m = (m4 >> i) & 1u;
+                        flag4 |= ((m && (!(x > 0.0) || es < e || (es > e && maxq_above))) ? 1u : 0u) << i;
+                        j += (int)((acc4 >> i) & 1u);
+                    }
+                }
+                // ---- the pass stops at the first position that is past the MI end or breaks a precondition
+                uint32_t stop4 = (~ex4 | flag4) & 0xFu;
+                if (lane == 0) stop4 &= ~((1u << skip) - 1u);   // positions before `skip` are not part of the pass
+                const uint64_t stop_lanes = __ballot(stop4 != 0u);
+                uint32_t p_stop = kPass;
+                if (stop_lanes) {
+                    const uint32_t ls = (uint32_t)__ffsll((unsigned long long)stop_lanes) - 1u;
+                    p_stop = 4u * ls + rl_u32(((uint32_t)__ffs((int)stop4) - 1u) & 3u, ls);
+                }
+                const uint32_t ncommit = p_stop - skip;
+                if (p_stop < kPass && ncommit < 32u) chain_left = 2u;   // q hovers around a binade edge or keeps running empty
+                if (ncommit) {
+                    if (TRACE && (int64_t)((uint64_t)st.a[0] + st.d[0] + st.a[1] + st.d[1] + ncommit) > D.trace_stride)
+                        st.flags |= PCC_FLAG_TRACE_OVERRUN;
+                    // ---- records: four dense runs (sender x accepted / dropped).  The lane's counts of each kind, 16 bits each
+                    // in one 64-bit word, and their exclusive prefix over the lanes
+                    uint32_t in4 = 0;
+                    unsigned long long cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t pp = 4u * lane + (uint32_t)i;
+                        if (pp >= skip && pp < p_stop) {
+                            in4 |= 1u << i;
+                            cnt += 1ull << (16u * (2u * ((s4 >> i) & 1u) + (((acc4 >> i) & 1u) ? 0u : 1u)));
+                        }
+                    }
+                    unsigned long long incl = cnt;
+#pragma unroll
+                    for (int o = 1; o < kWave; o <<= 1) {
+                        const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, o);
+                        if (lane >= (uint32_t)o) incl += up;
+                    }
+                    const unsigned long long total = rl_u64(incl, kWave - 1u);
+                    unsigned long long before = incl - cnt;
+                    double last_q = 0.0, last_t = 0.0;
+                    bool have_last = false;
+                    int j = jb;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bool a = (acc4 >> i) & 1u;
+                        if ((in4 >> i) & 1u) {
+                            const bool sdr = (s4 >> i) & 1u;
+                            const uint32_t kind = 2u * (sdr ? 1u : 0u) + (a ? 0u : 1u);
+                            const uint32_t idx = (uint32_t)(before >> (16u * kind)) & 0xFFFFu;
+                            before += 1ull << (16u * kind);
+                            const double x = (double)(Q0i + (int64_t)j * Ri - Dp[i]) * u;   // exact (as above)
+                            double2 rec;
+                            rec.y = dl + max0(x);         // ns:66-67, 170
+                            rec.x = tk[i] + rec.y;        // ns:174
+                            const uint32_t cp = sdr ? cap1 : cap0;
+                            const uint32_t off = a ? ((((sdr ? st.a[1] : st.a[0]) + idx) << 4) & ((cp - 1u) << 4))
+                                                   : (cp << 4) + ((((sdr ? st.d[1] : st.d[0]) + idx) << 4) & ((2u * cp - 1u) << 4));
+                            st_rec(reinterpret_cast<double2 *>((sdr ? base1 : base0) + off), rec);
+                            if ((m4 >> i) & 1u) { have_last = true; last_t = tk[i]; last_q = a ? x + R : x; }   // ns:75-82
+                        }
+                        j += a ? 1 : 0;
+                    }
+                    const uint64_t lm = __ballot(have_last);
+                    if (lm) {   // the link state behind the last committed packet that reached the queue
+                        const uint32_t ll = 63u - (uint32_t)__clzll((long long)lm);
+                        st.q = rl_f64(last_q, ll);
+                        st.tu = rl_f64(last_t, ll);
+                    }
+                    const uint32_t a0n = (uint32_t)(total & 0xFFFFu), d0n = (uint32_t)((total >> 16) & 0xFFFFu);
+                    const uint32_t a1n = (uint32_t)((total >> 32) & 0xFFFFu), d1n = (uint32_t)((total >> 48) & 0xFFFFu);
+                    st.t[0] = st.t[0] + (double)(a0n + d0n) * G2[0];   // exact
+                    st.t[1] = st.t[1] + (double)(a1n + d1n) * G2[1];
+                    st.a[0] += a0n; st.d[0] += d0n; st.sent[0] += a0n + d0n;
+                    st.a[1] += a1n; st.d[1] += d1n; st.sent[1] += a1n + d1n;
+                    continue;
+                }
+            }
+        }
         // ---- loss decisions of the next 64 packets of the merged stream
         uint64_t rm;
         if (TRACE) {
@@ -1121,104 +1358,6 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             const uint64_t vmask = __ballot(valid);
             nv = (uint32_t)__popcll(vmask);  // merged times increase: valid lanes are a prefix
             const uint64_t rmask = rm;
-            // ---- token pass: the queue stays backlogged in one binade (heavy_mi's regime B, here for the merged stream).
-            // Every quantity is a multiple of u = ulp(q): the queue in front of merged position p is
-            // x_p = Q0 + j_p R - D_p (j_p packets accepted before it, D_p = t_p - tu), it is accepted iff it is not lost at
-            // random and x_p + R <= maxq, i.e. iff tokens are left: b_p = N_p - j_p > 0 with N_p = floor((M - Q0 + D_p) / R).
-            // b_{p+1} = max(b_p - m_p, 0) + (N_{p+1} - N_p) is a Lindley map per position -- uneven token arrivals, because the
-            // two senders' send times interleave unevenly -- and the maps compose by one prefix scan (lind_exclusive_scan).
-            // A position whose queue runs empty or leaves the binade ends the pass in front of it; the accept chain below
-            // (no precondition) takes over from there.
-            bool committed = false;
-            if (chain_left) {
-                chain_left--;
-            } else {
-                const uint32_t e = exponent_bits(st.q), eb = exponent_bits(ebw);
-                const double T0 = rl_f64(tk, 0);
-                const double x0 = st.q - (T0 - st.tu);
-                bool okb = (st.q > 0.0) && e > 64u && e < 1100u && (x0 > 0.0) && eb <= e && exponent_bits(st.tu) >= e &&
-                           exponent_bits(maxq) >= e;
-                double u = 0.0, R = 0.0;
-                int64_t Q0i = 0, Ri = 1, Mi = 0, Dsi[2] = {0, 0}, Gsi[2] = {0, 0};
-                bool free_mode = false, maxq_above = false;
-                if (okb) {
-                    u = pow2_f64((int)e - 1023 - 52);
-                    const double inv_u = pow2_f64(-((int)e - 1023 - 52));
-                    const double probe = pow2_f64((int)e - 1023);
-                    R = (eb == e) ? ebw : (probe + ebw) - probe;   // 1/bw on the grid of u (ns:82 rounds x + 1/bw to it)
-                    const double err = ebw - R;
-                    const bool tie = fabs(err) == 0.5 * u;
-                    okb = (tend_max - st.tu) * inv_u < 4.0e18 && R > 0.0;
-                    if (okb) {
-                        Q0i = (int64_t)(st.q * inv_u);
-                        Ri = (int64_t)(R * inv_u);
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; s2++) {
-                            Dsi[s2] = (int64_t)((st.t[s2] - st.tu) * inv_u);   // exact: tu <= t <= 2 tu, multiples of u
-                            Gsi[s2] = (int64_t)(G[s2] * inv_u);
-                        }
-                        const double room = ((maxq - R) - x0) / R;   // packets of room in the queue (estimate)
-                        free_mode = room >= 64.0 + 44.0;              // nothing of this pass can be tail-dropped
-                        Mi = free_mode ? 0 : (int64_t)(maxq * inv_u);
-                        // a tie rounds to even: x + R holds only while every x is an even multiple of u
-                        if (tie && ((Q0i | Dsi[0] | Dsi[1] | Gsi[0] | Gsi[1]) & 1)) okb = false;
-                        maxq_above = exponent_bits(maxq) > e;
-                    }
-                }
-                if (okb) {
-                    const uint32_t cme = my_s ? c1 : c0;   // this packet is its sender's cme-th of the pass
-                    const int64_t Dp = (my_s ? Dsi[1] : Dsi[0]) + (int64_t)cme * (my_s ? Gsi[1] : Gsi[0]);
-                    const bool m = valid && !((rmask >> lane) & 1ull);   // reaches the queue
-                    bool acc;
-                    int jb;   // packets accepted before this position
-                    if (free_mode) {
-                        acc = m;
-                        jb = (int)__popcll(__ballot(acc) & lt);
-                    } else {
-                        // tokens up to this position: one division, double estimate + exact correction
-                        const int64_t num = (Mi - Q0i) + Dp;   // >= 0
-                        int N = (int)((double)num * (1.0 / (double)Ri));
-                        int64_t rem = num - (int64_t)N * Ri;
-                        if (rem < 0) { N--; rem += Ri; }
-                        if (rem >= Ri) { N++; rem -= Ri; }
-                        int a = __shfl_down(N, 1) - N;   // tokens that arrive between this position and the next
-                        if (lane == kWave - 1u) a = 0;
-                        int ssum = a - (m ? 1 : 0), cmax = a, tot_s, tot_c;
-                        lind_exclusive_scan(ssum, cmax, tot_s, tot_c);
-                        const int b0 = __builtin_amdgcn_readfirstlane(N);
-                        const int b = b0 + ssum > cmax ? b0 + ssum : cmax;
-                        acc = m && b > 0;
-                        jb = N - b;
-                    }
-                    const int64_t xi = Q0i + (int64_t)jb * Ri - Dp;
-                    const double x = (double)xi * u;   // exact
-                    const double sx = x + R;           // the queue behind this packet if it is accepted (ns:82)
-                    const uint32_t es = exponent_bits(sx);
-                    const bool flag = m && (!(x > 0.0) || es < e || (es > e && maxq_above));
-                    const uint64_t stop = __ballot(!valid || flag);
-                    const uint32_t ncommit = stop ? (uint32_t)__ffsll((unsigned long long)stop) - 1u : (uint32_t)kWave;
-                    if (ncommit < nv && ncommit < 16u) chain_left = 2u;   // (stopped early by a flag: q hovers around a binade edge or runs empty)
-                    if (ncommit) {
-                        const bool mine = lane < ncommit;
-                        const double qc = max0(x);   // ns:66-67
-                        my_lat = dl + qc;
-                        my_t = tk + my_lat;
-                        my_drop = !acc;
-                        const uint64_t touch = __ballot(mine && m);
-                        if (touch) {
-                            const uint32_t kl = 63u - (uint32_t)__clzll((long long)touch);
-                            st.q = rl_f64(acc ? sx : x, kl);
-                            st.tu = rl_f64(tk, kl);
-                        }
-                        const uint32_t n1 = (uint32_t)__popcll(__ballot(mine && my_s == 1u)), n0 = ncommit - n1;
-                        st.t[0] = st.t[0] + (double)n0 * G[0];   // exact
-                        st.t[1] = st.t[1] + (double)n1 * G[1];
-                        nv = ncommit;
-                        committed = true;
-                    }
-                }
-            }
-            if (!committed) {
             // phase 1: accepted packet to accepted packet
             double qm = st.q, tm = st.tu;
             uint64_t open = vmask & ~rmask, amask = 0;
@@ -1256,7 +1395,6 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             const uint32_t n1 = (uint32_t)__popcll(__ballot(valid && my_s == 1u)), n0 = nv - n1;
             st.t[0] = st.t[0] + (double)n0 * G[0];   // exact
             st.t[1] = st.t[1] + (double)n1 * G[1];
-            }  // !committed
         }
         // ---- records: four dense runs (sender x accepted/dropped)
         const bool valid = lane < nv;
@@ -3004,7 +3142,10 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
 // RESTART: the build that knows restart items (launched when the last retire launch may have filed some); the plain
 // build carries none of that code (the reset and the warm-up retire inlined here cost ~5 % of the launch otherwise)
 template <int NS, bool TRACE, bool RESTART>
-__global__ __launch_bounds__(4 * kWave, 4) void send_kernel(Dev D, int read_buf, int zero_buf, int warm, uint32_t warm_mi,
+// (The RESTART build -- the reset and the warm-up retire of restart items inlined -- is cut for 3 wavefronts per SIMD: at
+// 128 registers it spilled 290-350 bytes per lane, ran the same work 21 % slower, and its code generation broke when the
+// wave paths grew; at 168 it spills 130-160 bytes and --stagger runs 0.366 instead of 0.392 ms.)
+__global__ __launch_bounds__(4 * kWave, RESTART ? 3 : 4) void send_kernel(Dev D, int read_buf, int zero_buf, int warm, uint32_t warm_mi,
                                                          int gate, const void *actions, int actions_f64) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;  // every wavefront works on its own
