@@ -99,6 +99,11 @@ def lib():
             ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, _u64p,
             ctypes.c_long, _dp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, ctypes.c_int]
         L.pcc_oracle_use_latency_noise.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+        L.pcc_oracle_run_batch_at.restype = ctypes.c_int
+        L.pcc_oracle_run_batch_at.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int,
+            ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, _u64p,
+            ctypes.c_long, _dp, ctypes.c_long, _dp, _dp, _dp, ctypes.c_double, _ip, _dp, _dp, _dp, _dp, _dp, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -229,11 +234,13 @@ class OracleEnv(object):
 def run_batch(actions, n_senders=1, history_len=10, features=DEFAULT_FEATURES, mean_mode=MEAN_NUMPY,
               delta_scale=0.025, rng_mode=RNG_PHILOX, seed=0, env_gid_base=0, mt_seeds=None, mt_skip=5,
               trace=None, params=None, n_episodes=1, n_threads=None, want_obs=True, cwnd_actions=None,
-              latency_noise=None):
+              latency_noise=None, first_episode=None):
     """Run B independent envs for T steps.  actions: [B, T] or [B, T, n_senders].
     cwnd_actions (same shape) switches the USE_CWND engine option on and supplies the second
     action component; latency_noise (e.g. 1.1 = the reference's MAX_LATENCY_NOISE) switches
-    USE_LATENCY_NOISE on.
+    USE_LATENCY_NOISE on.  first_episode (an int or [B] ints, Philox uniforms only): the episode index env b starts at
+    -- with Philox an episode's links and draws are keyed by (env id, episode index), so an env in its k-th episode can
+    be checked without replaying the k episodes before it.
 
     Returns dict(steps [B, S, T, 19], obs [B, S, T, H*F], obs0 [B, S, H*F],
                  params [B, 5+S], warm [B, 2]); S axis squeezed when n_senders == 1.
@@ -255,10 +262,15 @@ def run_batch(actions, n_senders=1, history_len=10, features=DEFAULT_FEATURES, m
     ms = None if mt_seeds is None else np.ascontiguousarray(mt_seeds, dtype=np.uint64)
     nt = n_threads if n_threads else (os.cpu_count() or 1)
     ca = None if cwnd_actions is None else np.ascontiguousarray(cwnd_actions, dtype=np.float64).reshape(B, T, S)
-    bad = lib().pcc_oracle_run_batch_opts(
+    fe = None
+    if first_episode is not None:
+        if rng_mode != RNG_PHILOX:
+            raise ValueError("first_episode needs Philox uniforms (the other streams depend on the episodes before)")
+        fe = np.ascontiguousarray(np.broadcast_to(np.asarray(first_episode, dtype=np.int32), (B,)))
+    bad = lib().pcc_oracle_run_batch_at(
         B, S, T, n_episodes, history_len, _ptr(fids, _ip), len(fids), mean_mode, delta_scale, rng_mode,
         int(seed), int(env_gid_base), _ptr(ms, _u64p), int(mt_skip), _ptr(tr),
-        0 if tr is None else tr.shape[1], _ptr(p), _ptr(a), _ptr(ca), float(latency_noise or 0.0), _ptr(steps),
+        0 if tr is None else tr.shape[1], _ptr(p), _ptr(a), _ptr(ca), float(latency_noise or 0.0), _ptr(fe, _ip), _ptr(steps),
         _ptr(obs), _ptr(obs0), _ptr(pout), _ptr(warm), nt)
     if bad:
         raise RuntimeError("loss-uniform trace ran out for env %d" % (bad - 1))

@@ -20,7 +20,7 @@ import torch
 
 from . import native
 from .config import DELTA_SCALE, arg_or_default
-from .metrics import DEFAULT_FEATURES, feature_ids, get_max_obs_vector, get_min_obs_vector
+from .metrics import DEFAULT_FEATURES, feature_ids, get_max_obs_vector, get_min_obs_vector, metric_info
 from .native import PccError, check, lib
 from .spaces import Box
 
@@ -428,6 +428,12 @@ class SimulatedNetworkEnv(object):
     Python float reward, bool done, empty info dict).  One env = a batch of one on the GPU, so
     this adapter is for compatibility, not speed: use ``BatchedNetworkEnv`` to train.
 
+    Observations are float64 arrays, as the reference's are at run time (``SenderHistory.as_array`` concatenates float64
+    rows although the ``Box`` says float32: src/common/sender_obs.py:68-73): the adapter keeps the
+    history itself, from the full-precision per-step record of the library (every metric of the new monitor interval
+    divided by its scale, so:44-54), so an agent sees the reference's numbers bit for bit.  (``BatchedNetworkEnv``, the
+    fast path, hands out the float32 rows the device writes -- the ``Box`` dtype.)
+
     Differences from the reference, all deliberate: ``seed()`` really seeds the simulator (the
     reference's creates an RNG nothing reads, ns:396-398); nothing is printed; the JSON event
     log is written only when ``dump_events_to_file`` is called (the reference writes
@@ -453,20 +459,29 @@ class SimulatedNetworkEnv(object):
         self.event_record = {"Events": []}
         self.run_dur = None
         self.viewer = None
+        self._cols = [native.STEP_COLUMNS.index(f) for f in self.features]
+        self._scales = np.array([metric_info(f)[2] for f in self.features], dtype=np.float64)
+        self._hist = None
 
     def seed(self, seed=None):
         self._env.seed(seed)
         return [seed]
 
+    def _obs64(self):
+        return np.concatenate(self._hist)                                     # so:68-73: oldest interval first
+
     def reset(self):
-        obs = self._env.reset()
+        self._env.reset()
+        # so:57-62: a history of empty intervals -- every metric of one is 0 but the two ratios (so:179-191)
+        empty = np.array([1.0 if f in ("send ratio", "latency ratio") else 0.0 for f in self.features]) / self._scales
+        self._hist = [empty.copy() for _ in range(self.history_len)]
         self.steps_taken = 0
         self.episodes_run += 1
         self.event_record = {"Events": []}
         self.reward_ewma = 0.99 * self.reward_ewma + 0.01 * self.reward_sum   # ns:480-481
         self.reward_sum = 0.0
         self.run_dur = float(self._env.state("run_dur")[0].item())
-        return obs[0].cpu().numpy()
+        return self._obs64()
 
     def step(self, actions):
         if self.run_dur is None:
@@ -489,7 +504,9 @@ class SimulatedNetworkEnv(object):
             "Latency Ratio": float(row[col("latency ratio")]), "Send Ratio": float(row[col("send ratio")])})
         self.run_dur = float(row[col("run_dur")])
         self.reward_sum += reward
-        return obs[0].cpu().numpy(), reward, bool(done[0].item()), {}
+        self._hist.pop(0)                                                      # so:64-66
+        self._hist.append(row[self._cols] / self._scales)
+        return self._obs64(), reward, bool(done[0].item()), {}
 
     def render(self, mode="human"):
         pass

@@ -168,20 +168,21 @@ class PolicyRateController(object):
     init/get_rate/give_sample/reset keyed by flow id that the plugin loader binds."""
 
     def __init__(self, act, history_len=10, features=DEFAULT_FEATURES, start_rate=6.0, delta_scale=0.05,
-                 min_rate=0.5, max_rate=300.0):
+                 min_rate=0.5, max_rate=300.0, conn_min=None):
+        """conn_min: the latency minimum a flow of this id already has (so:158: the reference's table of connection
+        minima is keyed by flow id and outlives the driver object; udt_plugin.init passes it on re-initialisation)."""
         self.act, self.history_len, self.features = act, history_len, features
         self.start_rate, self.delta_scale, self.min_rate, self.max_rate = start_rate, delta_scale, min_rate, max_rate
-        self.reset()
+        self.rate = self.start_rate
+        self.history = SampleHistory(self.history_len, self.features, conn_min=conn_min)
+        self.got_data = False
 
     def reset(self):
         """loaded_client.py:94-110: a fresh history; no rate is sent until a new sample arrives.  Two things survive,
         as in the reference: the flow's latency minimum (so:158-176: the table of connection minima is never cleared)
         and the RATE -- reset_rate() there draws a new `current_rate` that nothing reads, so get_rate() goes on from
         the rate the flow had (pinned by tests/golden/udt_plugin.npz)."""
-        prev = getattr(self, "history", None)
-        if prev is None:
-            self.rate = self.start_rate
-        self.history = SampleHistory(self.history_len, self.features, conn_min=prev.conn_min if prev is not None else None)
+        self.history = SampleHistory(self.history_len, self.features, conn_min=self.history.conn_min)
         self.got_data = False
 
     def give_sample(self, bytes_sent, bytes_acked, bytes_lost, send_start, send_end, recv_start, recv_end,

@@ -39,12 +39,17 @@ def _policy():
 
 
 def init(flow_id):
-    """loaded_client.py:172-173 / 60-80: a driver for the flow, at the reset rate, with an empty history."""
+    """loaded_client.py:172-173 / 60-80: a driver for the flow, at the reset rate, with an empty history.  A flow id that
+    is initialised AGAIN keeps its latency minimum: the reference's table of connection minima is module-level and keyed
+    by flow id (so:158-176), a new PccGymDriver for the same id does not clear it -- so the empty intervals of the new
+    history evaluate "latency ratio" to 0 / min = 0.0, not the 1.0 of a first history."""
+    prev = _flows.get(flow_id)
     _flows[flow_id] = PolicyRateController(
         _policy(), history_len=arg_or_default("--history-len", default=10),
         features=arg_or_default("--input-features", default=DEFAULT_FEATURES),
         start_rate=float(arg_or_default("--reset-target-rate", default=6.0)),
-        delta_scale=DELTA_SCALE, min_rate=MIN_RATE, max_rate=MAX_RATE)
+        delta_scale=DELTA_SCALE, min_rate=MIN_RATE, max_rate=MAX_RATE,
+        conn_min=prev.history.conn_min if prev is not None else None)
 
 
 def get_rate(flow_id):

@@ -17,7 +17,12 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     """A GPU test that does not come back (a kernel that spins) must fail, not hold the box until somebody's limit kills it:
-    ten minutes per test, enforced from a watchdog thread (the main thread may sit in a blocking HIP call)."""
+    ten minutes per test, enforced from a watchdog thread (the main thread may sit in a blocking HIP call).  The limit is
+    pytest-timeout's: without the plugin the marker would do nothing, so GPU tests refuse to run without it."""
+    if not config.pluginmanager.hasplugin("timeout") and any(i.get_closest_marker("gpu") is not None for i in items):
+        markexpr = getattr(config.option, "markexpr", "") or ""
+        if "not gpu" not in markexpr:
+            raise pytest.UsageError("the GPU tests need pytest-timeout (their watchdog): it is not installed")
     for item in items:
         if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
             item.add_marker(pytest.mark.timeout(int(os.environ.get("PCC_TEST_TIMEOUT", "600")), method="thread"))

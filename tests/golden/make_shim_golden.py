@@ -142,6 +142,13 @@ def plugin_golden():
     do("give_sample", *sample(9))
     do("give_sample", *sample(9))
     do("get_rate", 9)
+    # a flow id that is initialised AGAIN: a new driver object, but the module-level table of connection minima
+    # (sender_obs.py:158) still holds the flow's entry
+    do("init", 3)
+    do("get_rate", 3)
+    for k in range(3):
+        do("give_sample", *sample(3))
+        do("get_rate", 3)
     np.savez(os.path.join(HERE, "udt_plugin.npz"), script=np.array(script), rates=np.array(rates), obs=np.array(obs),
              w=np.array(PLUGIN_W))
     print("wrote udt_plugin.npz:", len(script), "calls,", len(rates), "rates")

@@ -236,14 +236,16 @@ def test_old_gym_adapter_drop_in():
     assert env.seed(5) == [5]
     env._env.set_loss_trace(oracle.mt_uniforms(0, int(d["rng"][0, 1]), skip=10)[None, :])
     obs = env.reset()
-    assert obs.shape == (30,) and obs.dtype == np.float32
+    assert obs.shape == (30,) and obs.dtype == np.float64   # float64 at run time, like the reference's
     assert env.observation_space.shape == (30,) and env.action_space.shape == (1,)
-    assert np.array_equal(obs, np.tile([0.0, 1.0, 1.0], 10).astype(np.float32))
+    assert np.array_equal(obs, np.tile([0.0, 1.0, 1.0], 10))
     total, done, t = 0.0, False, 0
     while not done:
         obs, rew, done, info = env.step([d["actions"][0, t]])
         assert isinstance(rew, float) and isinstance(done, bool) and info == {}
         assert rew == d["steps"][0, t, 6]
+        assert obs.dtype == np.float64 and np.array_equal(obs[-3:], d["obs_tail"][0, t])   # the reference's own float64 values
+        assert np.array_equal(obs, d["obs_full"][0, t])   # ... the whole 30-vector, every step
         total += rew
         t += 1
     assert t == 400 and total == 625.6196947931776   # SURVEY.md section 8(c) KAT
