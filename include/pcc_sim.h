@@ -162,19 +162,21 @@ int pcc_set_rng(pcc_sim_t *sim, int mode, const double *trace, int64_t trace_str
  * seed(), ns:396-398, creates an RNG nothing reads; here it does what a caller expects.) */
 int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
 
-/* Performance knobs of the send half; results never depend on them (every send path is exact).
+/* Performance knobs; results never depend on them (every send path is exact).
  * The retire half files every env by its predicted packet count for the next interval; the send
- * half's persistent wavefronts take work items off those lists, heaviest first.  An env predicted
- * above HEAVY_PREDICT packets is an item of its own, sent by all 64 lanes of a wavefront 256 packets
- * per pass; lighter envs go SEND_ENVS_PER_WAVE (64) of about the same length at a time to one
- * wavefront, a lane each, in rounds of ROUND_PACKETS (default 256); when at most TAKEOVER_LANES
- * (default 1) lanes still have packets left after a round, those envs are finished by the whole
- * wavefront.  (Keys 0, 1, 6, 7 belonged to mechanisms of earlier builds and are rejected.) */
+ * half takes work items off those lists.  An env predicted above HEAVY_PREDICT packets is sent by all 64
+ * lanes of a wavefront 256 packets per pass (the wave kernel, persistent wavefronts, largest class
+ * first); lighter envs go SEND_ENVS_PER_WAVE (64) of about the same length at a time to one wavefront
+ * of the light kernel, a lane each, in rounds of ROUND_PACKETS (default 256); when at most
+ * TAKEOVER_LANES (default 1) lanes still have packets left after a round, those envs are finished by
+ * the whole wavefront.  Both kinds of workgroup are in one launch (send_kernel); envs that restart out of
+ * lockstep are a kernel of their own on a side stream of the handle, joined before the call returns.
+ * (Keys 0, 1, 6, 7 belonged to mechanisms of earlier builds and are rejected.) */
 enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_SEND_ENVS_PER_WAVE = 4 /* envs per light work item, 1..64 */,
        PCC_TUNE_HEAVY_PREDICT = 5 /* predicted packets per interval above which an env is a work item of
                                     its own (wave path); default 512 (two senders: 1024), 0 = every env, >= 1e9 = none */,
-       PCC_TUNE_SEND_WAVES = 8 /* persistent send wavefronts per compute unit, 1..32 (default 16) */,
+       PCC_TUNE_SEND_WAVES = 8 /* persistent wavefronts of the wave kernel per compute unit, 1..32 (default 12) */,
        PCC_TUNE_TEAM_PREDICT = 9 /* predicted packets per interval above which an env is sent by a whole workgroup (four
                                     wavefronts, 1 024 packets per pass); default 4096, >= 1e9 = never (one sender only) */,
        PCC_TUNE_HEAVY_ITEM_PACKETS = 10 /* a wave-path work item holds as many envs of one class (1..8) as make up about this
@@ -184,7 +186,19 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     0 = every env by 16, >= 1e9 = every env by 8 */,
        PCC_TUNE_LIST_MIN_ENVS = 12 /* batches of fewer envs are stepped without work lists, the envs in index order (a small
                                     batch's step is a chain of dependent loads, and the lists add three); default 8192,
-                                    0 = always with lists */ };
+                                    0 = always with lists */,
+       PCC_TUNE_RETIRE_SORTED = 13 /* debug: 0 = the retire launch walks the envs in index order even when there are lists */,
+       PCC_TUNE_LIGHT_SNAKE = 14 /* light kernel: a workgroup's four items in snake order over the ranking (their packets add up
+                                    to about the same for every compute unit); default 1 */,
+       PCC_TUNE_WAVE_OLDEST_FIRST = 15 /* wave kernel: the largest items go to the workgroups dispatched first (1, default) or last */,
+       PCC_TUNE_PRIO_LEVEL = 16 /* s_setprio level (0..3, default 0 = off) of the items the next three keys select */,
+       PCC_TUNE_PRIO_LIGHT_ITEMS = 17 /* ... the first (longest) this many light items */,
+       PCC_TUNE_PRIO_WAVE_ITEMS = 18 /* ... the first (largest) this many wave-path items */,
+       PCC_TUNE_PRIO_TEAM = 19 /* ... team items (0 / 1) */,
+       PCC_TUNE_SPLIT_STREAMS = 20 /* measurements: 1 = the light and the wave-path workgroups of the send half as two kernels on two
+                                    streams of the handle instead of one launch (default 0: slower, see pcc_send_bodies.h) */,
+       PCC_TUNE_LIGHT_FRONT_WGS = 21 /* send launch: light workgroups (4 items each, the longest) dispatched in front of the
+                                    wave-path workgroups; default 8 */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* Sizes of the shared ring pools (see pcc_create): tiers 1, 2, 3 get a slot for one sender in div1, div2, div3 (defaults

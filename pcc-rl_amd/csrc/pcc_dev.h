@@ -1,0 +1,458 @@
+// pcc_dev.h -- MI355X (gfx950) batched congestion-control simulator: what every kernel file shares
+// (state layout, the Dev argument block, RNG, the link model, ring addressing, work-list constants).
+//
+// What this replaces (reference = PCCproject/PCC-RL; "ns" = src/gym/network_sim.py,
+// "so" = src/common/sender_obs.py): the per-env heap-driven discrete-event loop
+// Network.run_for_dur (ns:123-205) with its Link queue model (ns:56-96) and Sender
+// accounting (ns:207-342), the monitor-interval metrics + history (so:20-206) and the env
+// protocol around them (ns:344-496) -- for N independent envs advanced one monitor interval
+// (MI) per step.
+//
+// Formulation (NOT the reference's heap; DESIGN.md section 3 has the arguments):
+//   * For one sender the heap only ever holds the single pending SEND, packets on the forward
+//     hop ("hop-1" events, time t1) and packets on the return hop ("hop-2" events, time
+//     t2 = t1 + dl).  Link state and the loss RNG are touched only by SEND events and the rate
+//     is constant inside an MI, so an MI splits into (1) the SEND stream -- a sequential
+//     recurrence per env -- and (2) retiring the packets whose events fall before the MI end.
+//   * In-flight packets live in two HBM rings per env per sender -- accepted packets and dropped
+//     packets -- appended in send order as 16-byte records (fp64 t1, fp64 forward latency).
+//     Records are never rewritten: t2 and the RTT are t1 + dl and latency + dl, recomputed.
+//   * Accepted packets leave the queue >= 1/bw apart, so their send order IS event order and
+//     every MI boundary on that ring is a monotone search; the RTT samples of an MI are a
+//     contiguous slice of it.  Dropped packets between two accepted ones arrive at
+//     mathematically equal times, so float rounding and the heap's tuple tie-break
+//     (time, latency, dropped) decide their order: the dropped ring is in event order only up
+//     to groups of near-equal times, and a small serial path orders the one group at each
+//     boundary exactly.
+//   * Every floating-point operation on the timeline is IEEE binary64 in the reference's order
+//     (compile with -ffp-contract=off).  The per-MI RTT means replicate numpy's pairwise
+//     summation bit for bit, because run_dur = 0.5 * mean feeds back into event boundaries.
+//
+// In-flight rings are tiered: small per-sender rings plus pools of 4x/16x/64x larger ones a sender
+// is promoted into (by its whole wavefront, at the start of an MI that could overflow them).
+//
+// Kernels per step, each in its own translation unit with its own register budget (csrc/*.hip; the C ABI and the
+// launch logic are in pcc_sim.hip):
+//   send_light_kernel    (pcc_send_light.hip) light items off the class lists the previous retire launch filed: 64 envs
+//                        of about the same predicted packet count, a lane each, in rounds (no loads in the loop);
+//   send_wave_kernel     (pcc_send_wave.hip) persistent wavefronts over the wave-path items -- an env sent by all 64
+//                        lanes, 256 packets per pass, from closed forms (heavy_mi) -- and the team items (the largest
+//                        envs, four wavefronts of a workgroup per env); runs beside the light kernel on a second stream;
+//   send_restart_kernel  (pcc_send_restart.hip) envs that finished their episode out of lockstep: new links, the two
+//                        warm-up intervals (send + retire each), then the first interval; third stream;
+//   retire_kernel        (pcc_retire.hip) retire_env, 8 or 16 lanes per env: searches of the rings for the hop-2 / hop-1
+//                        boundaries (all four advanced together), the MI-ending event, RTT sums as numpy's pairwise
+//                        tree, metrics, history, observation, reward, done; then files every env by its predicted
+//                        packet count for the next send;
+//   step_small_kernel    (pcc_small.hip) both halves of a small batch's step in one launch; reset_init_kernel.
+// No MFMA: there is no contraction anywhere on this path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <atomic>
+#include <new>
+#include <vector>
+
+#include "pcc_sim.h"
+
+// (the types every translation unit passes around live in a named namespace: one definition, external linkage)
+namespace pcc {
+
+constexpr int kMaxFeatures = 16;
+constexpr int kMaxSenders = 2;
+constexpr int kWave = 64;
+constexpr int kRetireBlock = 128;     // (16 lanes per env:) 8 envs per workgroup: 0.118 ms; 16 envs: 0.122 (a workgroup's slots are refilled
+                                      // together); one wavefront per workgroup: 0.212 (the launch then waits for the
+                                      // dispatcher, 16 384 workgroups at ~80 per us)
+#ifndef PCC_RETIRE_OCC
+#define PCC_RETIRE_OCC 4  // retire workgroups per SIMD the register budget is cut for: 5 spills (48 B/lane) and is slower
+#endif
+constexpr double kMaxRate = 1000.0;      // ns:36
+constexpr double kMinRate = 40.0;        // ns:37
+constexpr double kRewardScale = 0.001;   // ns:39
+constexpr int64_t kBytesPerPacket = 1500;  // ns:46
+constexpr uint32_t kNpBufsize = 8192;    // numpy add.reduce inner-loop chunk
+constexpr uint32_t kParamTag = 0xFFFFFFFFu;
+
+// metric registry so:193-206
+static __constant__ double c_metric_scale[PCC_N_METRICS] = {1e7, 1e7, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+
+constexpr int kMaxTiers = 4;
+
+// State of an env and of a sender, one 128-byte line each: an env's fields share a line instead of
+// sharing it with the same field of 15 other envs -- both halves walk the envs in work-list order, so
+// neighbours in a wavefront are not neighbours in memory.
+// Fields are grouped in 16-byte pieces by who writes them, so that each half loads and writes an env
+// with a few wide instructions: many narrow stores to ONE line queue up behind each other in the L2
+// channel that owns it (measured: the same retire half ran 25 % slower with one 4/8-byte store per field).
+struct alignas(128) EnvBlk {
+    double bw, dl;    //   0  the episode's link (reset)
+    double lr, maxq;  //  16
+    double ebw;       //  32
+    uint32_t episode;
+    uint32_t pad_c;
+    double q, tu;     //  48  link queue: send half, and the retire half's MI-ending event
+    double now, run_dur;            //  64  retire half
+    unsigned long long total_sent;  //  80  retire half
+    uint32_t steps;
+    uint8_t done, resetting;
+    uint8_t pad0[2];
+    uint32_t mi_draws;  //  96  send half: link-entry draws of the MI (a SEND the window blocks still draws)
+    uint32_t ep_draws;  //      ... of the episode: the position in a replayed loss trace
+    uint32_t flags;
+    uint32_t pad_h;
+};
+struct alignas(128) SndBlk {
+    double rate, rate0;          //  0  send half (rate)
+    double next_send, min_lat;   // 16  both halves / retire half
+    double ep_return, last_return;  // 32  retire half
+    char *ring_base;             // 48  accepted ring of the sender (the dropped ring follows it)
+    uint8_t ring_tier;
+    uint8_t pad0[7];
+    uint32_t ha, hd, ta, td;     // 64  accepted/dropped ring heads and tails
+    uint32_t mi_sent;            // 80
+    uint32_t ring_held[kMaxTiers];  // pool slot + 1 the sender holds in tier c (0 = none) until reset
+    uint32_t cwnd;     // the reference's dormant USE_CWND option (ns:54): the sender's window in packets (ns:227: 25 at reset)
+    uint32_t heap_n;   // event-loop build (event_engine): the sender's events in its heap = its packets in flight
+    uint32_t pad1;
+    // 112  retire half: where the last interval's four ring boundaries fell, as predictions of the next ones (speed only:
+    // search_many verifies them) -- acknowledgements and loss reports per second of simulated time, and the packets that were
+    // on the return hop at the interval's end (accepted / dropped ring)
+    float ack_rate, loss_rate;
+    uint32_t on_return_a, on_return_d;
+};
+static_assert(sizeof(EnvBlk) == 128 && sizeof(SndBlk) == 128, "one line per block");
+
+// Everything a kernel needs, passed by value.
+struct Dev {
+    int64_t n;
+    int ns, H, F, HF;
+    int32_t fid[kMaxFeatures];
+    // In-flight storage in tiers (see "In-flight packet storage" below): tier c rings hold
+    // cap0 * 4^c accepted + twice as many dropped records.  Tier 0 is one slot per (env, sender);
+    // the higher tiers are pools an env is promoted into when an MI could overflow its rings.
+    int n_tiers;
+    uint32_t cap0;
+    char *tier_base[kMaxTiers];
+    uint32_t *tier_free[kMaxTiers];  // [tier_slots[c]] free slot ids (a stack; c >= 1)
+    int32_t *tier_top;               // [kMaxTiers] stack heights
+    uint32_t tier_slots[kMaxTiers];  // slots of each pool
+    uint32_t key0, key1, gid_base;
+    double delta_scale;
+    uint32_t max_steps;
+    uint32_t *cls_count;  // [2][kClsStride] work lists of the send half (two buffers): envs per class, item cursor
+    uint32_t *cls_list;   // [2][kClasses][N] env ids by class
+    uint32_t *cursors;    // [3][kShards][kCursorStride] item cursors of the two list buffers (third block unused)
+    // [1] the retire half writes the step's sequence number (step_seq, below) here when an env finishes its episode;
+    // the gated auto-reset launches of that step run only if they find it.  Nobody ever clears the word: a clear by one
+    // workgroup of a launch races with the sets of the others (the L2 of every XCD writes back on its own schedule)
+    uint32_t *any_done;
+    uint32_t step_seq;    // sequence number of the step this launch belongs to (host counter, never 0)
+    uint64_t *timeline;  // profiling only (PCC_DEBUG_TIMELINE env): 8 words per send wavefront, see pcc_debug_timeline
+    unsigned long long *pass_stats;  // profiling only (same switch): counters of the wave passes, see pcc_debug_pass_stats
+    int pass_counters;               // ... per-pass counters on (PCC_DEBUG_TIMELINE=2: contended atomics, they slow the passes down)
+    // tuning (speed only): light items dealt to the workgroups in snake order (a workgroup's four items add up to about the
+    // same number of packets); the wave kernel's first items dealt oldest workgroup first (1) or youngest first (0);
+    // s_setprio level for the first prio_light_items light items / the first prio_wave_items wave-path items / team items
+    uint32_t light_snake, wave_oldest_first, prio_level, prio_light_items, prio_wave_items, prio_team;
+    uint32_t retire_sorted;  // debug: 0 = the retire launch walks the envs in index order even when there are lists
+    int debug_skip;  // profile build only (PCC_DEBUG_SKIP env): bit0 skip RTT means, bit1 skip history/obs, bit2 skip the
+                     // lane rounds' record stores, bit3 skip their Philox -- results wrong, timing only
+    uint32_t round_packets, takeover_lanes, send_envs_per_wave, send_waves;
+    double heavy_predict;  // predicted packets per MI above which an env goes to the heavy wave
+    double team_predict;   // ... above which a whole workgroup sends it (team pass)
+    float heavy_item_packets;  // a heavy work item is as many envs of its class as make up about this many packets (1..8 envs)
+    float retire_wide_predict; // retire half: envs predicted above this many packets per interval get 16 lanes instead of 8
+    double lo[5], hi[5];
+    int rng_mode;
+    const double *trace;
+    int64_t trace_stride;
+    const double *p_bw, *p_dl, *p_queue, *p_loss, *p_rate0;
+    EnvBlk *env;  // [N] link + env state, one 128-byte block per env
+    SndBlk *snd;  // [S][N] per sender, one 128-byte block each
+    // the reference's dormant USE_CWND engine option (ns:54)
+    int use_cwnd;
+    // the reference's dormant USE_LATENCY_NOISE engine option (ns:51-52): packets overtake each other, so the in-flight
+    // set is a real priority queue (see event_engine)
+    int use_noise;
+    // the event-loop build runs the interval (event_engine): with USE_LATENCY_NOISE, and with USE_CWND on two senders
+    int engine;
+    double noise_span;     // MAX_LATENCY_NOISE - 1.0: random.uniform(1.0, MAX) = 1.0 + span * random()
+    uint32_t noise_cap;    // events / RTT samples per sender (a power of two)
+    double2 *noise_heap;   // [S][N][noise_cap] (+-t, +-latency): sign of t = hop 2, sign of latency = dropped
+    double2 *noise_rtt;    // [S][N][noise_cap] (-, rtt) of the packets acknowledged in the current MI, in ack order
+    float *hist;    // [N][S][HF]
+    double2 *ring;  // [N][S][2][cap]: accepted ring, dropped ring
+};
+
+}  // namespace pcc
+using namespace pcc;
+
+namespace {
+
+// Profiling hooks (per-item timeline, pass counters, the "skip" switches that drop work to see what a phase costs --
+// the latter make results WRONG) exist only in the -DPCC_PROFILE=1 build (libpcc_sim_prof.so, used by tools/): the
+// product library carries none of it, and no environment variable can change what it computes.
+#ifndef PCC_PROFILE
+#define PCC_PROFILE 0
+#endif
+constexpr bool kProfile = PCC_PROFILE != 0;
+__device__ __forceinline__ bool prof_on(const Dev &D) { return kProfile && D.timeline != nullptr; }
+__device__ __forceinline__ bool prof_counters(const Dev &D) { return kProfile && D.pass_counters != 0; }
+__device__ __forceinline__ bool prof_skip(const Dev &D, int bit) { return kProfile && (D.debug_skip & bit) != 0; }
+
+// --------------------------------------------------------------------------------------
+// small helpers
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ double max0(double x) { return x > 0.0 ? x : 0.0; }  // max(0.0, x)
+
+// instruction-issue priority of this wavefront among those of its SIMD (level wave-uniform; s_setprio takes an immediate)
+__device__ __forceinline__ void set_prio(uint32_t level) {
+    if (level == 1u) __builtin_amdgcn_s_setprio(1);
+    else if (level == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (level >= 3u) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
+__device__ __forceinline__ uint64_t mul_wide_u32(uint32_t a, uint32_t b) {
+    uint64_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "vcc");
+    return r;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        // one v_mad_u64_u32 per 32x32->64 product (integer multiplies are quarter rate: the
+        // compiler's mul_hi + mul_lo pair costs twice as much)
+        const uint64_t p0 = mul_wide_u32(c0, 0xD2511F53u), p1 = mul_wide_u32(c2, 0xCD9E8D57u);
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u32_to_unit(uint32_t x) { return (double)x * (1.0 / 4294967296.0); }
+
+// loss uniform of the j-th SEND on the env's link (any sender) in monitor interval mi (the draw of
+// ns:73; one stream per env consumed in event order, like the reference's random.random())
+__device__ __forceinline__ double philox_packet_uniform(const Dev &D, uint32_t gid, uint32_t episode, uint32_t mi,
+                                                        uint32_t j) {
+    uint32_t w[4];
+    philox4x32_10(j >> 2, mi, episode, gid, D.key0, D.key1, w);
+    const uint32_t i = j & 3u;
+    return u32_to_unit(i == 0 ? w[0] : i == 1 ? w[1] : i == 2 ? w[2] : w[3]);
+}
+
+// Link.packet_enters_link + latency sampling for one SEND at time t: ns:66-84, 170-175.
+// Returns the record (t + lat0, lat0) and whether the packet was dropped.  Branch-free: the three
+// outcomes (random loss: queue untouched, ns:73-74; tail drop: queue drained but not grown,
+// ns:75-81; accepted: ns:82) are selects over values computed in the reference's operation order.
+__device__ __forceinline__ double2 link_send(double t, bool rnd /* random.random() < lr, ns:73 */, double dl,
+                                             double maxq, double ebw, double &q, double &tu, bool &dropped) {
+    const double qcur = max0(q - (t - tu));  // ns:66-67
+    const double lat0 = dl + qcur;           // ns:170: latency before this packet queues
+    const bool full = ebw + qcur > maxq;     // ns:79 (with queue_delay already = qcur)
+    const double grown = qcur + ebw;         // ns:82
+    q = rnd ? q : (full ? qcur : grown);
+    tu = rnd ? tu : t;                       // ns:76
+    dropped = rnd || full;                   // ns:175
+    double2 rec;
+    rec.x = t + lat0;                        // ns:174
+    rec.y = lat0;                            // ns:173 (0.0 + lat0)
+    return rec;
+}
+
+// ======================================================================================
+// In-flight packet storage.  Per env and sender two rings of 16-byte records (t1, lat0):
+//   accepted ring  packets that entered the queue, in send order.  Their arrival times grow
+//                  by >= 1/bw per packet, so send order IS event order (exactly), every
+//                  boundary is a monotone search, and the RTT samples of an MI are a
+//                  contiguous slice.
+//   dropped ring   packets lost at random or tail-dropped, in send order.  Consecutive drops
+//                  with no accepted packet in between arrive at mathematically equal times
+//                  (a dropped packet does not delay its successor), so rounding decides their
+//                  order: send order is event order only up to "near groups" (neighbours
+//                  within kNearTol relative time), which a serial path orders exactly.
+// ======================================================================================
+constexpr double kNearTol = 1e-12;  // >> the few-ulp spread of a tie group, << any 1/bw
+
+__device__ __forceinline__ bool near_time(double a, double b) {
+    return fabs(a - b) <= kNearTol * fmax(1.0, fabs(b));
+}
+
+// Ring accesses through explicit global-address-space pointers.  The ring addresses are loaded from
+// memory (tiers), which makes them "generic" pointers to the compiler -- flat_load / flat_store,
+// slower than global_load / global_store and counted against the LDS queue as well.
+typedef double gvec2 __attribute__((ext_vector_type(2)));
+#define PCC_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ double2 ld_rec(const double2 *p) {
+    const gvec2 v = *(const PCC_GLOBAL gvec2 *)(const void *)p;
+    double2 r;
+    r.x = v.x; r.y = v.y;
+    return r;
+}
+__device__ __forceinline__ void st_rec(double2 *p, const double2 &r) {
+    gvec2 v;
+    v.x = r.x; v.y = r.y;
+    *(PCC_GLOBAL gvec2 *)(void *)p = v;
+}
+__device__ __forceinline__ double ld_f64(const void *p) { return *(const PCC_GLOBAL double *)p; }
+__device__ __forceinline__ double ld_t1(const double2 *p) { return ld_f64(p); }  // .x of a record
+
+// the rings of one sender: accepted ring of `cap` records at base, dropped ring of 2 * cap after it
+struct RingRef {
+    char *base;
+    uint32_t cap;
+    __device__ __forceinline__ double2 *accepted() const { return reinterpret_cast<double2 *>(base); }
+    __device__ __forceinline__ double2 *dropped() const { return reinterpret_cast<double2 *>(base) + cap; }
+    __device__ __forceinline__ uint32_t mask() const { return cap - 1u; }
+    __device__ __forceinline__ uint32_t dmask() const { return 2u * cap - 1u; }
+};
+
+__device__ __forceinline__ uint32_t tier_cap(const Dev &D, uint32_t tier) { return D.cap0 << (2u * tier); }
+__device__ __forceinline__ size_t tier_slot_bytes(const Dev &D, uint32_t tier) { return (size_t)3 * tier_cap(D, tier) * sizeof(double2); }
+
+__device__ __forceinline__ RingRef ring_ref(const Dev &D, int64_t k /* s * n + i */) {
+    RingRef r;
+    r.base = D.snd[k].ring_base;
+    r.cap = tier_cap(D, D.snd[k].ring_tier);
+    return r;
+}
+
+// Smallest tier whose rings hold `need_a` accepted and `need_d` dropped records (n_tiers if none).
+__device__ __forceinline__ uint32_t tier_for(const Dev &D, uint32_t need_a, uint32_t need_d) {
+    uint32_t c = 0;
+    while (c < (uint32_t)D.n_tiers && (tier_cap(D, c) < need_a || 2u * tier_cap(D, c) < need_d)) c++;
+    return c;
+}
+
+// ======================================================================================
+// send_kernel: apply_rate_delta (ns:235-241, 275-281) + every SEND event with time < end of the
+// coming MI (ns:155-178).  One lane per env for the serial recurrence; envs with many packets in
+// the MI ("heavy": deep queue, overloaded) are then processed one at a time by the whole wave,
+// up to 256 packets per pass (heavy_mi below), the largest by the four wavefronts of a workgroup together.
+// ======================================================================================
+
+// how many bits of `mask` (a ballot) lie below this lane: v_mbcnt_lo / v_mbcnt_hi on the mask's scalar halves -- two
+// instructions and no lane mask in vector registers (__popcll(mask & ((1ull << lane) - 1)) is five and two registers)
+__device__ __forceinline__ uint32_t count_below(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ double rl_f64(double v, uint32_t l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), (int)l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), (int)l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint64_t rl_u64(uint64_t v, uint32_t l) {
+    const uint32_t lo = rl_u32((uint32_t)v, l), hi = rl_u32((uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+// records [h, h + n) of one ring to another, by the whole wavefront, kCopyDepth KB in flight: a load-then-store loop
+// waits one memory round trip per KB, and the promotion of a deep-queue env (10-25 k records) was the send launch's
+// critical path in most steps (100-140 us of a 110-170 us launch)
+constexpr int kCopyDepth = 8;
+__device__ __forceinline__ void copy_records(double2 *dst, uint32_t dmask, const double2 *src, uint32_t smask, uint32_t h,
+                                             uint32_t n, uint32_t lane) {
+    for (uint32_t j0 = 0; j0 < n; j0 += kCopyDepth * kWave) {
+        double2 r[kCopyDepth];
+#pragma unroll
+        for (int b = 0; b < kCopyDepth; b++) {
+            const uint32_t j = j0 + (uint32_t)b * kWave + lane;
+            r[b].x = 0.0; r[b].y = 0.0;
+            if (j < n) r[b] = ld_rec(src + ((h + j) & smask));
+        }
+#pragma unroll
+        for (int b = 0; b < kCopyDepth; b++) {
+            const uint32_t j = j0 + (uint32_t)b * kWave + lane;
+            if (j < n) st_rec(dst + ((h + j) & dmask), r[b]);
+        }
+    }
+}
+
+// Move the rings of sender k (lane `l` of the wavefront owns it) to a free slot of tier >= want:
+// all 64 lanes copy the live records [ha, ta) / [hd, td); ring indices stay what they are, only
+// the address of index j changes.  The slot the sender leaves stays reserved for it until its env
+// is reset (pops happen only in send launches, pushes only in reset launches: no stack races).
+// Returns false (and flags the env) when every pool from `want` up is empty.
+__device__ __forceinline__ bool promote_rings(const Dev &D, uint32_t lane, uint32_t l, int64_t k, uint32_t want,
+                                              uint32_t ha, uint32_t ta, uint32_t hd, uint32_t td) {
+    uint32_t got = 0xFFFFFFFFu, slot = 0;
+    if (lane == l) {
+        for (uint32_t c = want; c < (uint32_t)D.n_tiers; c++) {
+            const int32_t old = atomicSub(&D.tier_top[c], 1);
+            if (old > 0) { slot = D.tier_free[c][old - 1]; got = c; break; }
+            atomicAdd(&D.tier_top[c], 1);
+        }
+    }
+    got = rl_u32(got, l);
+    if (got == 0xFFFFFFFFu) return false;
+    slot = rl_u32(slot, l);
+    const int64_t kk = (int64_t)rl_u64((uint64_t)k, l);
+    const RingRef from = ring_ref(D, kk);
+    RingRef to;
+    to.cap = tier_cap(D, got);
+    to.base = D.tier_base[got < kMaxTiers ? got : 0] + (size_t)slot * tier_slot_bytes(D, got);
+    const uint32_t h_a = rl_u32(ha, l), n_a = rl_u32(ta, l) - h_a, h_d = rl_u32(hd, l), n_d = rl_u32(td, l) - h_d;
+    copy_records(to.accepted(), to.mask(), from.accepted(), from.mask(), h_a, n_a, lane);
+    copy_records(to.dropped(), to.dmask(), from.dropped(), from.dmask(), h_d, n_d, lane);
+    if (lane == l) {
+        D.snd[k].ring_base = to.base;
+        D.snd[k].ring_tier = (uint8_t)got;
+        D.snd[k].ring_held[got] = slot + 1u;
+    }
+    return true;
+}
+// ---- work lists ----------------------------------------------------------------------------
+// The retire half knows every env's packet count of the NEXT monitor interval to within the effect
+// of one action (run_dur x rate), so it files the env under one of kClasses geometric classes
+// (class c >= 1: [8 * 1.25^(c-1), 8 * 1.25^c) packets; c = 0: fewer than 8).  The send half's work
+// items come off those lists, heaviest class first: every env of a class at or above the heavy
+// threshold is an item of its own (wave path), the envs of a lighter class go 64 at a time to
+// lane-per-env rounds -- lanes of about the same length, so a wavefront's lanes finish together.
+// Persistent wavefronts take the items off sharded cursors (send_kernel): nobody waits for a
+// neighbour.  The lists are a permutation of the envs whatever the predictions say (a reset in
+// between leaves stale predictions: harmless).
+constexpr int kClasses = 32;
+constexpr int kCntStride = 32;            // words between two counters: every class count has its own 128-byte line.  The
+                                          // retire launch reads one buffer's counts while it files into the other with
+                                          // atomics; a load from a line that atomics are queueing on waits behind them (a
+                                          // shared line made the launch 45 % slower), and atomics on one line serialize
+constexpr int kClsStride = (kClasses + 1) * kCntStride;  // words per buffer: kClasses counts + the count of the restart list
+constexpr int kRestart = kClasses;        // row of the envs that finished their episode in the filing retire launch:
+                                          // the next send launch runs their reset's two warm-up intervals first
+constexpr int kListRows = kClasses + 1;
+
+__device__ __forceinline__ int class_of(float pred) {
+    if (!(pred >= 8.0f)) return 0;
+    const int c = 1 + (int)(__log2f(pred * 0.125f) * 3.1062837f);  // 1 / log2(1.25)
+    return c < kClasses - 1 ? c : kClasses - 1;
+}
+
+// read_buf < 0: no lists (after a reset, and for the warm-up intervals): the items are the envs in
+// index order, 64 (send_envs_per_wave) at a time.  zero_buf: the buffer the coming retire launch files
+// into; its counters are cleared here.
+// Hand-out: item t belongs to shard t % kShards; wavefront w starts with item w (no atomic) and then
+// claims the next item of its shard from the shard's cursor -- one returning device-scope atomic on
+// one word saturates near 90 claims/us, 16 words in separate cache lines do not -- and helps the other
+// shards when its own is empty (a plain look at their cursors first: no atomic on an empty shard).
+constexpr uint32_t kShards = 16;
+constexpr uint32_t kCursorStride = 32;  // words between shard cursors: one 128-byte line each
+
+// (send_kernel itself follows retire_env below: a restart item runs the env's warm-up intervals through both halves)
+
+}  // namespace

@@ -1,0 +1,32 @@
+// pcc_kernels.h -- the launch functions of the kernel files (each .hip defines its kernels and the host function that
+// launches them; pcc_sim.hip, the C ABI, calls these).  One translation unit per kernel family, so that every kernel
+// is compiled -- and register-allocated -- on its own.
+#pragma once
+#include "pcc_dev.h"
+
+namespace pcc {
+
+// pcc_send.hip: both kinds of workgroup in one launch -- `front` light workgroups, then wave_wgs wave-path workgroups, then the
+// other light workgroups (light_wgs in all).
+void launch_send(const Dev &d, bool trace, unsigned light_wgs, unsigned wave_wgs, unsigned front, hipStream_t st, int read_buf,
+                 int zero_buf, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64);
+// pcc_send_light.hip (the light workgroups as a kernel of their own: split_streams).  grid: workgroups of 4 wavefronts, one light item (or index-order chunk) per wavefront and round.
+void launch_send_light(const Dev &d, bool trace, unsigned grid, hipStream_t st, int read_buf, int zero_buf, int warm,
+                       uint32_t warm_mi, int gate, const void *actions, int actions_f64);
+// pcc_send_wave.hip (the wave-path workgroups as a kernel of their own: split_streams).  grid: persistent workgroups of 4 wavefronts (wave-path items off cursors; team items first).
+void launch_send_wave(const Dev &d, bool trace, unsigned grid, hipStream_t st, int read_buf, const void *actions, int actions_f64);
+// pcc_send_restart.hip.  grid: workgroups of 4 wavefronts, restart items dealt statically.
+void launch_send_restart(const Dev &d, bool trace, unsigned grid, hipStream_t st, int read_buf, const void *actions, int actions_f64);
+// pcc_retire.hip
+void launch_retire(const Dev &d, bool noise, unsigned grid, hipStream_t st, int read_buf, int fill_buf, int warm, uint32_t warm_mi,
+                   int last_warm, int gate, int restart, float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out,
+                   const void *actions, int actions_f64);
+// pcc_small.hip
+void launch_step_small(const Dev &d, bool trace, hipStream_t st, const void *actions, int actions_f64, float *obs_out,
+                       float *reward_out, uint8_t *done_out, double *steps_out);
+void launch_reset_init(const Dev &d, hipStream_t st, const uint8_t *mask, int use_done, int gate, int all_envs, float *obs_out);
+void launch_forget_ring_slots(const Dev &d, hipStream_t st);
+
+constexpr int kRetireEnvsPerBlockNarrow = 16;  // envs of a retire workgroup at 8 lanes per env (16 lanes: half)
+
+}  // namespace pcc

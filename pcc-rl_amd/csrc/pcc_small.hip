@@ -1,0 +1,114 @@
+// pcc_small.hip -- step_small_kernel (both halves of a small batch's step in one launch), reset_init_kernel (new links and
+// fresh state at a reset) and the pool bookkeeping kernel of pcc_set_ring_pools.
+#include "pcc_send_item.h"
+#include "pcc_retire_env.h"
+#include "pcc_kernels.h"
+
+#ifndef PCC_SMALL_OCC
+#define PCC_SMALL_OCC 3  // workgroups (4 wavefronts) per compute unit the register budget is cut for: the kernel is a chain of
+                         // dependent round trips of one workgroup per 64 envs, not an occupancy problem
+#endif
+
+namespace {
+
+// ======================================================================================
+// step_small_kernel: both halves of a step in ONE launch, for batches too small for work lists (pcc_step of fewer than
+// list_min_envs envs).  A workgroup owns 64 envs: its first wavefront sends them, a lane each (send_light_item, the tail by the
+// wave path), then the four wavefronts retire them, 8 lanes per env.  No cross-workgroup dependency: an env's retire
+// half needs only its own send half.  At 4 096 envs of two packets a step is launch overhead and dependent loads, and
+// one launch instead of two is a third of it (config 2: 34 -> about 24 us per step).
+// ======================================================================================
+template <int NS, bool TRACE>
+__global__ __launch_bounds__(4 * kWave, PCC_SMALL_OCC) void step_small_kernel(Dev D, const void *actions, int actions_f64, float *obs_out,
+                                                                           float *reward_out, uint8_t *done_out, double *steps_out) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int64_t base = (int64_t)blockIdx.x * kWave;
+    __shared__ EnvSlot<NS> s_slots[kSlots];
+    if (wv == 0) {
+        const int64_t i = base + lane;
+        const bool has = i < D.n;
+        uint32_t pk = 0;
+        const uint64_t left = send_light_item<NS, TRACE>(D, lane, has ? i : 0, has, blockIdx.x, 0, 0, actions, actions_f64, pk);
+        if (left) {  // the last lanes of the rounds go on by the wave path, from the state the item stored (pcc_send_item.h)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            (void)send_wave_item<NS, TRACE, 1>(D, lane, has ? i : 0, ((left >> lane) & 1ull) != 0ull, false, 0xFFFFFFFFu, 0, 0, actions, actions_f64, s_slots);
+        }
+    }
+    __syncthreads();  // the records and the state the first wavefront wrote are read by all four (same CU: workgroup scope)
+#pragma unroll 1
+    for (uint32_t r = 0; r < 2u; r++) {
+        const int64_t i = base + (int64_t)((wv * 2u + r) * 8u + lane / 8u);
+        Group g;
+        g.lane = lane & 7u;
+        g.shift = lane & ~7u;
+        if (i < D.n)
+            (void)retire_env<NS, false, 8>(D, i, g, 0, 0, 0, 0, obs_out, reward_out, done_out, steps_out, nullptr, 0);
+    }
+}
+
+// ======================================================================================
+// reset_init_kernel: ns:454-477 -- parameters, fresh link/sender/history state.  The two warm-up
+// MIs (ns:478-479) are run by send_kernel / retire_kernel in warm mode on the marked envs.
+// ======================================================================================
+// all_envs: the host knows that EVERY env is reset by this launch (a full reset, or the episode boundary of a batch in
+// lockstep).  Then nobody keeps a pool slot and the free stacks are simply rebuilt in order (slot 0 on top) instead of
+// being pushed slot by slot in whatever order the atomics land: a batch whose pool rings sit in the order they were
+// handed out runs its send half 15-35 % faster than one whose rings are scattered over the pools (the second episode of
+// a handle took 0.163 ms per send launch against 0.118 for the first; profiles/r03_experiments.json).
+template <int NS>
+__global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t *mask, int use_done, int gate, int all_envs,
+                                                           float *obs_out) {
+    if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != D.step_seq) return;
+    const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    if (all_envs) {
+        for (int c = 1; c < D.n_tiers; c++) {
+            const int64_t slots = (int64_t)D.tier_slots[c];
+            for (int64_t j = i; j < slots; j += (int64_t)gridDim.x * kWave) D.tier_free[c][j] = (uint32_t)(slots - 1 - j);
+            if (i == 0) D.tier_top[c] = (int32_t)slots;
+        }
+    }
+    if (i >= D.n) return;
+    // use_done 1: the envs that finished their episode; 2: the envs a retire launch marked for a restart
+    const bool sel = use_done == 2 ? D.env[i].resetting == 2 : (!mask || mask[i]) && (!use_done || D.env[i].done);
+    D.env[i].resetting = sel ? 1 : 0;
+    if (sel) {
+        release_ring_slots<NS>(D, i, !all_envs);
+        reset_env<NS>(D, i, obs_out);
+    }
+}
+
+// pcc_set_ring_pools: every sender back in its own tier-0 rings, holding no pool slot (the pools are being replaced)
+__global__ void forget_ring_slots_kernel(Dev D) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= D.n * D.ns) return;
+    for (int c = 0; c < kMaxTiers; c++) D.snd[k].ring_held[c] = 0;
+    D.snd[k].ring_tier = 0;
+    const int64_t s = k / D.n, i = k % D.n;
+    D.snd[k].ring_base = D.tier_base[0] + (size_t)(i * D.ns + s) * tier_slot_bytes(D, 0);
+}
+
+}  // namespace
+
+namespace pcc {
+
+void launch_step_small(const Dev &d, bool trace, hipStream_t st, const void *actions, int actions_f64, float *obs_out,
+                       float *reward_out, uint8_t *done_out, double *steps_out) {
+    const dim3 grid((unsigned)((d.n + kWave - 1) / kWave)), block(4 * kWave);
+#define PCC_S(NS_, TR_) hipLaunchKernelGGL((step_small_kernel<NS_, TR_>), grid, block, 0, st, d, actions, actions_f64, obs_out, reward_out, done_out, steps_out)
+    if (d.ns == 1) { if (trace) PCC_S(1, true); else PCC_S(1, false); }
+    else { if (trace) PCC_S(2, true); else PCC_S(2, false); }
+#undef PCC_S
+}
+
+void launch_reset_init(const Dev &d, hipStream_t st, const uint8_t *mask, int use_done, int gate, int all_envs, float *obs_out) {
+    const dim3 grid((unsigned)((d.n + kWave - 1) / kWave));
+    if (d.ns == 1) hipLaunchKernelGGL(reset_init_kernel<1>, grid, dim3(kWave), 0, st, d, mask, use_done, gate, all_envs, obs_out);
+    else hipLaunchKernelGGL(reset_init_kernel<2>, grid, dim3(kWave), 0, st, d, mask, use_done, gate, all_envs, obs_out);
+}
+
+void launch_forget_ring_slots(const Dev &d, hipStream_t st) {
+    const int64_t senders = d.n * d.ns;
+    hipLaunchKernelGGL(forget_ring_slots_kernel, dim3((unsigned)((senders + 255) / 256)), dim3(256), 0, st, d);
+}
+
+}  // namespace pcc

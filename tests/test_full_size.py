@@ -108,8 +108,8 @@ def test_config3_every_env_every_step_matches_the_oracle():
     n, steps = _size(65536)
     info = _run_and_compare(n, 1, seed=0, n_steps=steps, extra_steps=20)
     if n >= 65536 and steps >= 400:
-        # the point of the size: the giants are in the comparison
-        assert info["max_packets_in_a_step"] >= 8000, info
+        # the point of the size: the largest envs of a whole episode are in the comparison
+        assert info["max_packets_in_a_step"] >= 4096, info   # (the team items' threshold: the largest envs went that way)
     print("config 3 whole batch:", info)
 
 
