@@ -145,23 +145,28 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
     if (waves > d.n) waves = d.n;
     const unsigned wave_grid = wave ? (unsigned)((waves + 3) / 4) : 0u;
     const unsigned restart_grid = (unsigned)(sim->cu_count < (d.n + 3) / 4 ? sim->cu_count : (d.n + 3) / 4);
-    if (rs) {
+    if (sim->split_streams && wave) {   // (measurements only; restart items, if any, first on the caller's stream)
+        if (rs) launch_send_restart(d, tr, restart_grid, st, read_buf, actions, actions_f64);
         if (hipEventRecord(sim->ev_fork, st) != hipSuccess) return fail(PCC_EHIP, "hipEventRecord failed");
-        (void)hipStreamWaitEvent(sim->aux_restart, sim->ev_fork, 0);
-        launch_send_restart(d, tr, restart_grid, sim->aux_restart, read_buf, actions, actions_f64);
-        (void)hipEventRecord(sim->ev_restart, sim->aux_restart);
-    }
-    if (sim->split_streams && wave) {
-        if (!rs && hipEventRecord(sim->ev_fork, st) != hipSuccess) return fail(PCC_EHIP, "hipEventRecord failed");
         (void)hipStreamWaitEvent(sim->aux_wave, sim->ev_fork, 0);
         launch_send_wave(d, tr, wave_grid, sim->aux_wave, read_buf, actions, actions_f64);
         (void)hipEventRecord(sim->ev_wave, sim->aux_wave);
         launch_send_light(d, tr, light_grid, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
         (void)hipStreamWaitEvent(st, sim->ev_wave, 0);
+    } else if (rs) {
+        // The restart items are a chain of dependent passes (reset, two warm-up intervals, the first interval): longer than
+        // the whole main launch.  So the MAIN launch goes to the side stream and the restart kernel stays on the caller's:
+        // what the next launch of the caller's stream waits for across streams has then long finished (a cross-stream
+        // dependency on a kernel that is just ending costs ~15 us, one that ended long ago next to nothing)
+        if (hipEventRecord(sim->ev_fork, st) != hipSuccess) return fail(PCC_EHIP, "hipEventRecord failed");
+        (void)hipStreamWaitEvent(sim->aux_wave, sim->ev_fork, 0);
+        pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, sim->aux_wave, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+        (void)hipEventRecord(sim->ev_wave, sim->aux_wave);
+        launch_send_restart(d, tr, restart_grid, st, read_buf, actions, actions_f64);
+        (void)hipStreamWaitEvent(st, sim->ev_wave, 0);
     } else {
         pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
     }
-    if (rs) (void)hipStreamWaitEvent(st, sim->ev_restart, 0);
     if (rs && !warm) sim->restarts_pending = false;  // this launch runs what the restart list's envs were owed
     return check_hip(hipGetLastError(), "send kernel launch");
 }

@@ -56,6 +56,49 @@ def test_two_rank_gather_over_gloo(tmp_path):
         assert "rank %d ok" % rank in out
 
 
+GATHER4_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch
+    from pcc_rl_amd import distributed as D
+    rank, world, local = D.init_process_group(backend="gloo")
+    assert world == 4
+    # ranks whose envs finish their episodes at different steps: a rank gathers when ITS episodes end, every rank takes part
+    # in every gather (bench.py gathers at the same step count on every rank: episodes have one length) -- here the returns a
+    # rank contributes at gather g are those of its envs that have finished by then, -1 for the others
+    n, T = 6, 12
+    finish = [(3 + (rank * n + i) %% 5) for i in range(n)]            # env i of this rank finishes at this step
+    info = D.collective_info()
+    assert info["backend"] == "gloo" and info["dist_world_size"] == 4
+    for g, t in enumerate((4, 8, 12)):
+        mine = torch.tensor([float(100 * rank + i) if finish[i] <= t else -1.0 for i in range(n)])
+        allr = D.gather_episode_returns(mine)
+        assert allr.numel() == world * n
+        for r in range(world):
+            for i in range(n):
+                want = float(100 * r + i) if (3 + (r * n + i) %% 5) <= t else -1.0
+                assert allr[r * n + i].item() == want, (g, r, i)
+    assert D.gather_floats(1.5 * rank) == [0.0, 1.5, 3.0, 4.5]
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def test_four_rank_gather_with_uneven_finish_steps(tmp_path):
+    script = tmp_path / "worker4.py"
+    script.write_text(GATHER4_WORKER)
+    port = free_port()
+    procs = []
+    for rank in range(4):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="4", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
+
+
 def test_single_process_is_identity():
     import torch
     from pcc_rl_amd import distributed as D
@@ -142,6 +185,30 @@ def test_bench_starts_its_own_ranks():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["episode_return_allgathers"] >= 3
     assert out["value"] > 0 and out["steps"] == 30
+    # the line proves its own rank count: what the process group reports, and every rank's own clock
+    assert out["distributed"]["dist_world_size"] == 2 and out["distributed"]["backend"] == "gloo"
+    assert len(out["distributed"]["per_rank_ms_per_step"]) == 2
+
+
+@pytest.mark.gpu
+def test_one_rank_through_torchrun_equals_the_plain_run():
+    """`--gpus 1` launched the way the driver launches N ranks (torch.distributed.run, RCCL process group of one rank)
+    must measure what the plain single-process run measures: same value within a few per cent, and the line says which
+    launcher and backend it went through."""
+    common = ["--gpus", "1", "--steps", "400", "--warmup", "20", "--repeats", "3", "--no-cpu-baseline", "--no-pmc"]
+    envv = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(cmd):
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=envv)
+        assert res.returncode == 0, res.stdout[-3000:]
+        return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+
+    plain = run([sys.executable, os.path.join(ROOT, "bench.py")] + common)
+    tr = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")] + common)
+    assert plain["distributed"]["launcher"] == "plain" and tr["distributed"]["launcher"] == "torchrun"
+    assert tr["n_gpus"] == 1 and tr["distributed"]["dist_world_size"] == 1
+    assert abs(tr["value"] / plain["value"] - 1.0) < 0.05, (tr["value"], plain["value"], tr["runs_ms_per_step"], plain["runs_ms_per_step"])
 
 
 def test_bench_refuses_a_rank_count_mismatch():
