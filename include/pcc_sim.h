@@ -268,13 +268,17 @@ int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream)
 int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_out, float *reward_out,
              uint8_t *done_out, double *steps_out, int auto_reset, void *stream);
 
-/* n_steps calls of pcc_step with pre-computed actions, queued from C: actions [n_steps][N][S] (with the congestion-window
- * option [n_steps][N][S][2]); obs_out [n_steps][N][S][H*F], reward_out [n_steps][N][S], done_out [n_steps][N], any of them
- * NULL.  For open-loop drivers of small batches, where a step (one 25 us launch for 4 096 envs) is shorter than an
- * interpreter's trip around its loop; a policy in the loop needs the observation of every step and calls pcc_step.  The
- * reference has no counterpart (its step() is one Python call per interval, ns:406). */
+/* n_steps steps with pre-computed actions in one call: actions [n_steps][N][S] (with the congestion-window option
+ * [n_steps][N][S][2]); obs_out [n_steps][N][S][H*F], reward_out [n_steps][N][S], done_out [n_steps][N], steps_out
+ * [n_steps][N][S][PCC_STEP_COLS], any of them NULL.  Results are those of n_steps pcc_step calls.  A small batch (fewer
+ * envs than LIST_MIN_ENVS) whose episode boundaries the host knows runs the steps up to the next boundary inside ONE
+ * launch -- the loop over the steps is on the device, a workgroup per 64 envs, no launch boundary between steps (config 2:
+ * a step is a chain of dependent loads, and a launch boundary is a third of it); other batches are stepped launch by launch
+ * from C.  For open-loop drivers: a policy in the loop needs the observation of every step and calls pcc_step.  On an error
+ * the message says after how many steps the call stopped.  The reference has no counterpart (its step() is one Python call
+ * per interval, ns:406). */
 int pcc_step_many(pcc_sim_t *sim, const void *actions, int actions_f64, int n_steps, float *obs_out, float *reward_out,
-                  uint8_t *done_out, int auto_reset, void *stream);
+                  uint8_t *done_out, double *steps_out, int auto_reset, void *stream);
 
 /*
  * The two halves of pcc_step as separate calls (pcc_step = pcc_step_send + pcc_step_retire with the

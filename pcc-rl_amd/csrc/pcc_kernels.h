@@ -22,8 +22,9 @@ void launch_retire(const Dev &d, bool noise, unsigned grid, hipStream_t st, int 
                    int last_warm, int gate, int restart, float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out,
                    const void *actions, int actions_f64);
 // pcc_small.hip
+// n_steps steps inside one launch: step t takes actions + t * act_stride bytes and writes row t of every output
 void launch_step_small(const Dev &d, bool trace, hipStream_t st, const void *actions, int actions_f64, float *obs_out,
-                       float *reward_out, uint8_t *done_out, double *steps_out);
+                       float *reward_out, uint8_t *done_out, double *steps_out, int n_steps, int64_t act_stride);
 void launch_reset_init(const Dev &d, hipStream_t st, const uint8_t *mask, int use_done, int gate, int all_envs, float *obs_out);
 void launch_forget_ring_slots(const Dev &d, hipStream_t st);
 

@@ -4,6 +4,10 @@
 #include "pcc_retire_env.h"
 #include "pcc_kernels.h"
 
+#ifndef PCC_RETIRE_OCC2
+#define PCC_RETIRE_OCC2 3  // ... of the two-sender builds (156 registers, no scratch; at 4 they spill 128 B/lane: config 5 retire 0.147 -> 0.132 ms)
+#endif
+
 namespace {
 
 // Order: with work lists (read_buf >= 0) the launch walks the classes the send half of this step
@@ -18,13 +22,17 @@ namespace {
 constexpr int kRetireMaxPerBlock = kRetireBlock / 8;  // envs of a workgroup at 8 lanes per env
 
 template <int NS, bool NOISE>
-__global__ __launch_bounds__(kRetireBlock, PCC_RETIRE_OCC) void retire_kernel(Dev D, int read_buf, int fill_buf, int warm,
+__global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIRE_OCC) void retire_kernel(Dev D, int read_buf, int fill_buf, int warm,
                                                               uint32_t warm_mi, int last_warm, int gate, int restart, float *obs_out,
                                                               float *reward_out, uint8_t *done_out, double *steps_out,
                                                               const void *actions, int actions_f64) {
     if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != D.step_seq) return;
     __shared__ uint32_t s_env[kRetireMaxPerBlock], s_cls[kRetireMaxPerBlock], s_arrived;
     const uint32_t tid = threadIdx.x;
+    if (prof_on(D) && !warm) {  // profile build: the send items' timeline slots are cleared for the next send launch
+        const int64_t slot = (int64_t)blockIdx.x * kRetireBlock + tid;
+        if (slot < 2 * D.n) D.timeline[slot * 8] = 0;
+    }
     const uint32_t lane = tid & (kWave - 1);
     if (tid == 0) s_arrived = 0u;
     if (tid < (uint32_t)kRetireMaxPerBlock) s_env[tid] = 0xFFFFFFFFu;

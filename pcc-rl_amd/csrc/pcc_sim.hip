@@ -738,7 +738,7 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
     const Dev &d = sim->d;
     if (d.n < (int64_t)sim->list_min_envs && !d.engine) {
         // a small batch: both halves in one launch (step_small_kernel)
-        launch_step_small(d, d.rng_mode == PCC_RNG_TRACE, st, actions, actions_f64, obs_out, reward_out, done_out, steps_out);
+        launch_step_small(d, d.rng_mode == PCC_RNG_TRACE, st, actions, actions_f64, obs_out, reward_out, done_out, steps_out, 1, 0);
         const int rc0 = check_hip(hipGetLastError(), "step kernel launch");
         if (rc0 != PCC_OK) return rc0;
         return after_mi(sim, obs_out, auto_reset, st);
@@ -750,7 +750,7 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
 }
 
 int pcc_step_many(pcc_sim_t *sim, const void *actions, int actions_f64, int n_steps, float *obs_out, float *reward_out,
-                  uint8_t *done_out, int auto_reset, void *stream) {
+                  uint8_t *done_out, double *steps_out, int auto_reset, void *stream) {
     if (!sim || !actions || n_steps < 1) return fail(PCC_EINVAL, "NULL argument or n_steps < 1");
     // (what pcc_step would refuse is refused before the first step: after that only a failing launch can stop the loop)
     if (!sim->ever_reset) return fail(PCC_ESTATE, "pcc_step_many before pcc_reset (the reference raises TypeError: run_dur is None)");
@@ -758,10 +758,39 @@ int pcc_step_many(pcc_sim_t *sim, const void *actions, int actions_f64, int n_st
     const Dev &d = sim->d;
     const size_t row = (size_t)d.n * d.ns;
     const size_t act_row = row * (d.use_cwnd ? 2u : 1u) * (actions_f64 ? sizeof(double) : sizeof(float));
-    for (int t = 0; t < n_steps; t++) {
-        const int rc = pcc_step(sim, static_cast<const char *>(actions) + (size_t)t * act_row, actions_f64,
-                                obs_out ? obs_out + (size_t)t * row * d.HF : nullptr, reward_out ? reward_out + (size_t)t * row : nullptr,
-                                done_out ? done_out + (size_t)t * d.n : nullptr, nullptr, auto_reset, stream);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto obs_at = [&](int t) { return obs_out ? obs_out + (size_t)t * row * d.HF : nullptr; };
+    int t = 0;
+    if (d.n < (int64_t)sim->list_min_envs && !d.engine && (sim->lockstep || !auto_reset)) {
+        // a small batch whose episode boundaries the host knows (or that is never reset here): the steps up to the next
+        // boundary are ONE launch -- the loop over them runs inside step_small_kernel, a workgroup per 64 envs
+        DeviceGuard guard(sim->device);
+        while (t < n_steps) {
+            int seg = n_steps - t;
+            if (sim->lockstep && auto_reset) {
+                const int left = (int)d.max_steps - (int)sim->host_steps;
+                if (seg > (left > 1 ? left : 1)) seg = left > 1 ? left : 1;
+            }
+            next_step_seq(sim, st);
+            launch_step_small(d, d.rng_mode == PCC_RNG_TRACE, st, static_cast<const char *>(actions) + (size_t)t * act_row, actions_f64,
+                              obs_at(t), reward_out ? reward_out + (size_t)t * row : nullptr, done_out ? done_out + (size_t)t * d.n : nullptr,
+                              steps_out ? steps_out + (size_t)t * row * PCC_STEP_COLS : nullptr, seg, (int64_t)act_row);
+            int rc = check_hip(hipGetLastError(), "step kernel launch");
+            sim->host_steps += (uint32_t)(seg - 1);
+            if (rc == PCC_OK) rc = after_mi(sim, obs_at(t + seg - 1), auto_reset, st);  // (the boundary's reset writes that step's observation row)
+            if (rc != PCC_OK) {
+                char why[400];
+                snprintf(why, sizeof why, "%s", g_err);
+                return fail(rc, "pcc_step_many stopped after %d of %d steps: %s", t, n_steps, why);
+            }
+            t += seg;
+        }
+        return PCC_OK;
+    }
+    for (; t < n_steps; t++) {
+        const int rc = pcc_step(sim, static_cast<const char *>(actions) + (size_t)t * act_row, actions_f64, obs_at(t),
+                                reward_out ? reward_out + (size_t)t * row : nullptr, done_out ? done_out + (size_t)t * d.n : nullptr,
+                                steps_out ? steps_out + (size_t)t * row * PCC_STEP_COLS : nullptr, auto_reset, stream);
         if (rc != PCC_OK) {  // a launch failed: say how far the batch got (its clocks have advanced that many steps)
             char why[400];
             snprintf(why, sizeof why, "%s", g_err);

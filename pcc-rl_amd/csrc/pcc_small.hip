@@ -5,8 +5,8 @@
 #include "pcc_kernels.h"
 
 #ifndef PCC_SMALL_OCC
-#define PCC_SMALL_OCC 3  // workgroups (4 wavefronts) per compute unit the register budget is cut for: the kernel is a chain of
-                         // dependent round trips of one workgroup per 64 envs, not an occupancy problem
+#define PCC_SMALL_OCC 2  // wavefronts per SIMD the register budget is cut for: the kernel is a chain of dependent round trips of
+                         // one workgroup per 64 envs (at most 128 workgroups on 256 compute units), not an occupancy problem
 #endif
 
 namespace {
@@ -18,31 +18,46 @@ namespace {
 // half needs only its own send half.  At 4 096 envs of two packets a step is launch overhead and dependent loads, and
 // one launch instead of two is a third of it (config 2: 34 -> about 24 us per step).
 // ======================================================================================
+// n_steps > 1 (pcc_step_many): the workgroup runs that many steps of its 64 envs back to back inside the launch -- step t
+// reads actions + t * act_stride bytes and writes the t-th row of every output -- with a workgroup barrier between the
+// halves of a step and between steps: nothing of an env is ever touched by another workgroup, so no launch boundary is
+// needed, and at 4 096 envs of two packets a launch boundary (~8 us) is a third of a step.
 template <int NS, bool TRACE>
 __global__ __launch_bounds__(4 * kWave, PCC_SMALL_OCC) void step_small_kernel(Dev D, const void *actions, int actions_f64, float *obs_out,
-                                                                           float *reward_out, uint8_t *done_out, double *steps_out) {
+                                                                           float *reward_out, uint8_t *done_out, double *steps_out,
+                                                                           int n_steps, int64_t act_stride) {
     const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t base = (int64_t)blockIdx.x * kWave;
     __shared__ EnvSlot<NS> s_slots[kSlots];
-    if (wv == 0) {
-        const int64_t i = base + lane;
-        const bool has = i < D.n;
-        uint32_t pk = 0;
-        const uint64_t left = send_light_item<NS, TRACE>(D, lane, has ? i : 0, has, blockIdx.x, 0, 0, actions, actions_f64, pk);
-        if (left) {  // the last lanes of the rounds go on by the wave path, from the state the item stored (pcc_send_item.h)
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            (void)send_wave_item<NS, TRACE, 1>(D, lane, has ? i : 0, ((left >> lane) & 1ull) != 0ull, false, 0xFFFFFFFFu, 0, 0, actions, actions_f64, s_slots);
-        }
-    }
-    __syncthreads();  // the records and the state the first wavefront wrote are read by all four (same CU: workgroup scope)
+    const int64_t row = D.n * NS;
 #pragma unroll 1
-    for (uint32_t r = 0; r < 2u; r++) {
-        const int64_t i = base + (int64_t)((wv * 2u + r) * 8u + lane / 8u);
-        Group g;
-        g.lane = lane & 7u;
-        g.shift = lane & ~7u;
-        if (i < D.n)
-            (void)retire_env<NS, false, 8>(D, i, g, 0, 0, 0, 0, obs_out, reward_out, done_out, steps_out, nullptr, 0);
+    for (int t = 0; t < n_steps; t++) {
+        const void *act_t = static_cast<const char *>(actions) + (int64_t)t * act_stride;
+        if (wv == 0) {
+            const int64_t i = base + lane;
+            const bool has = i < D.n;
+            uint32_t pk = 0;
+            const uint64_t left = send_light_item<NS, TRACE>(D, lane, has ? i : 0, has, blockIdx.x, 0, 0, act_t, actions_f64, pk);
+            if (left) {  // the last lanes of the rounds go on by the wave path, from the state the item stored (pcc_send_item.h)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                (void)send_wave_item<NS, TRACE, 1>(D, lane, has ? i : 0, ((left >> lane) & 1ull) != 0ull, false, 0xFFFFFFFFu, 0, 0, act_t, actions_f64, s_slots);
+            }
+        }
+        __syncthreads();  // the records and the state the first wavefront wrote are read by all four (same CU: workgroup scope)
+        float *obs_t = obs_out ? obs_out + (int64_t)t * row * D.HF : nullptr;
+        float *rew_t = reward_out ? reward_out + (int64_t)t * row : nullptr;
+        uint8_t *done_t = done_out ? done_out + (int64_t)t * D.n : nullptr;
+        double *steps_t = steps_out ? steps_out + (int64_t)t * row * PCC_STEP_COLS : nullptr;
+#pragma unroll 1
+        for (uint32_t r = 0; r < 2u; r++) {
+            const int64_t i = base + (int64_t)((wv * 2u + r) * 8u + lane / 8u);
+            Group g;
+            g.lane = lane & 7u;
+            g.shift = lane & ~7u;
+            if (i < D.n)
+                (void)retire_env<NS, false, 8>(D, i, g, 0, 0, 0, 0, obs_t, rew_t, done_t, steps_t, nullptr, 0);
+        }
+        if (t + 1 < n_steps) __syncthreads();  // the next step's send half reads what this retire half wrote
     }
 }
 
@@ -92,9 +107,10 @@ __global__ void forget_ring_slots_kernel(Dev D) {
 namespace pcc {
 
 void launch_step_small(const Dev &d, bool trace, hipStream_t st, const void *actions, int actions_f64, float *obs_out,
-                       float *reward_out, uint8_t *done_out, double *steps_out) {
+                       float *reward_out, uint8_t *done_out, double *steps_out, int n_steps, int64_t act_stride) {
     const dim3 grid((unsigned)((d.n + kWave - 1) / kWave)), block(4 * kWave);
-#define PCC_S(NS_, TR_) hipLaunchKernelGGL((step_small_kernel<NS_, TR_>), grid, block, 0, st, d, actions, actions_f64, obs_out, reward_out, done_out, steps_out)
+#define PCC_S(NS_, TR_) \
+    hipLaunchKernelGGL((step_small_kernel<NS_, TR_>), grid, block, 0, st, d, actions, actions_f64, obs_out, reward_out, done_out, steps_out, n_steps, act_stride)
     if (d.ns == 1) { if (trace) PCC_S(1, true); else PCC_S(1, false); }
     else { if (trace) PCC_S(2, true); else PCC_S(2, false); }
 #undef PCC_S

@@ -270,11 +270,13 @@ class BatchedNetworkEnv(object):
                                _ptr(done_out), _ptr(self._steps), 1 if self.auto_reset else 0, self._stream()))
         self._t += 1
 
-    def step_many(self, actions, obs_out=None, reward_out=None, done_out=None):
-        """T steps with pre-computed actions in ONE library call (pcc_step_many: the loop over the steps runs in C):
-        actions [T, N(, S)(, 2)]; the optional outputs [T, N, S, H*F] / [T, N, S] / [T, N] (contiguous, on the env's
-        device) take every step's observation, reward and done row.  For open-loop drivers of small batches, where one
-        step is shorter than a trip around a Python loop."""
+    def step_many(self, actions, obs_out=None, reward_out=None, done_out=None, steps_out=None):
+        """T steps with pre-computed actions in ONE library call (pcc_step_many): actions [T, N(, S)(, 2)]; the optional outputs
+        [T, N, S, H*F] / [T, N, S] / [T, N] / [T, N, S, 19] float64 (contiguous, on the env's device) take every step's
+        observation, reward, done row and full-precision step record (``record_steps`` does not apply here: pass steps_out).
+        For open-loop drivers of small batches: below ``list_min_envs`` envs, in lockstep, the steps up to the next episode
+        boundary run inside one launch.  If the call fails part-way the error says after how many steps; the env's step
+        counter is not advanced then (reset before going on)."""
         a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions), device=self.device)
         if a.device != self.device:
             a = a.to(self.device)
@@ -287,11 +289,11 @@ class BatchedNetworkEnv(object):
         a = a.reshape(T, self.n_envs * width).contiguous()
         N, S, D = self.n_envs, self.n_senders, self.obs_dim
         for t, n, dt in ((obs_out, T * N * S * D, (torch.float32,)), (reward_out, T * N * S, (torch.float32,)),
-                         (done_out, T * N, (torch.uint8, torch.bool))):
+                         (done_out, T * N, (torch.uint8, torch.bool)), (steps_out, T * N * S * native.PCC_STEP_COLS, (torch.float64,))):
             if t is not None and (t.numel() != n or t.dtype not in dt or not t.is_contiguous() or t.device != self.device):
                 raise ValueError("step_many: an output tensor has the wrong size, dtype, layout or device")
         check(self._L.pcc_step_many(self._h, _ptr(a), 1 if a.dtype == torch.float64 else 0, T, _ptr(obs_out), _ptr(reward_out),
-                                    _ptr(done_out), 1 if self.auto_reset else 0, self._stream()))
+                                    _ptr(done_out), _ptr(steps_out), 1 if self.auto_reset else 0, self._stream()))
         self._t += T
 
     # ------------------------------------------------------------------ introspection

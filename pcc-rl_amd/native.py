@@ -85,7 +85,7 @@ def lib():
     L.pcc_set_max_steps.argtypes = [vp, i32]
     L.pcc_reset.argtypes = [vp, vp, vp, vp]
     L.pcc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
-    L.pcc_step_many.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, vp]
+    L.pcc_step_many.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp]
     L.pcc_step_send.argtypes = [vp, vp, i32, vp]
     L.pcc_step_retire.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     L.pcc_get_state.argtypes = [vp, i32, vp, vp]

@@ -1126,16 +1126,18 @@ def test_step_many_equals_single_steps(n_envs, lists):
         pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = None
     T, seed = 50, 17
     acts = torch.as_tensor(np.random.RandomState(seed).uniform(-1, 1.5, (T, n_envs)), dtype=torch.float32, device=DEV)
-    one = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, max_steps=20)
+    one = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, max_steps=20, record_steps=True)
     many = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, max_steps=20)
     assert torch.equal(one.reset(), many.reset())
     obs = torch.empty((T, n_envs, one.obs_dim), device=DEV)
     rew = torch.empty((T, n_envs), device=DEV)
     done = torch.empty((T, n_envs), dtype=torch.uint8, device=DEV)
-    many.step_many(acts, obs, rew, done)
+    rows = torch.empty((T, n_envs, 1, 19), dtype=torch.float64, device=DEV)
+    many.step_many(acts, obs, rew, done, rows)
     for t in range(T):
-        o, r, d, _ = one.step(acts[t])
+        o, r, d, info = one.step(acts[t])
         assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(d, done[t].view(torch.bool)), t
+        assert torch.equal(info["steps"], rows[t, :, 0]), t
     assert int(done.sum().item()) == 2 * n_envs
     one.check_flags(); many.check_flags()
     assert torch.equal(one.state("now"), many.state("now"))

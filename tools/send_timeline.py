@@ -17,23 +17,23 @@ import torch
 import pcc_rl_amd
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda:0")
-env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
+env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, n_senders=S)
 for k, v in os.environ.items():
     if k.startswith("PCC_TUNE_"):
         env.set_tuning(**{k[9:].lower(): float(v)})
 gen = torch.Generator(device=dev).manual_seed(1234)
-acts = torch.rand((64, N), generator=gen, device=dev) * 2 - 1
+acts = torch.rand((400, N, S), generator=gen, device=dev) * 2 - 1   # one action vector per episode step, like bench.py
 env.reset()
 out = []
 sample = {2, 10, 30, 60, 100, 150, 200, 250, 300, 350, 398}
 for t in range(400):
-    env.step_send(acts[t % 64])
+    env.step_send(acts[t])
     if t in sample:
         raw = env.debug_timeline().astype(np.int64)
-        n_items = int(env.debug_pass_stats(reset=False)["items"])
-        tl = raw[:n_items]
-        tl = tl[tl[:, 0] > 0]
+        tl = raw[:2 * N]             # item slots: light items from 0, wave-path items from N, team items behind them
+        tl = tl[tl[:, 0] > 0]        # (the retire launch clears the slots: what is there belongs to this send launch)
         t0 = tl[:, 0].min()
         start, mid, fin = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0   # us
         heavy_wave = np.arange(len(tl))  # placeholder, the heavy wavefronts are the ones with 0 round time and w[3] > 0
