@@ -126,12 +126,14 @@ const char *pcc_last_error(void);
  *                   records with k <= 3 chosen so that this is >= 256, i.e. 512 + 1024 by
  *                   default) and is moved -- at the start of a monitor interval whose packets
  *                   could overflow them -- into rings 4x, 16x, ... as large taken from shared
- *                   pools that by default hold 1/2, 1/8, 1/32 of the senders at once
- *                   (pcc_set_ring_pools changes the divisors; 1 = worst case).  An empty pool is flagged (PCC_FLAG_POOL_EXHAUSTED), never
- *                   silent.  Pool rings are held until the env is reset.  The tiers are about
- *                   memory, not speed (a pointer-chase microbenchmark shows TLB reach is not what
- *                   bounds these kernels): 65 536 envs take 6.4 GB instead of 103 GB.
- *                   pcc_device_bytes reports the total.
+ *                   pools.  Pool rings are held until the env is reset, so a pool with a slot for
+ *                   every sender can never run dry; by default the pools get what a third of the
+ *                   device memory that is free at creation pays for (65 536 senders on an idle
+ *                   288 GB MI355X: a slot for every sender in tiers 1 and 2 and for every second one
+ *                   in tier 3, 83 GB), never less than slots for 1/2, 1/8, 1/32 of the senders
+ *                   (6.4 GB at 65 536: what U(-1, 1) policies need; pcc_set_ring_pools sets the
+ *                   divisors explicitly, 1 = a slot for every sender).  An empty pool is flagged
+ *                   (PCC_FLAG_POOL_EXHAUSTED), never silent.  pcc_device_bytes reports the total.
  *   device_id       HIP device ordinal (-1 = current device).
  * No env is usable before pcc_reset.
  */
@@ -198,7 +200,10 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_SPLIT_STREAMS = 20 /* measurements: 1 = the light and the wave-path workgroups of the send half as two kernels on two
                                     streams of the handle instead of one launch (default 0: slower, see pcc_send_bodies.h) */,
        PCC_TUNE_LIGHT_FRONT_WGS = 21 /* send launch: light workgroups (4 items each, the longest) dispatched in front of the
-                                    wave-path workgroups; default 8 */ };
+                                    wave-path workgroups; default 8 */,
+       PCC_TUNE_RETIRE_GRID_FRAC = 22 /* retire launch: the grid is n / 16 workgroups plus this share of as many again (for envs of
+                                    the 16-lane classes, 8 per workgroup); workgroups loop when there are more.  Default 0.125;
+                                    1 = the worst case (twice n / 16: the dispatch of ~8 200 workgroups alone takes 0.1 ms) */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* Sizes of the shared ring pools (see pcc_create): tiers 1, 2, 3 get a slot for one sender in div1, div2, div3 (defaults

@@ -30,8 +30,8 @@ __global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIR
     __shared__ uint32_t s_env[kRetireMaxPerBlock], s_cls[kRetireMaxPerBlock], s_arrived;
     const uint32_t tid = threadIdx.x;
     if (prof_on(D) && !warm) {  // profile build: the send items' timeline slots are cleared for the next send launch
-        const int64_t slot = (int64_t)blockIdx.x * kRetireBlock + tid;
-        if (slot < 2 * D.n) D.timeline[slot * 8] = 0;
+        for (int64_t slot = (int64_t)blockIdx.x * kRetireBlock + tid; slot < 2 * D.n; slot += (int64_t)gridDim.x * kRetireBlock)
+            D.timeline[slot * 8] = 0;
     }
     const uint32_t lane = tid & (kWave - 1);
     if (tid == 0) s_arrived = 0u;
@@ -51,7 +51,16 @@ __global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIR
         }
         const uint32_t total = rl_u32(incl, kClasses);
         const int cls_wide = NOISE ? kClasses : (D.retire_wide_predict >= 1e9f ? kClasses : class_of(D.retire_wide_predict));
-        const uint32_t n_top = cls_wide < kClasses ? rl_u32(incl, (uint32_t)(kClasses - 1 - cls_wide)) : 0u;  // envs of the wide classes
+        uint32_t n_top = cls_wide < kClasses ? rl_u32(incl, (uint32_t)(kClasses - 1 - cls_wide)) : 0u;  // envs of the wide classes
+        // The host sizes the grid for the usual share of wide envs, not for the worst case (twice n / 16 workgroups: the
+        // command processor dispatches ~80 workgroups per microsecond, and 8 193 of them, half of them finding nothing to do,
+        // ARE the 0.1 ms this launch took in round 3).  Should more envs sit in the wide classes than the grid has room for,
+        // the smallest of them go 8 lanes like everybody else: lanes per env is a speed choice, every result is the same.
+        {
+            const uint32_t narrow_all = (total + 15u) / 16u;   // workgroups if nobody were wide
+            const uint32_t spare = gridDim.x > narrow_all + 1u ? gridDim.x - narrow_all - 1u : 0u;   // each takes 16 wide envs' extra share
+            if (n_top > 16u * spare) n_top = 16u * spare;
+        }
         const uint32_t wg_wide = (n_top + 7u) / 8u;  // workgroups that take them, 8 each
         wide = blockIdx.x < wg_wide;
         uint32_t p;  // this lane's position in the walk (the same for the lanes of a group)

@@ -147,7 +147,14 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
     // ---- wave-path items: the first one dealt statically to the workgroups without team items, the rest claimed
     const uint32_t n_static = (G - n_tw) * 4u;
     uint32_t t = 0xFFFFFFFFu;
-    if (b_wg >= n_tw) t = (D.wave_oldest_first ? b_wg - n_tw : G - 1u - b_wg) * 4u + wv;
+    if (b_wg >= n_tw) {
+        // workgroup b' of the Gs without team items, wavefront wv: rank wv * Gs + b' -- a workgroup's four items (and the items
+        // of the workgroups that share its compute unit, b' + 256, ...) are spread over the ranking, so every compute unit gets
+        // about the same number of packets; wave_oldest_first = 0 deals a workgroup four consecutive ranks instead (the largest
+        // items of every third of the ranking then meet on the same compute units: measured slower, r04_experiments.json)
+        const uint32_t Gs = G - n_tw, bs = b_wg - n_tw;
+        t = D.wave_oldest_first ? wv * Gs + bs : bs * 4u + wv;
+    }
     uint32_t *cursors = D.cursors + (uint32_t)read_buf * kShards * kCursorStride;
     const uint32_t s_mine = wave % kShards;
     for (;;) {

@@ -63,6 +63,7 @@ struct pcc_sim {
     hipStream_t aux_wave, aux_restart;
     hipEvent_t ev_fork, ev_wave, ev_restart;
     int split_streams;      // measurements: 1 = the light and the wave-path workgroups as two kernels on two streams
+    double retire_grid_frac;  // tuning: share of the envs the retire grid expects in the wide classes (see launch_retire_half)
     unsigned light_front_wgs; // tuning: light workgroups dispatched in front of the wave-path workgroups (the longest light items)
     uint32_t step_seq;      // sequence number of the last step (Dev::step_seq of its launches)
     hipStream_t last_stream; // the stream of the last pcc_reset / pcc_step (what pcc_set_tuning's flush is queued on)
@@ -181,8 +182,12 @@ int launch_retire_half(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm
     // (class counts), so the grid covers the worst case plus the one workgroup the split can leave partly filled
     const bool lists = d.n >= (int64_t)sim->list_min_envs;
     const int read = (warm || !d.retire_sorted || !lists) ? -1 : sim->read_buf;  // the lists this step's send launch read
-    const int64_t per_block = read >= 0 ? 8 : kRetireEnvsPerBlockNarrow;
-    const unsigned grid = (unsigned)((d.n + per_block - 1) / per_block + (read >= 0 ? 1 : 0));
+    // With lists the walk is n / 16 workgroups plus one more for every 16 envs of the wide classes (8 per workgroup there): the
+    // grid is sized for retire_grid_frac of the envs being wide (default 1/8: about 3 % are) and the workgroups loop if there
+    // are more -- the worst case, twice n / 16, is ~8 200 workgroups for 65 536 envs, which the command processor needs
+    // 0.1 ms to dispatch even when half of them find nothing to do
+    const int64_t narrow = (d.n + kRetireEnvsPerBlockNarrow - 1) / kRetireEnvsPerBlockNarrow;
+    const unsigned grid = (unsigned)(read >= 0 ? narrow + (int64_t)(sim->retire_grid_frac * (double)narrow) + 1 : narrow);
     const int fill = (warm || !lists) ? -1 : sim->fill_buf;
     launch_retire(d, false, grid, st, read, fill, warm, warm_mi, last_warm, gate, restart, obs_out, reward_out, done_out, steps_out,
                   nullptr, 0);
@@ -360,10 +365,31 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         return fail(PCC_ENOMEM, "hipMalloc(%zu) for env state failed", want);
     }
     carve_state(d, static_cast<char *>(sim->state_blob));
-    // pool sizes: by default 1/2, 1/8, 1/32 of the senders can sit in tiers 1, 2, 3 at the same
-    // time (measured need at the ICML'19 ranges with U(-1, 1) actions: ~25 %, ~2 %, ~0.02 %); pcc_set_ring_pools changes
-    // the divisors (1 = every sender could, the worst case -- what a rate-maximising policy may need)
-    const unsigned div[kMaxTiers] = {1, 2, 8, 32};
+    // Pool sizes.  A sender keeps the slots it was promoted into until its env is reset, so the pools of tiers 1, 2, 3 can
+    // never run dry when each has a slot for every sender (divisor 1) -- and a policy that climbs towards the rate limit on
+    // every link (what PPO learns on generous links) does need most of that.  An MI355X has 288 GB: the pools get what a
+    // third of the memory that is free right now pays for, the largest tier halved first (round 3 sized them for U(-1, 1)
+    // policies -- divisors 2, 8, 32, measured need ~25 %, ~2 %, ~0.02 % of the senders -- and a saturating policy ended a
+    // training run with PCC_FLAG_POOL_EXHAUSTED); those divisors are the floor.  pcc_set_ring_pools overrides.
+    unsigned div[kMaxTiers] = {1, 1, 1, 1};
+    {
+        const unsigned floor_div[kMaxTiers] = {1, 2, 8, 32};
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const double budget = 0.33 * (double)free_b;
+        const double senders = (double)n_envs * n_senders;
+        auto tier_bytes = [&](int c) { return senders / div[c] * 3.0 * (double)((size_t)d.cap0 << (2 * c)) * sizeof(double2); };
+        for (;;) {
+            double total = 0.0;
+            int big = -1;
+            for (int c = 1; c < d.n_tiers; c++) {
+                total += tier_bytes(c);
+                if (div[c] < floor_div[c] && (big < 0 || tier_bytes(c) > tier_bytes(big))) big = c;
+            }
+            if (total <= budget || big < 0) break;
+            div[big] *= 2;
+        }
+    }
     sim->ring_bytes = 0;
     for (int c = 0; c < d.n_tiers; c++) {
         const int rc = alloc_tier(sim, c, div[c]);
@@ -400,6 +426,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     sim->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     sim->split_streams = 0;
     sim->light_front_wgs = 8;
+    sim->retire_grid_frac = 0.125;
     if (hipStreamCreateWithFlags(&sim->aux_wave, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&sim->aux_restart, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&sim->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -545,6 +572,10 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
         case PCC_TUNE_PRIO_LIGHT_ITEMS: sim->d.prio_light_items = value >= 4e9 ? 0xFFFFFFFFu : (uint32_t)(value < 0.0 ? 0.0 : value); return PCC_OK;
         case PCC_TUNE_PRIO_WAVE_ITEMS: sim->d.prio_wave_items = value >= 4e9 ? 0xFFFFFFFFu : (uint32_t)(value < 0.0 ? 0.0 : value); return PCC_OK;
         case PCC_TUNE_PRIO_TEAM: sim->d.prio_team = value != 0.0 ? 1u : 0u; return PCC_OK;
+        case PCC_TUNE_RETIRE_GRID_FRAC:
+            if (!(value >= 0.0 && value <= 1.0)) return fail(PCC_EINVAL, "retire_grid_frac must be in [0, 1]");
+            sim->retire_grid_frac = value;
+            return PCC_OK;
         case PCC_TUNE_LIGHT_FRONT_WGS:
             if (!(value >= 0.0 && value <= 65536.0)) return fail(PCC_EINVAL, "light_front_wgs out of range");
             sim->light_front_wgs = (unsigned)value;

@@ -89,8 +89,9 @@ class BatchedNetworkEnv(object):
         self._h = handle
         self._L = L
         if ring_pools is not None:
-            # (div1, div2, div3): tier k of the in-flight ring pools holds a slot for one sender in div_k (defaults 2, 8, 32
-            # fit U(-1, 1) policies; a policy that saturates every link wants smaller divisors -- PCC_FLAG_POOL_EXHAUSTED says so)
+            # (div1, div2, div3): tier k of the in-flight ring pools holds a slot for one sender in div_k.  By default the
+            # library sizes the pools from the free device memory (a slot for every sender where a third of it pays for that,
+            # never less than divisors 2, 8, 32): a policy that saturates every link cannot run them dry
             check(L.pcc_set_ring_pools(self._h, *[int(v) for v in ring_pools]))
         if self.DEFAULT_LIST_MIN_ENVS is not None:
             check(L.pcc_set_tuning(self._h, 12, float(self.DEFAULT_LIST_MIN_ENVS)))
@@ -181,12 +182,12 @@ class BatchedNetworkEnv(object):
     def set_tuning(self, round_packets=None, takeover_lanes=None, send_envs_per_wave=None, heavy_predict=None,
                    send_waves=None, team_predict=None, heavy_item_packets=None, retire_wide_predict=None, list_min_envs=None,
                    retire_sorted=None, light_snake=None, wave_oldest_first=None, prio_level=None, prio_light_items=None,
-                   prio_wave_items=None, prio_team=None, split_streams=None, light_front_wgs=None):
+                   prio_wave_items=None, prio_team=None, split_streams=None, light_front_wgs=None, retire_grid_frac=None):
         """Performance knobs (results do not depend on them); see pcc_set_tuning in include/pcc_sim.h."""
         for key, value in ((2, round_packets), (3, takeover_lanes), (4, send_envs_per_wave), (5, heavy_predict),
                            (8, send_waves), (9, team_predict), (10, heavy_item_packets), (11, retire_wide_predict), (12, list_min_envs),
                            (13, retire_sorted), (14, light_snake), (15, wave_oldest_first), (16, prio_level), (17, prio_light_items),
-                           (18, prio_wave_items), (19, prio_team), (20, split_streams), (21, light_front_wgs)):
+                           (18, prio_wave_items), (19, prio_team), (20, split_streams), (21, light_front_wgs), (22, retire_grid_frac)):
             if value is not None:
                 check(self._L.pcc_set_tuning(self._h, key, float(value)))
 

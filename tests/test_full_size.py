@@ -189,3 +189,32 @@ def test_staggered_phases_every_env_every_step_matches_the_oracle(n_senders):
                 break
         assert not problems, "\n".join(p for p in problems if p)
     env.close()
+
+
+def test_saturating_policy_at_full_size_with_default_pools():
+    """65 536 envs driven towards the rate limit (U(0, 2) actions, like the reference-generated saturating_0_2 goldens) for a
+    whole episode with the DEFAULT ring pools: no env may be flagged -- a policy that learns to fill its links must not end a
+    training run with PCC_FLAG_POOL_EXHAUSTED (round 3's pools were sized for U(-1, 1) policies and did) -- and the first 512
+    envs are compared with the oracle, every step.  ns:235-241, 275-281 (the rate climbs to MAX_RATE and stays there)."""
+    n, steps = _size(65536)
+    M = min(512, n)
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=2, record_steps=True, auto_reset=False)
+    env.reset()
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    rows, acts = [], []
+    for t in range(steps):
+        a = torch.rand((n,), generator=gen, device=DEV, dtype=torch.float32) * 2
+        o, r, d, info = env.step(a)
+        rows.append(info["steps"][:M].clone())
+        acts.append(a[:M].clone())
+    torch.cuda.synchronize()
+    flags = env.state("flags").cpu().numpy()
+    assert not flags.any(), "flagged envs: %d (pool exhausted: %d, ring overflow: %d)" % (
+        int((flags != 0).sum()), int(((flags & pcc_rl_amd.native.PCC_FLAG_POOL_EXHAUSTED) != 0).sum()),
+        int(((flags & pcc_rl_amd.native.PCC_FLAG_RING_OVERFLOW) != 0).sum()))
+    tiers = env.state("ring_tier").cpu().numpy()
+    ref = oracle.run_batch(torch.stack(acts, 1).to(torch.float64).cpu().numpy(), rng_mode=oracle.RNG_PHILOX, seed=2, want_obs=False)
+    problem = _first_mismatch(torch.stack(rows, 1).cpu().numpy(), ref["steps"], "saturating policy, first %d envs" % M)
+    assert not problem, problem
+    print("saturating policy: senders by ring tier", [int((tiers == c).sum()) for c in range(4)], "device GB", env.device_bytes / 1e9)
+    env.close()
