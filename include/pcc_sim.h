@@ -184,8 +184,9 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_HEAVY_ITEM_PACKETS = 10 /* a wave-path work item holds as many envs of one class (1..8) as make up about this
                                     many predicted packets; default 2048, 0 = one env per item */,
        PCC_TUNE_RETIRE_WIDE_PREDICT = 11 /* retire half: an env predicted above this many packets per interval is retired by
-                                    16 lanes (whole-list and half sums side by side), the others by 8; default 1024,
-                                    0 = every env by 16, >= 1e9 = every env by 8 */,
+                                    16 lanes (whole-list and half sums side by side), the others by 8; default 256 --
+                                    but never more envs than the launch's grid has room for (RETIRE_GRID_FRAC: the largest);
+                                    0 = as many by 16 as fit, >= 1e9 = every env by 8 */,
        PCC_TUNE_LIST_MIN_ENVS = 12 /* batches of fewer envs are stepped without work lists, the envs in index order (a small
                                     batch's step is a chain of dependent loads, and the lists add three); default 8192,
                                     0 = always with lists */,
@@ -200,7 +201,7 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_SPLIT_STREAMS = 20 /* measurements: 1 = the light and the wave-path workgroups of the send half as two kernels on two
                                     streams of the handle instead of one launch (default 0: slower, see pcc_send_bodies.h) */,
        PCC_TUNE_LIGHT_FRONT_WGS = 21 /* send launch: light workgroups (4 items each, the longest) dispatched in front of the
-                                    wave-path workgroups; default 8 */,
+                                    wave-path workgroups; default 0 */,
        PCC_TUNE_RETIRE_GRID_FRAC = 22 /* retire launch: the grid is n / 16 workgroups plus this share of as many again (for envs of
                                     the 16-lane classes, 8 per workgroup); workgroups loop when there are more.  Default 0.125;
                                     1 = the worst case (twice n / 16: the dispatch of ~8 200 workgroups alone takes 0.1 ms) */ };

@@ -348,7 +348,9 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.heavy_predict = n_senders == 2 ? 1024.0 : 512.0;
     d.team_predict = 4096.0;
     d.heavy_item_packets = 2048.0f;
-    d.retire_wide_predict = 1024.0f;
+    // (the wide classes are cut by COUNT in the end: the grid has room for retire_grid_frac of the envs at 16 lanes, the
+    // largest; measured on one handle, r04_experiments.json: threshold 1024 -> 0.097 ms, 200-512 with the cut -> 0.091)
+    d.retire_wide_predict = 256.0f;
     d.retire_sorted = 1u;
     d.light_snake = 1u;
     d.wave_oldest_first = 1u;
@@ -425,7 +427,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     sim->list_min_envs = 8192;
     sim->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     sim->split_streams = 0;
-    sim->light_front_wgs = 8;
+    sim->light_front_wgs = 0;   // (measured on one handle: 0 -> 0.1076 ms, 8 -> 0.1107, 64 -> 0.1112)
     sim->retire_grid_frac = 0.125;
     if (hipStreamCreateWithFlags(&sim->aux_wave, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&sim->aux_restart, hipStreamNonBlocking) != hipSuccess ||
