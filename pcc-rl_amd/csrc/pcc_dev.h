@@ -97,7 +97,7 @@ struct alignas(128) EnvBlk {
     double lr, maxq;  //  16
     double ebw;       //  32
     uint32_t episode;
-    uint32_t pad_c;
+    uint32_t fill_seq;  // (a shadow block) sequence number of the step whose refill prepared it: usable three steps later
     double q, tu;     //  48  link queue: send half, and the retire half's MI-ending event
     double now, run_dur;            //  64  retire half
     unsigned long long total_sent;  //  80  retire half
@@ -175,8 +175,17 @@ struct Dev {
     const double *trace;
     int64_t trace_stride;
     const double *p_bw, *p_dl, *p_queue, *p_loss, *p_rate0;
-    EnvBlk *env;  // [N] link + env state, one 128-byte block per env
-    SndBlk *snd;  // [S][N] per sender, one 128-byte block each
+    // State blocks.  Index i < N is env i; index N + i is its SHADOW: the next episode of env i, prepared ahead of time
+    // (new links, the two warm-up intervals) by the refill kernel while the env is still running, and swapped in by the
+    // retire half the moment the env finishes -- out of lockstep a restart is then no chain of dependent passes in the
+    // step's critical path (pcc_send_restart.hip).  stride = 2 N.
+    EnvBlk *env;  // [2N] link + env state, one 128-byte block per env
+    SndBlk *snd;  // [S][2N] per sender, one 128-byte block each
+    int64_t stride;       // 2 N: sender s of block i is snd[s * stride + i]
+    char *shadow_rings;   // [N][S] private rings of the shadows, tier-1 size each (the warm-up intervals' packets in flight)
+    uint32_t *refill_count;  // [4][kCntStride] envs whose shadow was swapped in (or invalidated) at step seq: row seq & 3
+    uint32_t *refill_list;   // [4][N]
+    int shadows;          // the retire half may swap shadows in (Philox uniforms, envs out of lockstep, lists on)
     // the reference's dormant USE_CWND engine option (ns:54)
     int use_cwnd;
     // the reference's dormant USE_LATENCY_NOISE engine option (ns:51-52): packets overtake each other, so the in-flight
@@ -321,7 +330,15 @@ struct RingRef {
     __device__ __forceinline__ uint32_t dmask() const { return 2u * cap - 1u; }
 };
 
-__device__ __forceinline__ uint32_t tier_cap(const Dev &D, uint32_t tier) { return D.cap0 << (2u * tier); }
+// ring_tier of a sender whose rings are still its (former) shadow's private ones: the next send half moves the records
+// in flight into the sender's own storage (load_env), after which the shadow can be refilled
+constexpr uint32_t kTierBorrowed = 0xFEu;
+constexpr uint32_t kShadowTier = 1u;  // a shadow's private rings have the size of tier 1
+
+__device__ __forceinline__ int64_t sidx(const Dev &D, int s, int64_t i) { return (int64_t)s * D.stride + i; }
+__device__ __forceinline__ int64_t env_of(const Dev &D, int64_t i) { return i >= D.n ? i - D.n : i; }  // block index -> env id
+
+__device__ __forceinline__ uint32_t tier_cap(const Dev &D, uint32_t tier) { return D.cap0 << (2u * (tier == kTierBorrowed ? kShadowTier : tier)); }
 __device__ __forceinline__ size_t tier_slot_bytes(const Dev &D, uint32_t tier) { return (size_t)3 * tier_cap(D, tier) * sizeof(double2); }
 
 __device__ __forceinline__ RingRef ring_ref(const Dev &D, int64_t k /* s * n + i */) {
@@ -389,11 +406,13 @@ __device__ __forceinline__ void copy_records(double2 *dst, uint32_t dmask, const
 // the address of index j changes.  The slot the sender leaves stays reserved for it until its env
 // is reset (pops happen only in send launches, pushes only in reset launches: no stack races).
 // Returns false (and flags the env) when every pool from `want` up is empty.
+// want == 0 (only for a sender on borrowed rings, see kTierBorrowed): into the sender's own tier-0 rings at `own0`.
 __device__ __forceinline__ bool promote_rings(const Dev &D, uint32_t lane, uint32_t l, int64_t k, uint32_t want,
-                                              uint32_t ha, uint32_t ta, uint32_t hd, uint32_t td) {
+                                              uint32_t ha, uint32_t ta, uint32_t hd, uint32_t td, char *own0 = nullptr) {
     uint32_t got = 0xFFFFFFFFu, slot = 0;
     if (lane == l) {
-        for (uint32_t c = want; c < (uint32_t)D.n_tiers; c++) {
+        if (want == 0u) got = 0u;
+        for (uint32_t c = want; got == 0xFFFFFFFFu && c < (uint32_t)D.n_tiers; c++) {
             const int32_t old = atomicSub(&D.tier_top[c], 1);
             if (old > 0) { slot = D.tier_free[c][old - 1]; got = c; break; }
             atomicAdd(&D.tier_top[c], 1);
@@ -407,13 +426,14 @@ __device__ __forceinline__ bool promote_rings(const Dev &D, uint32_t lane, uint3
     RingRef to;
     to.cap = tier_cap(D, got);
     to.base = D.tier_base[got < kMaxTiers ? got : 0] + (size_t)slot * tier_slot_bytes(D, got);
+    if (got == 0u) to.base = reinterpret_cast<char *>(rl_u64(reinterpret_cast<uint64_t>(own0), l));  // (back into the sender's own tier-0 rings)
     const uint32_t h_a = rl_u32(ha, l), n_a = rl_u32(ta, l) - h_a, h_d = rl_u32(hd, l), n_d = rl_u32(td, l) - h_d;
     copy_records(to.accepted(), to.mask(), from.accepted(), from.mask(), h_a, n_a, lane);
     copy_records(to.dropped(), to.dmask(), from.dropped(), from.dmask(), h_d, n_d, lane);
     if (lane == l) {
         D.snd[k].ring_base = to.base;
         D.snd[k].ring_tier = (uint8_t)got;
-        D.snd[k].ring_held[got] = slot + 1u;
+        if (got) D.snd[k].ring_held[got] = slot + 1u;
     }
     return true;
 }

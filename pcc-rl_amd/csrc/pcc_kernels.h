@@ -17,6 +17,8 @@ void launch_send_light(const Dev &d, bool trace, unsigned grid, hipStream_t st, 
 void launch_send_wave(const Dev &d, bool trace, unsigned grid, hipStream_t st, int read_buf, const void *actions, int actions_f64);
 // pcc_send_restart.hip.  grid: workgroups of 4 wavefronts, restart items dealt statically.
 void launch_send_restart(const Dev &d, bool trace, unsigned grid, hipStream_t st, int read_buf, const void *actions, int actions_f64);
+// ... refill_kernel: the shadows of the envs in refill row `row` (their next episodes: new links + warm-up intervals)
+void launch_refill(const Dev &d, unsigned grid, hipStream_t st, uint32_t row, uint32_t fill_seq);
 // pcc_retire.hip
 void launch_retire(const Dev &d, bool noise, unsigned grid, hipStream_t st, int read_buf, int fill_buf, int warm, uint32_t warm_mi,
                    int last_warm, int gate, int restart, float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out,

@@ -669,8 +669,8 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
     o.flags = 0;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + i;
-        hn[s] = D.snd[k].heap_n;
+        const int64_t k = (int64_t)s * D.n + i;   // (the event heaps are [S][N]; the sender blocks [S][2N]: sidx)
+        hn[s] = D.snd[sidx(D, s, i)].heap_n;
         H[s] = D.noise_heap + (size_t)k * D.noise_cap;
         R[s] = D.noise_rtt + (size_t)k * D.noise_cap;
         nsend[s] = nsend0[s];
@@ -684,7 +684,7 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
             return D.trace[i * D.trace_stride + pos];
         }
         ep_draws++;
-        return philox_packet_uniform(D, D.gid_base + (uint32_t)i, episode, mi, mi_draws++);
+        return philox_packet_uniform(D, D.gid_base + (uint32_t)env_of(D, i), episode, mi, mi_draws++);
     };
     auto noisy = [&](double ll) -> double {  // ns:150-151, 171-172
         if (D.use_noise) ll *= 1.0 + D.noise_span * draw();
@@ -754,7 +754,7 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
     }
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        D.snd[(int64_t)s * D.n + i].heap_n = hn[s];
+        D.snd[sidx(D, s, i)].heap_n = hn[s];
         o.nsend[s] = nsend[s];
     }
     D.env[i].ep_draws = ep_draws;
@@ -771,7 +771,7 @@ template <int NS>
 __device__ __forceinline__ void release_ring_slots(const Dev &D, const int64_t i, const bool push = true) {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + i;
+        const int64_t k = sidx(D, s, i);
         for (int c = 1; c < D.n_tiers; c++) {
             const uint32_t held = D.snd[k].ring_held[c];
             if (held) {
@@ -791,13 +791,14 @@ __device__ __forceinline__ void reset_env(const Dev &D, const int64_t i, float *
     D.env[i].episode = episode + 1;
 
     double bw, lat, queue, loss, rate0[NS];
+    const int64_t ie = env_of(D, i);   // (block i may be the shadow of env ie: the same links, keyed by the env's id)
     if (D.p_bw) {
-        bw = D.p_bw[i]; lat = D.p_dl[i]; queue = D.p_queue[i]; loss = D.p_loss[i];
+        bw = D.p_bw[ie]; lat = D.p_dl[ie]; queue = D.p_queue[ie]; loss = D.p_loss[ie];
 #pragma unroll
-        for (int s = 0; s < NS; s++) rate0[s] = D.p_rate0[(int64_t)s * D.n + i];
+        for (int s = 0; s < NS; s++) rate0[s] = D.p_rate0[(int64_t)s * D.n + ie];
     } else {  // ns:455-466
         uint32_t w0[4], w1[4];
-        const uint32_t gid = D.gid_base + (uint32_t)i;
+        const uint32_t gid = D.gid_base + (uint32_t)ie;
         philox4x32_10(0u, kParamTag, episode, gid, D.key0, D.key1, w0);
         philox4x32_10(1u, kParamTag, episode, gid, D.key0, D.key1, w1);
         bw = D.lo[0] + (D.hi[0] - D.lo[0]) * u32_to_unit(w0[0]);
@@ -830,7 +831,7 @@ __device__ __forceinline__ void reset_env(const Dev &D, const int64_t i, float *
     D.env[i].mi_draws = 0; D.env[i].ep_draws = 0;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + i;
+        const int64_t k = sidx(D, s, i);
         D.snd[k].rate = rate0[s];
         D.snd[k].rate0 = rate0[s];
         D.snd[k].next_send = 1.0 / rate0[s];  // ns:111
@@ -841,9 +842,10 @@ __device__ __forceinline__ void reset_env(const Dev &D, const int64_t i, float *
         D.snd[k].ack_rate = 0.f; D.snd[k].loss_rate = 0.f; D.snd[k].on_return_a = 0; D.snd[k].on_return_d = 0;
         D.snd[k].ep_return = 0.0;
         // all-empty history (so:57-62): every metric of an empty MI is 0 except the two ratios
-        float *hist = D.hist + ((int64_t)i * NS + s) * D.HF;
-        float *obs = obs_out ? obs_out + ((int64_t)i * NS + s) * D.HF : nullptr;
-        for (int h = 0; h < D.H; h++)
+        // (a shadow has no history row: the retire half writes the empty history when it swaps the shadow in)
+        float *hist = D.hist + ((int64_t)ie * NS + s) * D.HF;
+        float *obs = obs_out ? obs_out + ((int64_t)ie * NS + s) * D.HF : nullptr;
+        for (int h = 0; i < D.n && h < D.H; h++)
             for (int f = 0; f < D.F; f++) {
                 const int id = D.fid[f];
                 const double v = (id == PCC_M_SEND_RATIO || id == PCC_M_LATENCY_RATIO) ? 1.0 : 0.0;
@@ -888,7 +890,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
     uint32_t amask[NS], dmasks[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + i;
+        const int64_t k = sidx(D, s, i);
         nsend[s] = D.snd[k].next_send;
         ha[s] = D.snd[k].ha; hd[s] = D.snd[k].hd; ta[s] = D.snd[k].ta; td[s] = D.snd[k].td;
         sent[s] = D.snd[k].mi_sent;
@@ -910,7 +912,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         uint32_t cw[NS];
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            const int64_t k = (int64_t)s * D.n + i;
+            const int64_t k = sidx(D, s, i);
             rate[s] = D.snd[k].rate;
             cw[s] = D.use_cwnd ? D.snd[k].cwnd : 0xFFFFFFFFu;
             if (!warm) {
@@ -939,7 +941,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         if (lead) {
             o = event_engine<NS>(D, i, start, end, rate, nsend, warm ? warm_mi : steps + 2, cw);
 #pragma unroll
-            for (int s = 0; s < NS; s++) D.snd[(int64_t)s * D.n + i].rate = rate[s];
+            for (int s = 0; s < NS; s++) D.snd[sidx(D, s, i)].rate = rate[s];
             D.env[i].q = o.q; D.env[i].tu = o.tu;
         }
         // the RTT samples the lead lane stored are read by all lanes of the group below: same wavefront, same L1 -- a
@@ -970,7 +972,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             const double adds[4] = {dl, 0.0, dl, 0.0};
             Bound bnd[4];
             // where the boundaries would be if this interval retired what the last one did (per second of simulated time)
-            const int64_t k_s = (int64_t)s * D.n + i;
+            const int64_t k_s = sidx(D, s, i);
             const float span = (float)run_dur;
             const uint32_t h_pa = ha[s] + (uint32_t)(D.snd[k_s].ack_rate * span), h_pd = hd[s] + (uint32_t)(D.snd[k_s].loss_rate * span);
             const uint32_t hints[4] = {h_pa, h_pa + D.snd[k_s].on_return_a, h_pd, h_pd + D.snd[k_s].on_return_d};
@@ -1071,7 +1073,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
 #pragma unroll
                     for (int x = 0; x < NS; x++) j += sent[x];
                     if (D.use_cwnd) j = D.env[i].mi_draws;  // draws, not packets: blocked SENDs drew too
-                    u = philox_packet_uniform(D, D.gid_base + (uint32_t)i, D.env[i].episode - 1,
+                    u = philox_packet_uniform(D, D.gid_base + (uint32_t)env_of(D, i), D.env[i].episode - 1,
                                               warm ? warm_mi : steps + 2, j);
                 }
                 if (D.use_cwnd && D.rng_mode == PCC_RNG_TRACE) {
@@ -1081,9 +1083,9 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                 }
                 // USE_CWND (ns:251-255): everything due before this event is retired, so what is in
                 // flight is exactly what the rings still hold
-                const bool can_send = !D.use_cwnd || (ta[s] - ha[s]) + (td[s] - hd[s]) < D.snd[(int64_t)s * D.n + i].cwnd;
+                const bool can_send = !D.use_cwnd || (ta[s] - ha[s]) + (td[s] - hd[s]) < D.snd[sidx(D, s, i)].cwnd;
                 if (D.use_cwnd && lead) D.env[i].ep_draws += 1u;
-                const double rate = D.snd[(int64_t)s * D.n + i].rate;
+                const double rate = D.snd[sidx(D, s, i)].rate;
                 sent[s] += can_send ? 1u : 0u;
                 nsend[s] = t + 1.0 / rate;
                 bool dropped;
@@ -1115,7 +1117,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         if (flags) D.env[i].flags |= flags;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            const int64_t k = (int64_t)s * D.n + i;
+            const int64_t k = sidx(D, s, i);
             D.snd[k].ha = ha[s]; D.snd[k].hd = hd[s]; D.snd[k].ta = ta[s]; D.snd[k].td = td[s];  // one 16-byte store
         }
     }
@@ -1124,7 +1126,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             D.env[i].now = now;
             D.env[i].total_sent = total_before + sent_total;
 #pragma unroll
-            for (int s = 0; s < NS; s++) D.snd[(int64_t)s * D.n + i].next_send = nsend[s];
+            for (int s = 0; s < NS; s++) D.snd[sidx(D, s, i)].next_send = nsend[s];
             if (last_warm) D.env[i].resetting = 0;
         }
         return -1.0f;
@@ -1142,7 +1144,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
     double new_run_dur = run_dur, rate_sum = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + i;
+        const int64_t k = sidx(D, s, i);
         double lat = 0.0, inc = 0.0;
         PCC_TL_STAMP(7)  // state write-back
         if (acked[s] > 0 && !prof_skip(D, 1))
@@ -1211,11 +1213,11 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                 float v = (x - keep) < G ? nf0 : nf1;
                 if (x < keep) v = old_row[b];
                 if (x < D.HF && !prof_skip(D, 2)) {
-                    hist[x] = v;
-                    if (restarts) {
+                    if (restarts) {  // (the next episode's history starts empty -- whether its state is swapped in below or set up later)
                         const int id = D.fid[x % D.F];
                         v = (float)(((id == PCC_M_SEND_RATIO || id == PCC_M_LATENCY_RATIO) ? 1.0 : 0.0) / c_metric_scale[id]);
                     }
+                    hist[x] = v;
                     if (obs) obs[x] = v;
                 }
             }
@@ -1225,11 +1227,11 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                 float v = (x - keep) < G ? nf0 : nf1;
                 if (x < keep) v = hist[x + D.F];
                 if (x < D.HF) {
-                    hist[x] = v;
                     if (restarts) {
                         const int id = D.fid[x % D.F];
                         v = (float)(((id == PCC_M_SEND_RATIO || id == PCC_M_LATENCY_RATIO) ? 1.0 : 0.0) / c_metric_scale[id]);
                     }
+                    hist[x] = v;
                     if (obs) obs[x] = v;
                 }
             }
@@ -1270,15 +1272,55 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         if (done_out) done_out[i] = done;
     }
     if (restart && steps + 1 >= D.max_steps) {
-        // auto-reset of envs that are not in lockstep, without extra launches: the env is marked and filed in the restart
-        // list, and the send launch of the next step gives it new links (ns:469-477) and runs the two warm-up
-        // intervals (ns:478-479) right before its first interval -- nothing in between reads any of that (the first
-        // observation of an episode is the empty history, written above)
+        // auto-reset of envs that are not in lockstep, without extra launches.
+        // (1) The env's SHADOW (block N + i) holds its next episode, prepared ahead of time by the refill kernel -- new links
+        // (ns:469-477) and the two warm-up intervals (ns:478-479) already run: it is swapped in here, the env is filed like
+        // every other by the packets its first interval will send, and the next send launch treats it like every other
+        // (its rings are still the shadow's: load_env moves the records in flight into the env's own storage).
+        // (2) No valid shadow (restart without bit 1; a masked reset overtook the refill; the warm-up intervals did not fit
+        // the shadow's rings): the env is marked and filed in the restart list, and the next send half gives it new links
+        // and runs the warm-up intervals right before its first interval (pcc_send_restart.hip) -- nothing in between reads
+        // any of that (the first observation of an episode is the empty history, written above).
+        float filed = -2.0f;
         if (lead) {
-            D.env[i].resetting = 2;
             release_ring_slots<NS>(D, i);  // here, not in the send launch: see release_ring_slots
+            const int64_t sh = D.n + i;
+            // (a shadow is trusted three steps after the launch that prepared it was queued: the caller's stream has waited
+            // for that launch by then -- pcc_sim.hip -- so every line of it is what the refill wrote)
+            const bool ok = (restart & 2) != 0 && D.env[sh].resetting == 0 && D.env[sh].episode == D.env[i].episode + 1u &&
+                            D.step_seq - D.env[sh].fill_seq >= 3u;
+            if (ok) {
+                D.env[i].bw = D.env[sh].bw; D.env[i].dl = D.env[sh].dl; D.env[i].lr = D.env[sh].lr; D.env[i].maxq = D.env[sh].maxq;
+                D.env[i].ebw = D.env[sh].ebw; D.env[i].episode = D.env[sh].episode;
+                D.env[i].q = D.env[sh].q; D.env[i].tu = D.env[sh].tu; D.env[i].now = D.env[sh].now; D.env[i].run_dur = D.env[sh].run_dur;
+                D.env[i].total_sent = total_before + sent_total + D.env[sh].total_sent;
+                D.env[i].steps = 0; D.env[i].done = 0; D.env[i].resetting = 0;
+                D.env[i].mi_draws = D.env[sh].mi_draws; D.env[i].ep_draws = D.env[sh].ep_draws;
+                if (D.env[sh].flags) D.env[i].flags |= D.env[sh].flags;
+                double rates = 0.0;
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const int64_t kp = sidx(D, s, i), ks = sidx(D, s, sh);
+                    D.snd[kp].rate = D.snd[ks].rate; D.snd[kp].rate0 = D.snd[ks].rate0;
+                    D.snd[kp].next_send = D.snd[ks].next_send; D.snd[kp].min_lat = D.snd[ks].min_lat;
+                    D.snd[kp].ep_return = 0.0;
+                    D.snd[kp].ring_base = D.snd[ks].ring_base; D.snd[kp].ring_tier = (uint8_t)kTierBorrowed;
+                    D.snd[kp].ha = D.snd[ks].ha; D.snd[kp].hd = D.snd[ks].hd; D.snd[kp].ta = D.snd[ks].ta; D.snd[kp].td = D.snd[ks].td;
+                    D.snd[kp].mi_sent = D.snd[ks].mi_sent; D.snd[kp].cwnd = D.snd[ks].cwnd; D.snd[kp].heap_n = D.snd[ks].heap_n;
+                    D.snd[kp].ack_rate = D.snd[ks].ack_rate; D.snd[kp].loss_rate = D.snd[ks].loss_rate;
+                    D.snd[kp].on_return_a = D.snd[ks].on_return_a; D.snd[kp].on_return_d = D.snd[ks].on_return_d;
+                    rates += D.snd[ks].rate;
+                }
+                filed = (float)(D.env[sh].run_dur * rates);   // (the class of the new episode's first interval)
+                D.env[sh].resetting = 2;                       // consumed: the refill kernel prepares the episode after this one
+                const uint32_t row = D.step_seq & 3u;
+                const uint32_t at = atomicAdd(&D.refill_count[row * kCntStride], 1u);
+                D.refill_list[(size_t)row * (size_t)D.n + at] = (uint32_t)i;
+            } else {
+                D.env[i].resetting = 2;
+            }
         }
-        return -2.0f;
+        return __shfl(filed, 0, G);
     }
     PCC_TL_STAMP(11)  // outputs
     if (tl) atomicMax(reinterpret_cast<unsigned long long *>(&tlw[1]), (unsigned long long)tl_t);

@@ -31,10 +31,12 @@ struct LaneEnv {
 // fresh: the interval starts here (the action is applied, nothing of it is sent); otherwise the lane rounds of a light item
 // have sent part of it and stored the state (send_light_item's stragglers).
 // W > 1: every wavefront of the team loads the same env and computes alike; wavefront 0 stores.
+// no_promote (the refill of a shadow, pcc_send_restart.hip): the rings are what they are -- an interval that could overflow
+// them is not sent at all (E.run = false) and flagged PCC_FLAG_INTERNAL in E.flags for the caller to see (never stored).
 template <int NS, bool TRACE, int W>
 __device__ __forceinline__ LaneEnv<NS> load_env(const Dev &D, const uint32_t lane, const int64_t i, const bool in_range,
                                                 const bool fresh, const int warm, const uint32_t warm_mi, const void *actions,
-                                                const int actions_f64, const uint32_t wv) {
+                                                const int actions_f64, const uint32_t wv, const bool no_promote = false) {
     LaneEnv<NS> E;
     const bool writer = W == 1 || wv == 0u;
     E.live = in_range && !(warm && !D.env[in_range ? i : 0].resetting);
@@ -45,11 +47,11 @@ __device__ __forceinline__ LaneEnv<NS> load_env(const Dev &D, const uint32_t lan
     E.end = now + D.env[ii].run_dur;  // ns:124
     E.episode = D.env[ii].episode - 1;
     E.mi = warm ? warm_mi : D.env[ii].steps + 2;
-    E.gid = D.gid_base + (uint32_t)ii;
+    E.gid = D.gid_base + (uint32_t)env_of(D, ii);
     E.flags = 0;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + ii;
+        const int64_t k = sidx(D, s, ii);
         double rate = D.snd[k].rate;
         const bool act = fresh && !warm && E.live;
         if (act) {
@@ -79,21 +81,32 @@ __device__ __forceinline__ LaneEnv<NS> load_env(const Dev &D, const uint32_t lan
     // that could overflow are moved to a bigger tier now, by the whole wavefront
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-        const int64_t k = (int64_t)s * D.n + ii;
+        const int64_t k = sidx(D, s, ii);
         if (fresh) {
             uint32_t want = 0;
-            if (E.run) {
+            const uint32_t tier_now = (uint32_t)D.snd[k].ring_tier;
+            // (a sender whose episode was just swapped in still sits on its former shadow's rings: it moves into storage of its
+            // own now, whatever the interval needs, so that the shadow can be refilled)
+            const bool borrowed = E.live && tier_now == kTierBorrowed;
+            if (E.run || borrowed) {
                 const double ahead = E.nsend[s] < E.end ? (E.end - E.nsend[s]) / E.gap[s] + 4.0 : 1.0;
                 const uint32_t n_max = ahead < 1e9 ? (uint32_t)ahead : 1000000000u;
                 want = tier_for(D, E.ta[s] - E.ha[s] + n_max, E.td[s] - E.hd[s] + n_max);
+                if (borrowed && want >= (uint32_t)D.n_tiers) want = (uint32_t)D.n_tiers - 1u;  // (it has to move; an overflow is flagged later)
             }
-            uint64_t pm = __ballot(E.run && want > (uint32_t)D.snd[k].ring_tier && want < (uint32_t)D.n_tiers);
-            while (pm && writer) {
-                const uint32_t l = (uint32_t)__ffsll((unsigned long long)pm) - 1u;
-                pm &= pm - 1ull;
-                if (!promote_rings(D, lane, l, k, want, E.ha[s], E.ta[s], E.hd[s], E.td[s]) && lane == l) E.flags |= PCC_FLAG_POOL_EXHAUSTED;
+            if (no_promote) {
+                if (E.run && want > tier_now) { E.run = false; E.flags |= PCC_FLAG_INTERNAL; }
+            } else {
+                uint64_t pm = __ballot((borrowed && want < (uint32_t)D.n_tiers) ||
+                                       (E.run && tier_now != kTierBorrowed && want > tier_now && want < (uint32_t)D.n_tiers));
+                char *own0 = D.tier_base[0] + (size_t)(env_of(D, ii) * NS + s) * tier_slot_bytes(D, 0);
+                while (pm && writer) {
+                    const uint32_t l = (uint32_t)__ffsll((unsigned long long)pm) - 1u;
+                    pm &= pm - 1ull;
+                    if (!promote_rings(D, lane, l, k, want, E.ha[s], E.ta[s], E.hd[s], E.td[s], own0) && lane == l) E.flags |= PCC_FLAG_POOL_EXHAUSTED;
+                }
+                if constexpr (W > 1) __syncthreads();  // the other wavefronts of a team read the address wavefront 0 just stored
             }
-            if constexpr (W > 1) __syncthreads();  // the other wavefronts of a team read the address wavefront 0 just stored
         }
         E.rings[s] = ring_ref(D, k);
     }
@@ -110,7 +123,7 @@ __device__ __forceinline__ void store_env(const Dev &D, const int64_t i, LaneEnv
     for (int s = 0; s < NS; s++) {
         // never silent: more packets in flight than a ring holds means records were overwritten
         if (E.ta[s] - E.ha[s] > E.rings[s].cap || E.td[s] - E.hd[s] > 2u * E.rings[s].cap) E.flags |= PCC_FLAG_RING_OVERFLOW;
-        const int64_t k = (int64_t)s * D.n + i;
+        const int64_t k = sidx(D, s, i);
         D.snd[k].next_send = E.nsend[s];
         D.snd[k].ta = E.ta[s]; D.snd[k].td = E.td[s];
         D.snd[k].mi_sent = E.sent[s];
@@ -431,7 +444,8 @@ template <int NS, bool TRACE, int W>
 __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t lane, const int64_t i, const bool in_range,
                                                    const bool fresh, const uint32_t tl_slot, const int warm, const uint32_t warm_mi,
                                                    const void *actions, const int actions_f64, EnvSlot<NS> *slots,
-                                                   const uint32_t wv = 0, TeamX *X = nullptr) {
+                                                   const uint32_t wv = 0, TeamX *X = nullptr, const bool no_promote = false,
+                                                   bool *refused = nullptr) {
     static_assert(W == 1 || NS == 1, "team items are built for one sender");
     const bool writer = W == 1 || wv == 0u;
     const uint64_t tl0 = prof_on(D) ? wall_clock64() : 0;
@@ -446,7 +460,11 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
         todo &= ~chunk;
         const uint32_t n_chunk = (uint32_t)__popcll(chunk);
         {
-            LaneEnv<NS> E = load_env<NS, TRACE, W>(D, lane, i, mine, fresh, warm, warm_mi, actions, actions_f64, wv);
+            LaneEnv<NS> E = load_env<NS, TRACE, W>(D, lane, i, mine, fresh, warm, warm_mi, actions, actions_f64, wv, no_promote);
+            if (refused) {  // (no_promote: an interval the rings cannot hold was not sent; the flag is the caller's, not the env's)
+                *refused = __ballot(mine && (E.flags & PCC_FLAG_INTERNAL)) != 0ull;
+                E.flags &= ~(uint32_t)PCC_FLAG_INTERNAL;
+            }
             if (mine) {
                 EnvSlot<NS> &S = slots[rank];
                 S.dl = E.dl; S.lr = E.lr; S.maxq = E.maxq; S.ebw = E.ebw; S.q = E.q; S.tu = E.tu; S.end = E.end;
@@ -525,7 +543,7 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
                     // never silent: more packets in flight than a ring holds means records were overwritten
                     const uint32_t cap = S.cap[s];
                     if (ta_new[s] - S.ha[s] > cap || td_new[s] - S.hd[s] > 2u * cap) flags |= PCC_FLAG_RING_OVERFLOW;
-                    const int64_t ks = (int64_t)s * D.n + ie;
+                    const int64_t ks = sidx(D, s, ie);
                     D.snd[ks].next_send = nsend_new[s];
                     D.snd[ks].ta = ta_new[s]; D.snd[ks].td = td_new[s];
                     D.snd[ks].mi_sent = sent_new[s];

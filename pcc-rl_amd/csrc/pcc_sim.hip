@@ -66,6 +66,10 @@ struct pcc_sim {
     double retire_grid_frac;  // tuning: share of the envs the retire grid expects in the wide classes (see launch_retire_half)
     unsigned light_front_wgs; // tuning: light workgroups dispatched in front of the wave-path workgroups (the longest light items)
     uint32_t step_seq;      // sequence number of the last step (Dev::step_seq of its launches)
+    void *shadow_blob;      // the shadows' private rings (allocated when envs first restart out of lockstep)
+    size_t shadow_bytes;
+    hipEvent_t ev_ret, ev_refill[4];
+    bool refill_recorded[4];
     hipStream_t last_stream; // the stream of the last pcc_reset / pcc_step (what pcc_set_tuning's flush is queued on)
 };
 
@@ -98,8 +102,11 @@ struct Carver {
 size_t carve_state(Dev &d, char *base) {
     Carver c(base);
     const size_t n = (size_t)d.n, sn = n * d.ns;
-    d.env = c.take<EnvBlk>(n);
-    d.snd = c.take<SndBlk>(sn);
+    d.env = c.take<EnvBlk>(2 * n);        // (env blocks and their shadows: pcc_dev.h)
+    d.snd = c.take<SndBlk>(2 * sn);
+    d.stride = (int64_t)(2 * n);
+    d.refill_count = c.take<uint32_t>(4 * kCntStride);
+    d.refill_list = c.take<uint32_t>(4 * n);
     d.cls_count = c.take<uint32_t>(2 * kClsStride);
     d.cursors = c.take<uint32_t>(3 * 16 * 32);
     d.any_done = c.take<uint32_t>(1);
@@ -154,6 +161,12 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
         (void)hipEventRecord(sim->ev_wave, sim->aux_wave);
         launch_send_light(d, tr, light_grid, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
         (void)hipStreamWaitEvent(st, sim->ev_wave, 0);
+    } else if (rs && d.shadows) {
+        // with shadows nearly every restart is a swap inside the retire half: the restart list holds only the envs whose shadow
+        // was not usable (a masked reset overtook it; links whose warm-up intervals overflow a shadow's rings) -- nearly always
+        // nobody: the kernel follows the main launch on the caller's stream, no fork, no join
+        pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+        launch_send_restart(d, tr, restart_grid, st, read_buf, actions, actions_f64);
     } else if (rs) {
         // The restart items are a chain of dependent passes (reset, two warm-up intervals, the first interval): longer than
         // the whole main launch.  So the MAIN launch goes to the side stream and the restart kernel stays on the caller's:
@@ -237,6 +250,23 @@ int launch_reset(pcc_sim_t *sim, const uint8_t *mask, int use_done, int gate, fl
 // option (no send half) -- those keep the gated reset launches after the step.
 bool restarts_in_step(const pcc_sim_t *sim, int auto_reset) {
     return auto_reset && !sim->lockstep && !sim->d.use_cwnd && !sim->d.engine && sim->d.n >= (int64_t)sim->list_min_envs;
+}
+
+// Shadows (the next episode of an env prepared ahead of time, swapped in when it finishes: pcc_dev.h, pcc_send_restart.hip)
+// need uniforms that do not depend on the order of events across episodes (Philox, not a replayed trace) and their private
+// rings (tier-1 size per sender: allocated the first time envs restart out of lockstep -- 6.4 GB for 65 536 senders).
+bool use_shadows(pcc_sim_t *sim) {
+    Dev &d = sim->d;
+    if (d.rng_mode != PCC_RNG_PHILOX) { d.shadows = 0; return false; }
+    if (!sim->shadow_blob) {
+        const size_t bytes = (size_t)d.n * d.ns * 3 * ((size_t)d.cap0 << (2 * kShadowTier)) * sizeof(double2);
+        if (d.n_tiers < 2 || hipMalloc(&sim->shadow_blob, bytes) != hipSuccess) { sim->shadow_blob = nullptr; d.shadows = 0; return false; }
+        (void)hipMemset(sim->shadow_blob, 0, bytes);   // (first use of fresh device memory is slow: not in somebody's step)
+        sim->shadow_bytes = bytes;
+        d.shadow_rings = static_cast<char *>(sim->shadow_blob);
+    }
+    d.shadows = 1;
+    return true;
 }
 
 // What is still owed to the envs of the restart list -- new links, fresh state, the two warm-up intervals -- is
@@ -433,7 +463,12 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         hipStreamCreateWithFlags(&sim->aux_restart, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&sim->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sim->ev_wave, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sim->ev_restart, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&sim->ev_restart, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sim->ev_ret, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sim->ev_refill[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sim->ev_refill[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sim->ev_refill[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sim->ev_refill[3], hipEventDisableTiming) != hipSuccess) {
         pcc_destroy(sim);
         return fail(PCC_EHIP, "creating the side streams of the send half failed");
     }
@@ -480,6 +515,10 @@ void pcc_destroy(pcc_sim_t *sim) {
     if (sim->ev_fork) (void)hipEventDestroy(sim->ev_fork);
     if (sim->ev_wave) (void)hipEventDestroy(sim->ev_wave);
     if (sim->ev_restart) (void)hipEventDestroy(sim->ev_restart);
+    if (sim->ev_ret) (void)hipEventDestroy(sim->ev_ret);
+    for (int k = 0; k < 4; k++)
+        if (sim->ev_refill[k]) (void)hipEventDestroy(sim->ev_refill[k]);
+    if (sim->shadow_blob) (void)hipFree(sim->shadow_blob);
     if (sim->timeline_blob) (void)hipFree(sim->timeline_blob);
     if (sim->list_blob) (void)hipFree(sim->list_blob);
     if (sim->noise_blob) (void)hipFree(sim->noise_blob);
@@ -492,7 +531,9 @@ void pcc_destroy(pcc_sim_t *sim) {
     delete sim;
 }
 
-int64_t pcc_device_bytes(const pcc_sim_t *sim) { return sim ? (int64_t)(sim->state_bytes + sim->ring_bytes + sim->list_bytes + sim->noise_bytes) : 0; }
+int64_t pcc_device_bytes(const pcc_sim_t *sim) {
+    return sim ? (int64_t)(sim->state_bytes + sim->ring_bytes + sim->list_bytes + sim->noise_bytes + sim->shadow_bytes) : 0;
+}
 
 int pcc_set_link_params(pcc_sim_t *sim, const double *bw, const double *dl, const double *queue, const double *loss,
                         const double *rate0) {
@@ -690,7 +731,16 @@ int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream)
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     DeviceGuard guard(sim->device);
     sim->last_stream = static_cast<hipStream_t>(stream);
-    if (!mask) sim->restarts_pending = false;  // everything starts over
+    if (!mask) {
+        sim->restarts_pending = false;  // everything starts over
+        // ... the shadows too: whatever refill is still in flight finishes first, the rows are emptied, nothing is trusted
+        for (int k = 0; k < 4; k++) {
+            if (sim->refill_recorded[k]) (void)hipStreamWaitEvent(static_cast<hipStream_t>(stream), sim->ev_refill[k], 0);
+            sim->refill_recorded[k] = false;
+        }
+        (void)hipMemsetAsync(sim->d.refill_count, 0, 4 * kCntStride * sizeof(uint32_t), static_cast<hipStream_t>(stream));
+        sim->d.shadows = 0;
+    }
     int rc = flush_restarts(sim, static_cast<hipStream_t>(stream));
     if (rc == PCC_OK) rc = launch_reset(sim, mask, 0, 0, obs_out, static_cast<hipStream_t>(stream));
     if (rc != PCC_OK) return rc;
@@ -710,9 +760,35 @@ namespace {
 // every step has its sequence number (never 0): an env that finishes its episode leaves it in Dev::any_done, and the gated
 // auto-reset launches of the same step look for it
 void next_step_seq(pcc_sim_t *sim, hipStream_t st) {
-    if (++sim->step_seq == 0u) sim->step_seq = 1u;
+    if (++sim->step_seq == 0u) sim->step_seq = 4u;   // (never 0; a multiple of 4 keeps the refill rows' rotation)
     sim->d.step_seq = sim->step_seq;
     sim->last_stream = st;
+    // shadows prepared by the refill launch queued three steps ago may be swapped in from this step on (retire_env trusts a
+    // shadow three steps after its fill_seq): the caller's stream waits for that launch -- it finished long ago
+    const uint32_t row = (sim->step_seq - 3u) & 3u;
+    if (sim->d.shadows && sim->refill_recorded[row]) (void)hipStreamWaitEvent(st, sim->ev_refill[row], 0);
+}
+
+// 0: finished envs are reset by the gated launches after the step (or the host knows the boundary: lockstep); 1: inside the
+// step's own launches, through the restart list; 3: ... and by swapping in their shadows where those are ready
+int restart_mode(pcc_sim_t *sim, int auto_reset) {
+    if (!restarts_in_step(sim, auto_reset)) { sim->d.shadows = 0; return 0; }
+    return use_shadows(sim) ? 3 : 1;
+}
+
+// Behind the retire launch of step seq: the refill of the shadows that were emptied (or invalidated) at step seq - 1 -- the
+// envs they belong to have moved off the shadows' rings in this step's send half -- on the side stream, never joined into this
+// step or the next.
+void queue_refill(pcc_sim_t *sim, hipStream_t st) {
+    const Dev &d = sim->d;
+    const uint32_t seq = sim->step_seq - 1u, row = seq & 3u;
+    if (hipEventRecord(sim->ev_ret, st) != hipSuccess) return;
+    (void)hipStreamWaitEvent(sim->aux_restart, sim->ev_ret, 0);
+    const unsigned grid = (unsigned)(sim->cu_count < (d.n + 3) / 4 ? sim->cu_count : (d.n + 3) / 4);
+    launch_refill(d, grid, sim->aux_restart, row, seq);
+    (void)hipMemsetAsync(d.refill_count + row * kCntStride, 0, sizeof(uint32_t), sim->aux_restart);
+    (void)hipEventRecord(sim->ev_refill[row], sim->aux_restart);
+    sim->refill_recorded[row] = true;
 }
 
 // host bookkeeping after the MI of a step: episode boundary, auto-reset (ns:444, the gym wrapper's reset)
@@ -753,9 +829,10 @@ int pcc_step_retire(pcc_sim_t *sim, float *obs_out, float *reward_out, uint8_t *
     if (!sim->send_pending) return fail(PCC_ESTATE, "pcc_step_retire without a preceding pcc_step_send");
     DeviceGuard guard(sim->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rc = launch_retire_half(sim, 0, 0, 0, 0, restarts_in_step(sim, auto_reset) ? 1 : 0, obs_out, reward_out, done_out,
-                                      steps_out, st);
+    const int restart = restart_mode(sim, auto_reset);
+    const int rc = launch_retire_half(sim, 0, 0, 0, 0, restart, obs_out, reward_out, done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
+    if (restart & 2) queue_refill(sim, st);
     sim->send_pending = false;
     return after_mi(sim, obs_out, auto_reset, st);
 }
@@ -776,9 +853,10 @@ int pcc_step(pcc_sim_t *sim, const void *actions, int actions_f64, float *obs_ou
         if (rc0 != PCC_OK) return rc0;
         return after_mi(sim, obs_out, auto_reset, st);
     }
-    const int rc = launch_mi(sim, 0, 0, 0, 0, restarts_in_step(sim, auto_reset) ? 1 : 0, actions, actions_f64, obs_out, reward_out,
-                             done_out, steps_out, st);
+    const int restart = restart_mode(sim, auto_reset);
+    const int rc = launch_mi(sim, 0, 0, 0, 0, restart, actions, actions_f64, obs_out, reward_out, done_out, steps_out, st);
     if (rc != PCC_OK) return rc;
+    if (restart & 2) queue_refill(sim, st);
     return after_mi(sim, obs_out, auto_reset, st);
 }
 
@@ -877,8 +955,14 @@ int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream) {
         const int rc = flush_restarts(sim, static_cast<hipStream_t>(stream));
         if (rc != PCC_OK) return rc;
     }
-    return check_hip(hipMemcpy2DAsync(out, width, src, 128, width, rows, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)),
-                     "pcc_get_state copy");
+    // (sender blocks are [S][2N] -- every env's block is followed, N blocks on, by its shadow's: one strided copy per sender)
+    const size_t parts = rows == sn ? (size_t)d.ns : 1;
+    for (size_t sdr = 0; sdr < parts; sdr++) {
+        const int rc = check_hip(hipMemcpy2DAsync(static_cast<char *>(out) + sdr * n * width, width, src + sdr * (size_t)d.stride * 128, 128, width, n,
+                                                  hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)), "pcc_get_state copy");
+        if (rc != PCC_OK) return rc;
+    }
+    return PCC_OK;
 }
 
 }  // extern "C"

@@ -86,6 +86,13 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
     // use_done 1: the envs that finished their episode; 2: the envs a retire launch marked for a restart
     const bool sel = use_done == 2 ? D.env[i].resetting == 2 : (!mask || mask[i]) && (!use_done || D.env[i].done);
     D.env[i].resetting = sel ? 1 : 0;
+    if (sel && D.shadows && !all_envs) {
+        // a reset that is not the env's own episode end overtakes its shadow (prepared for the episode index this reset now
+        // takes): have the shadow prepared again, for the episode after this one
+        D.env[D.n + i].resetting = 2;
+        const uint32_t row = D.step_seq & 3u;
+        D.refill_list[(size_t)row * (size_t)D.n + atomicAdd(&D.refill_count[row * kCntStride], 1u)] = (uint32_t)i;
+    }
     if (sel) {
         release_ring_slots<NS>(D, i, !all_envs);
         reset_env<NS>(D, i, obs_out);
