@@ -304,6 +304,8 @@ def main():
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, env_gid_base=pdist.env_gid_base(rank, N), n_senders=S,
                                        link_params=(200.0, 0.03, 5.0, 0.0, 60.0) if cfg == 2 else None,   # ns:459-464
                                        auto_reset=True, ring_capacity=args.ring_capacity, max_steps=args.max_steps)
+    if os.environ.get("PCC_BENCH_TUNING"):   # experiments: {"knob": value, ...} for env.set_tuning (speed only, never results)
+        env.set_tuning(**json.loads(os.environ["PCC_BENCH_TUNING"]))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     # one action vector per step of an episode (fresh U(-1, 1) actions every step), generated before the timed
     # region.  (A short pool is not harmless: cycled, it gives every env the same net rate change each cycle, the rates
@@ -438,6 +440,7 @@ def main():
                 "note": "the same steps queued from C by one pcc_step_many call (open loop: actions pre-computed); supplementary"}
     if not os.environ.get("PCC_BENCH_IGNORE_FLAGS"):   # experiments only: an overflowed ring means invalid results
         env.check_flags()
+    restart_stats = env.restart_stats() if args.stagger else None
     env.close()
     coll = pdist.collective_info()
     numa_all = None
@@ -544,6 +547,8 @@ def main():
                     other["traffic_over_algorithmic"] = pmc[other["kernel"]].get("traffic_over_algorithmic")
         elif why:
             out["roofline"]["traffic_source"] = "none: " + str(why)
+        if restart_stats is not None:
+            out["restarts_out_of_lockstep"] = restart_stats
         if many is not None:
             out["many_steps_per_call"] = many
         if world == 1 and args.groups > 1:

@@ -204,7 +204,9 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     wave-path workgroups; default 0 */,
        PCC_TUNE_RETIRE_GRID_FRAC = 22 /* retire launch: the grid is n / 16 workgroups plus this share of as many again (for envs of
                                     the 16-lane classes, 8 per workgroup); workgroups loop when there are more.  Default 0.125;
-                                    1 = the worst case (twice n / 16: the dispatch of ~8 200 workgroups alone takes 0.1 ms) */ };
+                                    1 = the worst case (twice n / 16: the dispatch of ~8 200 workgroups alone takes 0.1 ms) */,
+       PCC_TUNE_RESTART_FORK = 23 /* out of lockstep with shadows: the restart kernel (nearly always without work) beside the main
+                                    send launch on a side stream (1) or behind it on the caller's stream (0, default: measured faster) */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* Sizes of the shared ring pools (see pcc_create): tiers 1, 2, 3 get a slot for one sender in div1, div2, div3 (defaults
@@ -296,6 +298,12 @@ int pcc_step_many(pcc_sim_t *sim, const void *actions, int actions_f64, int n_st
 int pcc_step_send(pcc_sim_t *sim, const void *actions, int actions_f64, void *stream);
 int pcc_step_retire(pcc_sim_t *sim, float *obs_out, float *reward_out, uint8_t *done_out,
                     double *steps_out, int auto_reset, void *stream);
+
+/* How the episodes of envs that finished out of lockstep (auto_reset, after a masked reset) were started, since creation:
+ * out2[0] by swapping in the env's shadow -- its next episode (new links, ns:469-477, and the two warm-up intervals,
+ * ns:478-479) prepared ahead of time on a side stream -- out2[1] through the restart list (the warm-up intervals run in
+ * front of the env's first interval inside the send half).  Host pointer; synchronizes `stream`.  No reference counterpart. */
+int pcc_restart_stats(pcc_sim_t *sim, uint64_t *out2, void *stream);
 
 /* copy one state field into a caller-owned device buffer (see the PCC_F_* table) */
 int pcc_get_state(pcc_sim_t *sim, int field, void *out, void *stream);

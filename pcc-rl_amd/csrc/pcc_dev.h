@@ -186,6 +186,7 @@ struct Dev {
     uint32_t *refill_count;  // [4][kCntStride] envs whose shadow was swapped in (or invalidated) at step seq: row seq & 3
     uint32_t *refill_list;   // [4][N]
     int shadows;          // the retire half may swap shadows in (Philox uniforms, envs out of lockstep, lists on)
+    unsigned long long *restart_stats;  // [2] episodes started by a shadow swap / through the restart list (running totals)
     // the reference's dormant USE_CWND engine option (ns:54)
     int use_cwnd;
     // the reference's dormant USE_LATENCY_NOISE engine option (ns:51-52): packets overtake each other, so the in-flight

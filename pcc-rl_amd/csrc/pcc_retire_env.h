@@ -1316,8 +1316,10 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                 const uint32_t row = D.step_seq & 3u;
                 const uint32_t at = atomicAdd(&D.refill_count[row * kCntStride], 1u);
                 D.refill_list[(size_t)row * (size_t)D.n + at] = (uint32_t)i;
+                atomicAdd(&D.restart_stats[0], 1ull);
             } else {
                 D.env[i].resetting = 2;
+                atomicAdd(&D.restart_stats[1], 1ull);
             }
         }
         return __shfl(filed, 0, G);

@@ -63,6 +63,7 @@ struct pcc_sim {
     hipStream_t aux_wave, aux_restart;
     hipEvent_t ev_fork, ev_wave, ev_restart;
     int split_streams;      // measurements: 1 = the light and the wave-path workgroups as two kernels on two streams
+    int restart_fork;         // tuning: with shadows, the restart kernel beside the main send launch (side stream) or behind it
     double retire_grid_frac;  // tuning: share of the envs the retire grid expects in the wide classes (see launch_retire_half)
     unsigned light_front_wgs; // tuning: light workgroups dispatched in front of the wave-path workgroups (the longest light items)
     uint32_t step_seq;      // sequence number of the last step (Dev::step_seq of its launches)
@@ -107,6 +108,7 @@ size_t carve_state(Dev &d, char *base) {
     d.stride = (int64_t)(2 * n);
     d.refill_count = c.take<uint32_t>(4 * kCntStride);
     d.refill_list = c.take<uint32_t>(4 * n);
+    d.restart_stats = c.take<unsigned long long>(2);
     d.cls_count = c.take<uint32_t>(2 * kClsStride);
     d.cursors = c.take<uint32_t>(3 * 16 * 32);
     d.any_done = c.take<uint32_t>(1);
@@ -165,8 +167,17 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
         // with shadows nearly every restart is a swap inside the retire half: the restart list holds only the envs whose shadow
         // was not usable (a masked reset overtook it; links whose warm-up intervals overflow a shadow's rings) -- nearly always
         // nobody: the kernel follows the main launch on the caller's stream, no fork, no join
-        pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
-        launch_send_restart(d, tr, restart_grid, st, read_buf, actions, actions_f64);
+        if (sim->restart_fork) {   // ... or beside it on the side stream: it is done long before the main launch, so the join is free
+            if (hipEventRecord(sim->ev_fork, st) != hipSuccess) return fail(PCC_EHIP, "hipEventRecord failed");
+            (void)hipStreamWaitEvent(sim->aux_wave, sim->ev_fork, 0);
+            launch_send_restart(d, tr, restart_grid, sim->aux_wave, read_buf, actions, actions_f64);
+            (void)hipEventRecord(sim->ev_wave, sim->aux_wave);
+            pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+            (void)hipStreamWaitEvent(st, sim->ev_wave, 0);
+        } else {
+            pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+            launch_send_restart(d, tr, restart_grid < 32u ? restart_grid : 32u, st, read_buf, actions, actions_f64);  // (a handful of items at most)
+        }
     } else if (rs) {
         // The restart items are a chain of dependent passes (reset, two warm-up intervals, the first interval): longer than
         // the whole main launch.  So the MAIN launch goes to the side stream and the restart kernel stays on the caller's:
@@ -459,6 +470,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     sim->split_streams = 0;
     sim->light_front_wgs = 0;   // (measured on one handle: 0 -> 0.1076 ms, 8 -> 0.1107, 64 -> 0.1112)
     sim->retire_grid_frac = 0.125;
+    sim->restart_fork = 0;   // (measured, bench --stagger: behind the main launch 0.153 ms, beside it 0.166)
     if (hipStreamCreateWithFlags(&sim->aux_wave, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&sim->aux_restart, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&sim->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -615,6 +627,7 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
         case PCC_TUNE_PRIO_LIGHT_ITEMS: sim->d.prio_light_items = value >= 4e9 ? 0xFFFFFFFFu : (uint32_t)(value < 0.0 ? 0.0 : value); return PCC_OK;
         case PCC_TUNE_PRIO_WAVE_ITEMS: sim->d.prio_wave_items = value >= 4e9 ? 0xFFFFFFFFu : (uint32_t)(value < 0.0 ? 0.0 : value); return PCC_OK;
         case PCC_TUNE_PRIO_TEAM: sim->d.prio_team = value != 0.0 ? 1u : 0u; return PCC_OK;
+        case PCC_TUNE_RESTART_FORK: sim->restart_fork = value != 0.0 ? 1 : 0; return PCC_OK;
         case PCC_TUNE_RETIRE_GRID_FRAC:
             if (!(value >= 0.0 && value <= 1.0)) return fail(PCC_EINVAL, "retire_grid_frac must be in [0, 1]");
             sim->retire_grid_frac = value;
@@ -908,6 +921,16 @@ int pcc_step_many(pcc_sim_t *sim, const void *actions, int actions_f64, int n_st
             return fail(rc, "pcc_step_many stopped after %d of %d steps: %s", t, n_steps, why);
         }
     }
+    return PCC_OK;
+}
+
+int pcc_restart_stats(pcc_sim_t *sim, uint64_t *out2, void *stream) {
+    if (!sim || !out2) return fail(PCC_EINVAL, "NULL argument");
+    DeviceGuard guard(sim->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(out2, sim->d.restart_stats, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(PCC_EHIP, "reading the restart statistics failed");
     return PCC_OK;
 }
 

@@ -188,6 +188,9 @@ def test_staggered_phases_every_env_every_step_matches_the_oracle(n_senders):
             if len(problems) > 8:
                 break
         assert not problems, "\n".join(p for p in problems if p)
+    # the envs' own episode ends (from step P on) went through the shadows: next episodes prepared ahead of time and swapped in
+    stats = env.restart_stats()
+    assert stats["shadow_swaps"] > n and stats["shadow_swaps"] > 20 * stats["restart_list"], stats
     env.close()
 
 
