@@ -11,9 +11,14 @@
 
 namespace {
 
+// envs of a workgroup of the small-batch kernel: 32 = one round of the four wavefronts at 8 lanes per env in the retire part
+// (64 envs per workgroup were two rounds, i.e. the retire half's chain of dependent round trips twice: 19.0 us per step of
+// config 2 against 14-15; a batch below 8 192 envs is at most 256 workgroups either way: one per compute unit)
+constexpr int kSmallEnvs = 32;
+
 // ======================================================================================
 // step_small_kernel: both halves of a step in ONE launch, for batches too small for work lists (pcc_step of fewer than
-// list_min_envs envs).  A workgroup owns 64 envs: its first wavefront sends them, a lane each (send_light_item, the tail by the
+// list_min_envs envs).  A workgroup owns kSmallEnvs envs: its first wavefront sends them, a lane each (send_light_item, the tail by the
 // wave path), then the four wavefronts retire them, 8 lanes per env.  No cross-workgroup dependency: an env's retire
 // half needs only its own send half.  At 4 096 envs of two packets a step is launch overhead and dependent loads, and
 // one launch instead of two is a third of it (config 2: 34 -> about 24 us per step).
@@ -27,7 +32,7 @@ __global__ __launch_bounds__(4 * kWave, PCC_SMALL_OCC) void step_small_kernel(De
                                                                            float *reward_out, uint8_t *done_out, double *steps_out,
                                                                            int n_steps, int64_t act_stride) {
     const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    const int64_t base = (int64_t)blockIdx.x * kWave;
+    const int64_t base = (int64_t)blockIdx.x * kSmallEnvs;
     __shared__ EnvSlot<NS> s_slots[kSlots];
     const int64_t row = D.n * NS;
 #pragma unroll 1
@@ -35,7 +40,7 @@ __global__ __launch_bounds__(4 * kWave, PCC_SMALL_OCC) void step_small_kernel(De
         const void *act_t = static_cast<const char *>(actions) + (int64_t)t * act_stride;
         if (wv == 0) {
             const int64_t i = base + lane;
-            const bool has = i < D.n;
+            const bool has = lane < (uint32_t)kSmallEnvs && i < D.n;
             uint32_t pk = 0;
             const uint64_t left = send_light_item<NS, TRACE>(D, lane, has ? i : 0, has, blockIdx.x, 0, 0, act_t, actions_f64, pk);
             if (left) {  // the last lanes of the rounds go on by the wave path, from the state the item stored (pcc_send_item.h)
@@ -48,13 +53,12 @@ __global__ __launch_bounds__(4 * kWave, PCC_SMALL_OCC) void step_small_kernel(De
         float *rew_t = reward_out ? reward_out + (int64_t)t * row : nullptr;
         uint8_t *done_t = done_out ? done_out + (int64_t)t * D.n : nullptr;
         double *steps_t = steps_out ? steps_out + (int64_t)t * row * PCC_STEP_COLS : nullptr;
-#pragma unroll 1
-        for (uint32_t r = 0; r < 2u; r++) {
-            const int64_t i = base + (int64_t)((wv * 2u + r) * 8u + lane / 8u);
+        {   // 4 wavefronts x 8 envs at 8 lanes each: the workgroup's 32 envs in one round
+            const int64_t i = base + (int64_t)(wv * 8u + lane / 8u);
             Group g;
             g.lane = lane & 7u;
             g.shift = lane & ~7u;
-            if (i < D.n)
+            if (i < base + kSmallEnvs && i < D.n)
                 (void)retire_env<NS, false, 8>(D, i, g, 0, 0, 0, 0, obs_t, rew_t, done_t, steps_t, nullptr, 0);
         }
         if (t + 1 < n_steps) __syncthreads();  // the next step's send half reads what this retire half wrote
@@ -115,7 +119,7 @@ namespace pcc {
 
 void launch_step_small(const Dev &d, bool trace, hipStream_t st, const void *actions, int actions_f64, float *obs_out,
                        float *reward_out, uint8_t *done_out, double *steps_out, int n_steps, int64_t act_stride) {
-    const dim3 grid((unsigned)((d.n + kWave - 1) / kWave)), block(4 * kWave);
+    const dim3 grid((unsigned)((d.n + kSmallEnvs - 1) / kSmallEnvs)), block(4 * kWave);
 #define PCC_S(NS_, TR_) \
     hipLaunchKernelGGL((step_small_kernel<NS_, TR_>), grid, block, 0, st, d, actions, actions_f64, obs_out, reward_out, done_out, steps_out, n_steps, act_stride)
     if (d.ns == 1) { if (trace) PCC_S(1, true); else PCC_S(1, false); }
