@@ -509,7 +509,7 @@ def main():
             send_gbps = send_bytes / (send_ms * 1e-3) / 1e9
             retire_gbps, retire_ms = 0.0, 0.0
             both = send_gbps
-        out["roofline"] = {"bound": "hbm", "kernel": ("step_small_kernel<%d, false>" if fused else "send_kernel<%d, false, false>") % S, "achieved": send_gbps,
+        out["roofline"] = {"bound": "hbm", "kernel": ("step_small_kernel<%d, false>" if fused else "send_kernel<%d, false>") % S, "achieved": send_gbps,
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": send_gbps / HBM_PEAK_GBPS,
                            "traffic": None, "kernel_ms": send_ms, "algorithmic_bytes_per_launch": send_bytes,
                            "measured_over": roof_src,

@@ -9,7 +9,7 @@ import collections, csv, glob, json, os, sys
 
 
 def short(name):
-    for k in ("step_small_kernel", "step_kernel", "send_kernel", "retire_kernel", "reset_init_kernel"):
+    for k in ("step_small_kernel", "step_kernel", "send_restart_kernel", "send_light_kernel", "send_wave_kernel", "refill_kernel", "send_kernel", "retire_kernel", "reset_init_kernel"):
         if k in name:
             targs = name[name.index(k) + len(k):].split(">")[0].lstrip("<")
             return "%s<%s>" % (k, targs)

@@ -14,9 +14,10 @@ timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 python $R/tools/pmc_aggregate.py $O/pmc_hbm.json $O/pmc_fetch $O/pmc_write > /dev/null
 timeout 200 python $R/bench.py --no-cpu-baseline --no-pmc --stagger --steps 800 --repeats 1 > $O/bench_stagger.log 2>&1
 cd $R
+timeout 200 python $R/bench.py --no-cpu-baseline --no-pmc --config 5 --steps 800 --repeats 1 > $O/bench_config5.log 2>&1
+timeout 200 python $R/bench.py --no-cpu-baseline --no-pmc --config 2 --repeats 1 > $O/bench_config2.log 2>&1
 timeout 200 python tools/send_timeline.py > $O/send_critical_path.json 2> $O/tl.err
-timeout 200 python tools/retire_phases.py > $O/retire_phases.json 2>> $O/tl.err
-timeout 200 python tools/retire_timeline.py > $O/retire_timeline.json 2>> $O/tl.err
-timeout 300 python tools/restart_items.py > $O/restart_items.json 2>> $O/tl.err
+timeout 300 python tools/engine_throughput.py 16384 60 > $O/engine_throughput.json 2>> $O/tl.err
+timeout 300 python tools/ppo_throughput.py > $O/ppo_throughput.json 2>> $O/tl.err
 find $O -name "*kernel_stats.csv" | head -3
 tail -c 2500 $O/bench.log
