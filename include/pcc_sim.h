@@ -198,15 +198,19 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_PRIO_LIGHT_ITEMS = 17 /* ... the first (longest) this many light items */,
        PCC_TUNE_PRIO_WAVE_ITEMS = 18 /* ... the first (largest) this many wave-path items */,
        PCC_TUNE_PRIO_TEAM = 19 /* ... team items (0 / 1) */,
-       PCC_TUNE_SPLIT_STREAMS = 20 /* measurements: 1 = the light and the wave-path workgroups of the send half as two kernels on two
-                                    streams of the handle instead of one launch (default 0: slower, see pcc_send_bodies.h) */,
-       PCC_TUNE_LIGHT_FRONT_WGS = 21 /* send launch: light workgroups (4 items each, the longest) dispatched in front of the
-                                    wave-path workgroups; default 0 */,
+       PCC_TUNE_SPLIT_STREAMS = 20 /* gone (an experiment of round 4, measured slower: the two kinds of send workgroup as two kernels
+                                    on two streams); only 0 is accepted */,
+       PCC_TUNE_LIGHT_FRONT_WGS = 21 /* gone (light workgroups dispatched in front of the wave-path ones); only 0 is accepted */,
        PCC_TUNE_RETIRE_GRID_FRAC = 22 /* retire launch: the grid is n / 16 workgroups plus this share of as many again (for envs of
                                     the 16-lane classes, 8 per workgroup); workgroups loop when there are more.  Default 0.125;
                                     1 = the worst case (twice n / 16: the dispatch of ~8 200 workgroups alone takes 0.1 ms) */,
        PCC_TUNE_RESTART_FORK = 23 /* out of lockstep with shadows: the restart kernel (nearly always without work) beside the main
-                                    send launch on a side stream (1) or behind it on the caller's stream (0, default: measured faster) */ };
+                                    send launch on a side stream (1) or behind it on the caller's stream (0, default: measured faster) */,
+       PCC_TUNE_PARTS = 24 /* partitions of the batch (1 or 8): contiguous env-id ranges with work lists, item cursors and pool
+                                    stacks of their own; workgroup b of a launch works for partition b % 8, i.e. an XCD keeps to
+                                    one eighth of the rings (a scattered access costs 2.5x as much once the addresses an XCD
+                                    touches span more than ~2 GB).  Default 8 from 8 192 envs up, else 1.  Changing it puts every
+                                    sender back into its own tier-0 rings: pcc_reset must follow */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* Sizes of the shared ring pools (see pcc_create): tiers 1, 2, 3 get a slot for one sender in div1, div2, div3 (defaults

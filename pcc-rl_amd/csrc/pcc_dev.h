@@ -33,13 +33,13 @@
 //
 // Kernels per step, each in its own translation unit with its own register budget (csrc/*.hip; the C ABI and the
 // launch logic are in pcc_sim.hip):
-//   send_light_kernel    (pcc_send_light.hip) light items off the class lists the previous retire launch filed: 64 envs
-//                        of about the same predicted packet count, a lane each, in rounds (no loads in the loop);
-//   send_wave_kernel     (pcc_send_wave.hip) persistent wavefronts over the wave-path items -- an env sent by all 64
-//                        lanes, 256 packets per pass, from closed forms (heavy_mi) -- and the team items (the largest
-//                        envs, four wavefronts of a workgroup per env); runs beside the light kernel on a second stream;
+//   send_kernel          (pcc_send.hip) one launch, two kinds of workgroup: light items off the class lists the previous
+//                        retire launch filed -- 64 envs of about the same predicted packet count, a lane each, in rounds
+//                        (no loads in the loop) -- and persistent wavefronts over the wave-path items -- an env sent by all
+//                        64 lanes, 256 packets per pass, from closed forms (heavy_mi) -- and the team items (the largest
+//                        envs, four wavefronts of a workgroup per env);
 //   send_restart_kernel  (pcc_send_restart.hip) envs that finished their episode out of lockstep: new links, the two
-//                        warm-up intervals (send + retire each), then the first interval; third stream;
+//                        warm-up intervals (send + retire each), then the first interval;
 //   retire_kernel        (pcc_retire.hip) retire_env, 8 or 16 lanes per env: searches of the rings for the hop-2 / hop-1
 //                        boundaries (all four advanced together), the MI-ending event, RTT sums as numpy's pairwise
 //                        tree, metrics, history, observation, reward, done; then files every env by its predicted
@@ -141,15 +141,22 @@ struct Dev {
     int n_tiers;
     uint32_t cap0;
     char *tier_base[kMaxTiers];
-    uint32_t *tier_free[kMaxTiers];  // [tier_slots[c]] free slot ids (a stack; c >= 1)
-    int32_t *tier_top;               // [kMaxTiers] stack heights
+    // free slots of the pools (c >= 1): a stack per partition of the envs over its share of the pool's slots.  Addressed by
+    // arithmetic and device memory, not by arrays of this struct: a kernel-argument array indexed by a run-time tier inside
+    // the loop over the partitions ended up copied to scratch by the compiler
+    uint32_t *pool_free;             // [kMaxTiers][pool_free_stride]: tier c's stacks, partition p's at p * pool_share[c]
+    size_t pool_free_stride;
+    uint32_t *pool_share;            // [kMaxTiers] slots of one partition's share (slots [p * share, (p + 1) * share) of the pool)
+    int32_t *tier_top;               // [kMaxTiers][kParts] stack heights, kTopStride words apart
     uint32_t tier_slots[kMaxTiers];  // slots of each pool
+    // XCD-affine partitions (see "partitions" below): the envs in `parts` contiguous id ranges of part_envs envs each
+    uint32_t parts, parts_shift, part_envs;   // (parts = 1 << parts_shift)
     uint32_t key0, key1, gid_base;
     double delta_scale;
     uint32_t max_steps;
-    uint32_t *cls_count;  // [2][kClsStride] work lists of the send half (two buffers): envs per class, item cursor
-    uint32_t *cls_list;   // [2][kClasses][N] env ids by class
-    uint32_t *cursors;    // [3][kShards][kCursorStride] item cursors of the two list buffers (third block unused)
+    uint32_t *cls_count;  // [2][parts][kClsStride] work lists of the send half (two buffers, a set per partition): envs per class
+    uint32_t *cls_list;   // [2][parts][kListRows][part_envs] env ids by class
+    uint32_t *cursors;    // [2][parts][kShards][kCursorStride] item cursors of the list buffers
     // [1] the retire half writes the step's sequence number (step_seq, below) here when an env finishes its episode;
     // the gated auto-reset launches of that step run only if they find it.  Nobody ever clears the word: a clear by one
     // workgroup of a launch races with the sets of the others (the L2 of every XCD writes back on its own schedule)
@@ -339,6 +346,33 @@ constexpr uint32_t kShadowTier = 1u;  // a shadow's private rings have the size 
 __device__ __forceinline__ int64_t sidx(const Dev &D, int s, int64_t i) { return (int64_t)s * D.stride + i; }
 __device__ __forceinline__ int64_t env_of(const Dev &D, int64_t i) { return i >= D.n ? i - D.n : i; }  // block index -> env id
 
+// Partitions of the batch (see "partitions" below): contiguous id ranges with work lists and pool stacks of their own
+constexpr uint32_t kParts = 8;
+constexpr uint32_t kTopStride = 32;   // words between two pool-stack heights: a line each (they are atomics)
+__device__ __forceinline__ uint32_t part_of(const Dev &D, const int64_t env) { return (uint32_t)env / D.part_envs; }  // env < N
+
+// A free slot of pool c for an env of partition p0: its own partition's stack first (the slots of a partition are one
+// contiguous share of the pool), the others' when that one is empty.  -1: the pool is empty.  (Pops happen only in send
+// launches, pushes only in reset and retire launches: no stack races.)
+__device__ __forceinline__ int64_t pool_pop(const Dev &D, const uint32_t c, const uint32_t p0) {
+    for (uint32_t k = 0; k < D.parts; k++) {
+        uint32_t p = p0 + k;
+        if (p >= D.parts) p -= D.parts;
+        int32_t *top = D.tier_top + (size_t)(c * kParts + p) * kTopStride;
+        const int32_t old = atomicSub(top, 1);
+        if (old > 0) return (int64_t)D.pool_free[(size_t)c * D.pool_free_stride + (size_t)p * D.pool_share[c] + (uint32_t)(old - 1)];
+        atomicAdd(top, 1);
+    }
+    return -1;
+}
+__device__ __forceinline__ void pool_push(const Dev &D, const uint32_t c, const uint32_t slot) {
+    const uint32_t share = D.pool_share[c];
+    uint32_t p = slot / share;
+    if (p >= D.parts) p = D.parts - 1u;
+    int32_t *top = D.tier_top + (size_t)(c * kParts + p) * kTopStride;
+    D.pool_free[(size_t)c * D.pool_free_stride + (size_t)p * share + (uint32_t)atomicAdd(top, 1)] = slot;
+}
+
 __device__ __forceinline__ uint32_t tier_cap(const Dev &D, uint32_t tier) { return D.cap0 << (2u * (tier == kTierBorrowed ? kShadowTier : tier)); }
 __device__ __forceinline__ size_t tier_slot_bytes(const Dev &D, uint32_t tier) { return (size_t)3 * tier_cap(D, tier) * sizeof(double2); }
 
@@ -413,10 +447,10 @@ __device__ __forceinline__ bool promote_rings(const Dev &D, uint32_t lane, uint3
     uint32_t got = 0xFFFFFFFFu, slot = 0;
     if (lane == l) {
         if (want == 0u) got = 0u;
+        const uint32_t p0 = part_of(D, env_of(D, k % D.stride));
         for (uint32_t c = want; got == 0xFFFFFFFFu && c < (uint32_t)D.n_tiers; c++) {
-            const int32_t old = atomicSub(&D.tier_top[c], 1);
-            if (old > 0) { slot = D.tier_free[c][old - 1]; got = c; break; }
-            atomicAdd(&D.tier_top[c], 1);
+            const int64_t sl = pool_pop(D, c, p0);
+            if (sl >= 0) { slot = (uint32_t)sl; got = c; break; }
         }
     }
     got = rl_u32(got, l);
@@ -473,6 +507,26 @@ __device__ __forceinline__ int class_of(float pred) {
 // shards when its own is empty (a plain look at their cursors first: no atomic on an empty shard).
 constexpr uint32_t kShards = 16;
 constexpr uint32_t kCursorStride = 32;  // words between shard cursors: one 128-byte line each
+
+// ---- partitions ----------------------------------------------------------------------------
+// A scattered 16-byte access costs a compute unit 2.5x as much when the addresses its XCD touches span more than ~2 GB
+// than when they span less (tools/microbench/store_bench4: 200 G records/s chip-wide up to 2 GB, 160 at 3 GB, 80 from 4 GB
+// up -- the reach of an XCD's address translation, not a bandwidth), and the rings of 65 536 envs span 1.5 GB in tier 0 alone,
+// plus the pools.  So the batch is cut into kParts contiguous id ranges, each with work lists, item cursors and pool stacks
+// of its own: workgroup b of a launch works for partition b % kParts -- the hardware places block b on XCD b % 8 (observed,
+// MI355X_MICROARCH.md; nothing depends on it but speed) -- so an XCD keeps touching the same eighth of tier 0 and of every
+// pool.  Which workgroup handles an env never changes a result.  Batches too small for it (and the event-loop builds) run
+// as one partition.
+
+// the list set of partition `part` in buffer `buf`
+__device__ __forceinline__ uint32_t list_view(const Dev &D, const int buf, const uint32_t part) { return (uint32_t)buf * D.parts + part; }
+__device__ __forceinline__ uint32_t *cls_count_of(const Dev &D, const uint32_t view, const uint32_t row) {
+    return D.cls_count + ((size_t)view * kClsStride + (size_t)row * kCntStride);
+}
+__device__ __forceinline__ uint32_t *cls_list_of(const Dev &D, const uint32_t view, const uint32_t row) {
+    return D.cls_list + ((size_t)view * kListRows + row) * (size_t)D.part_envs;
+}
+__device__ __forceinline__ uint32_t *cursors_of(const Dev &D, const uint32_t view) { return D.cursors + (size_t)view * kShards * kCursorStride; }
 
 // (send_kernel itself follows retire_env below: a restart item runs the env's warm-up intervals through both halves)
 

@@ -6,15 +6,10 @@
 
 namespace pcc {
 
-// pcc_send.hip: both kinds of workgroup in one launch -- `front` light workgroups, then wave_wgs wave-path workgroups, then the
-// other light workgroups (light_wgs in all).
-void launch_send(const Dev &d, bool trace, unsigned light_wgs, unsigned wave_wgs, unsigned front, hipStream_t st, int read_buf,
+// pcc_send.hip: both kinds of workgroup in one launch -- wave_wgs wave-path workgroups, then light_wgs light workgroups (with
+// lists both are multiples of Dev::parts: workgroup b works for partition b % parts).
+void launch_send(const Dev &d, bool trace, unsigned light_wgs, unsigned wave_wgs, hipStream_t st, int read_buf,
                  int zero_buf, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64);
-// pcc_send_light.hip (the light workgroups as a kernel of their own: split_streams).  grid: workgroups of 4 wavefronts, one light item (or index-order chunk) per wavefront and round.
-void launch_send_light(const Dev &d, bool trace, unsigned grid, hipStream_t st, int read_buf, int zero_buf, int warm,
-                       uint32_t warm_mi, int gate, const void *actions, int actions_f64);
-// pcc_send_wave.hip (the wave-path workgroups as a kernel of their own: split_streams).  grid: persistent workgroups of 4 wavefronts (wave-path items off cursors; team items first).
-void launch_send_wave(const Dev &d, bool trace, unsigned grid, hipStream_t st, int read_buf, const void *actions, int actions_f64);
 // pcc_send_restart.hip.  grid: workgroups of 4 wavefronts, restart items dealt statically.
 void launch_send_restart(const Dev &d, bool trace, unsigned grid, hipStream_t st, int read_buf, const void *actions, int actions_f64);
 // ... refill_kernel: the shadows of the envs in refill row `row` (their next episodes: new links + warm-up intervals)

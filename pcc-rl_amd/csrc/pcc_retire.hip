@@ -30,7 +30,8 @@ __global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIR
     __shared__ uint32_t s_env[kRetireMaxPerBlock], s_cls[kRetireMaxPerBlock], s_arrived;
     const uint32_t tid = threadIdx.x;
     if (prof_on(D) && !warm) {  // profile build: the send items' timeline slots are cleared for the next send launch
-        for (int64_t slot = (int64_t)blockIdx.x * kRetireBlock + tid; slot < 2 * D.n; slot += (int64_t)gridDim.x * kRetireBlock)
+        const int64_t tl_slots = 2 * D.n + 64 * kParts < 3 * D.n ? 2 * D.n + 64 * kParts : 3 * D.n;   // (pcc_send.hip / pcc_send_bodies.h: tl_base)
+        for (int64_t slot = (int64_t)blockIdx.x * kRetireBlock + tid; slot < tl_slots; slot += (int64_t)gridDim.x * kRetireBlock)
             D.timeline[slot * 8] = 0;
     }
     const uint32_t lane = tid & (kWave - 1);
@@ -39,11 +40,15 @@ __global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIR
     __syncthreads();  // the workgroup's wavefronts start together: this one is free
     int64_t i = D.n;   // (beyond the envs: nothing)
     bool wide = false;  // this workgroup: 16 lanes per env
+    // With lists, workgroup b walks the lists of partition b % parts (pcc_dev.h "partitions": the XCD that block b lands on
+    // keeps reading the same eighth of the rings), as workgroup b / parts of that partition's share of the grid
+    const uint32_t P = D.parts, part = blockIdx.x % P, b_loc = blockIdx.x / P, grid_loc = gridDim.x / P;
     if (read_buf >= 0) {
+        const uint32_t view = list_view(D, read_buf, part);
         // lane l < kClasses looks after class kClasses-1-l, lane kClasses after the restart list (envs that were reset
         // by the retire launch before this one: last); inclusive prefix of the counts in that order
         const uint32_t row_mine = lane < (uint32_t)kClasses ? (uint32_t)(kClasses - 1) - lane : (uint32_t)kRestart;
-        const uint32_t n_mine = lane <= (uint32_t)kClasses ? D.cls_count[read_buf * kClsStride + row_mine * kCntStride] : 0u;
+        const uint32_t n_mine = lane <= (uint32_t)kClasses ? *cls_count_of(D, view, row_mine) : 0u;
         uint32_t incl = n_mine;
         for (int o = 1; o <= kClasses; o <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
@@ -58,18 +63,18 @@ __global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIR
         // the smallest of them go 8 lanes like everybody else: lanes per env is a speed choice, every result is the same.
         {
             const uint32_t narrow_all = (total + 15u) / 16u;   // workgroups if nobody were wide
-            const uint32_t spare = gridDim.x > narrow_all + 1u ? gridDim.x - narrow_all - 1u : 0u;   // each takes 16 wide envs' extra share
+            const uint32_t spare = grid_loc > narrow_all + 1u ? grid_loc - narrow_all - 1u : 0u;   // each takes 16 wide envs' extra share
             if (n_top > 16u * spare) n_top = 16u * spare;
         }
         const uint32_t wg_wide = (n_top + 7u) / 8u;  // workgroups that take them, 8 each
-        wide = blockIdx.x < wg_wide;
+        wide = b_loc < wg_wide;
         uint32_t p;  // this lane's position in the walk (the same for the lanes of a group)
         bool has;
         if (wide) {
-            p = blockIdx.x * 8u + tid / 16u;
+            p = b_loc * 8u + tid / 16u;
             has = p < n_top;
         } else {
-            p = n_top + (blockIdx.x - wg_wide) * 16u + tid / 8u;
+            p = n_top + (b_loc - wg_wide) * 16u + tid / 8u;
             has = p < total;
         }
         // the row whose inclusive prefix first exceeds p: binary search over lanes 0..kClasses (33 values)
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIR
         if (has) {
             const uint32_t row = L < (uint32_t)kClasses ? (uint32_t)(kClasses - 1) - L : (uint32_t)kRestart;
             const uint32_t off = p - (inc_L - n_L);
-            i = (int64_t)D.cls_list[((size_t)read_buf * kListRows + row) * (size_t)D.n + off];
+            i = (int64_t)cls_list_of(D, view, row)[off];
         }
     } else {
         i = (int64_t)blockIdx.x * kRetireMaxPerBlock + tid / 8u;
@@ -136,10 +141,12 @@ __global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIR
         rank += (match && l < lane) ? 1u : 0u;
         if (match && l < leader) leader = l;
     }
+    // the workgroup's envs are all of one partition: the one whose lists it walked, or (index order) 16 consecutive ids
+    const uint32_t fview = list_view(D, fill_buf, read_buf >= 0 ? part : min(part_of(D, (int64_t)blockIdx.x * kRetireMaxPerBlock), P - 1u));
     uint32_t base = 0u;
-    if (files && leader == lane) base = atomicAdd(&D.cls_count[fill_buf * kClsStride + c * kCntStride], same);
+    if (files && leader == lane) base = atomicAdd(cls_count_of(D, fview, c), same);
     base = (uint32_t)__shfl((int)base, (int)leader);
-    if (files) D.cls_list[((size_t)fill_buf * kListRows + c) * (size_t)D.n + base + rank] = e;
+    if (files) cls_list_of(D, fview, c)[base + rank] = e;
 }
 
 }  // namespace

@@ -775,7 +775,7 @@ __device__ __forceinline__ void release_ring_slots(const Dev &D, const int64_t i
         for (int c = 1; c < D.n_tiers; c++) {
             const uint32_t held = D.snd[k].ring_held[c];
             if (held) {
-                if (push) D.tier_free[c][atomicAdd(&D.tier_top[c], 1)] = held - 1u;
+                if (push) pool_push(D, (uint32_t)c, held - 1u);
                 D.snd[k].ring_held[c] = 0;
             }
         }

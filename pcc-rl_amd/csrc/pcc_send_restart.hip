@@ -19,12 +19,20 @@ template <int NS, bool TRACE>
 __global__ __launch_bounds__(4 * kWave, PCC_RESTART_OCC) void send_restart_kernel(Dev D, int read_buf, const void *actions, int actions_f64) {
     const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const uint32_t wave = blockIdx.x * 4u + wv, n_waves = gridDim.x * 4u;
-    const uint32_t n_restart = D.cls_count[read_buf * kClsStride + kRestart * kCntStride];
-    const uint32_t tl_base = (uint32_t)D.n + (uint32_t)(D.n / 2);  // profile build: timeline slots of the restart items
     __shared__ EnvSlot<NS> s_slots[4][kSlots];
-    for (uint32_t t = wave; t < n_restart; t += n_waves) {
+    // the restart lists of the partitions, one after the other, as one ranking
+    uint32_t total = 0;
+    for (uint32_t part = 0; part < D.parts; part++) total += *cls_count_of(D, list_view(D, read_buf, part), (uint32_t)kRestart);
+    for (uint32_t g = wave; g < total; g += n_waves) {
+        uint32_t part = 0, t = g;
+        for (;;) {
+            const uint32_t n_p = *cls_count_of(D, list_view(D, read_buf, part), (uint32_t)kRestart);
+            if (t < n_p) break;
+            t -= n_p;
+            part++;
+        }
         const bool has = lane == 0;
-        const int64_t i = has ? (int64_t)D.cls_list[((size_t)read_buf * kListRows + kRestart) * (size_t)D.n + t] : 0;
+        const int64_t i = has ? (int64_t)cls_list_of(D, list_view(D, read_buf, part), (uint32_t)kRestart)[t] : 0;
         // new links and fresh state (ns:469-477) unless a flush already did all of it (pcc_get_state, a masked reset)
         if (has && D.env[i].resetting == 2) reset_env<NS>(D, i, nullptr);
         if (has && D.shadows) {   // its shadow (if any) was not usable: have it prepared for the episode after this one
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(4 * kWave, PCC_RESTART_OCC) void send_restart_kerne
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
-        (void)send_wave_item<NS, TRACE, 1>(D, lane, i, has, true, tl_base + t, 0, 0, actions, actions_f64, s_slots[wv]);
+        (void)send_wave_item<NS, TRACE, 1>(D, lane, i, has, true, 0xFFFFFFFFu, 0, 0, actions, actions_f64, s_slots[wv]);
     }
 }
 

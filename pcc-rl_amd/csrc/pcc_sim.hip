@@ -1,5 +1,5 @@
 // pcc_sim.hip -- MI355X (gfx950) batched congestion-control simulator: the C ABI (include/pcc_sim.h) and the launch
-// logic.  The kernels live in their own translation units (pcc_send_light.hip, pcc_send_wave.hip, pcc_send_restart.hip,
+// logic.  The kernels live in their own translation units (pcc_send.hip, pcc_send_restart.hip,
 // pcc_retire.hip, pcc_small.hip; pcc_kernels.h declares their launch functions, pcc_dev.h what they share).
 //
 // What this replaces (reference = PCCproject/PCC-RL; "ns" = src/gym/network_sim.py, "so" =
@@ -37,7 +37,6 @@ struct pcc_sim {
     void *state_blob;
     size_t state_bytes;
     void *tier_blob[kMaxTiers];   // tier 0: one slot per (env, sender); tiers >= 1: pools
-    void *tier_free_blob[kMaxTiers];
     uint32_t tier_slots[kMaxTiers];
     size_t tier_bytes[kMaxTiers];
     size_t ring_bytes;
@@ -58,14 +57,12 @@ struct pcc_sim {
     bool restarts_pending;  // a retire launch may have left envs in the restart list (their warm-up intervals are due)
     bool read_has_restarts; // the list buffer read_buf was filed by a retire launch that resets finished envs (restart list)
     uint32_t list_min_envs; // batches below this size are stepped without work lists (index order)
-    // the send half of a step with work lists is up to three kernels side by side: the light kernel on the caller's stream,
-    // the wave kernel and the restart kernel on these (forked from / joined to the caller's stream by events)
+    // side streams of the handle: the restart kernel (or, without shadows, the main send launch beside it) and the refill
+    // kernel, forked from / joined to the caller's stream by events
     hipStream_t aux_wave, aux_restart;
     hipEvent_t ev_fork, ev_wave, ev_restart;
-    int split_streams;      // measurements: 1 = the light and the wave-path workgroups as two kernels on two streams
     int restart_fork;         // tuning: with shadows, the restart kernel beside the main send launch (side stream) or behind it
     double retire_grid_frac;  // tuning: share of the envs the retire grid expects in the wide classes (see launch_retire_half)
-    unsigned light_front_wgs; // tuning: light workgroups dispatched in front of the wave-path workgroups (the longest light items)
     uint32_t step_seq;      // sequence number of the last step (Dev::step_seq of its launches)
     void *shadow_blob;      // the shadows' private rings (allocated when envs first restart out of lockstep)
     size_t shadow_bytes;
@@ -109,10 +106,13 @@ size_t carve_state(Dev &d, char *base) {
     d.refill_count = c.take<uint32_t>(4 * kCntStride);
     d.refill_list = c.take<uint32_t>(4 * n);
     d.restart_stats = c.take<unsigned long long>(2);
-    d.cls_count = c.take<uint32_t>(2 * kClsStride);
-    d.cursors = c.take<uint32_t>(3 * 16 * 32);
+    d.cls_count = c.take<uint32_t>(2 * kParts * kClsStride);
+    d.cursors = c.take<uint32_t>(2 * kParts * kShards * kCursorStride);
     d.any_done = c.take<uint32_t>(1);
-    d.tier_top = c.take<int32_t>(kMaxTiers);
+    d.tier_top = c.take<int32_t>(kMaxTiers * kParts * kTopStride);
+    d.pool_share = c.take<uint32_t>(kMaxTiers);
+    d.pool_free_stride = sn < 256 ? 256 : sn;   // (a pool has at most a slot per sender, at least 256: alloc_tier)
+    d.pool_free = c.take<uint32_t>(kMaxTiers * d.pool_free_stride);
     d.hist = c.take<float>(sn * d.HF);
     return (c.off + 255) & ~(size_t)255;
 }
@@ -129,7 +129,6 @@ int check_hip(hipError_t err, const char *what) {
 // launch reset out of lockstep (the restart list: warm-up intervals first) are a kernel of their own on a side stream of the
 // handle, forked from and joined to the caller's stream by events; it never touches an env the main launch touches.
 // Without lists (after a reset, warm-up intervals, small batches): light workgroups only, the envs in index order.
-// (split_streams = 1, measurements only: the light and the wave-path workgroups as two kernels on two streams.)
 int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64, hipStream_t st) {
     const Dev &d = sim->d;
     const bool tr = d.rng_mode == PCC_RNG_TRACE;
@@ -139,31 +138,26 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
     const int read_buf = (warm || !lists) ? -1 : sim->read_buf;
     const int zero_buf = lists ? sim->fill_buf : -1;
     // light workgroups: one item per wavefront; the grid covers the worst case (every env light: n / E items + a partial
-    // one per class), wavefronts without an item leave at once
+    // one per class), wavefronts without an item leave at once.  With lists every partition has its own share of the
+    // workgroups (pcc_dev.h "partitions"): both kinds' counts are multiples of d.parts
     const int64_t E = d.send_envs_per_wave;
-    const int64_t light_items = (d.n + E - 1) / E + (read_buf >= 0 ? kClasses : 0);
-    const unsigned light_grid = (unsigned)((light_items + 3) / 4);
     if (read_buf < 0) {
-        pcc::launch_send(d, tr, light_grid, 0u, 0u, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+        const unsigned light_grid = (unsigned)(((d.n + E - 1) / E + 3) / 4);
+        pcc::launch_send(d, tr, light_grid, 0u, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
         return check_hip(hipGetLastError(), "send kernel launch");
     }
+    const int64_t P = d.parts;
+    const int64_t light_items_part = ((int64_t)d.part_envs + E - 1) / E + kClasses;
+    const unsigned light_grid = (unsigned)(P * ((light_items_part + 3) / 4));
     // restart items can only be in lists that a retire launch with `restart` filed
     const bool rs = sim->read_has_restarts;
     const bool wave = !d.use_cwnd && d.heavy_predict < 1e9;  // (USE_CWND sends every env lane-serially: no wave-path classes)
     // wave-path workgroups: persistent wavefronts, send_waves per compute unit, at most one wavefront per env
     int64_t waves = (int64_t)sim->cu_count * d.send_waves;
     if (waves > d.n) waves = d.n;
-    const unsigned wave_grid = wave ? (unsigned)((waves + 3) / 4) : 0u;
+    const unsigned wave_grid = wave ? (unsigned)(P * (((waves + 3) / 4 + P - 1) / P)) : 0u;
     const unsigned restart_grid = (unsigned)(sim->cu_count < (d.n + 3) / 4 ? sim->cu_count : (d.n + 3) / 4);
-    if (sim->split_streams && wave) {   // (measurements only; restart items, if any, first on the caller's stream)
-        if (rs) launch_send_restart(d, tr, restart_grid, st, read_buf, actions, actions_f64);
-        if (hipEventRecord(sim->ev_fork, st) != hipSuccess) return fail(PCC_EHIP, "hipEventRecord failed");
-        (void)hipStreamWaitEvent(sim->aux_wave, sim->ev_fork, 0);
-        launch_send_wave(d, tr, wave_grid, sim->aux_wave, read_buf, actions, actions_f64);
-        (void)hipEventRecord(sim->ev_wave, sim->aux_wave);
-        launch_send_light(d, tr, light_grid, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
-        (void)hipStreamWaitEvent(st, sim->ev_wave, 0);
-    } else if (rs && d.shadows) {
+    if (rs && d.shadows) {
         // with shadows nearly every restart is a swap inside the retire half: the restart list holds only the envs whose shadow
         // was not usable (a masked reset overtook it; links whose warm-up intervals overflow a shadow's rings) -- nearly always
         // nobody: the kernel follows the main launch on the caller's stream, no fork, no join
@@ -172,10 +166,10 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
             (void)hipStreamWaitEvent(sim->aux_wave, sim->ev_fork, 0);
             launch_send_restart(d, tr, restart_grid, sim->aux_wave, read_buf, actions, actions_f64);
             (void)hipEventRecord(sim->ev_wave, sim->aux_wave);
-            pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+            pcc::launch_send(d, tr, light_grid, wave_grid, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
             (void)hipStreamWaitEvent(st, sim->ev_wave, 0);
         } else {
-            pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+            pcc::launch_send(d, tr, light_grid, wave_grid, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
             launch_send_restart(d, tr, restart_grid < 32u ? restart_grid : 32u, st, read_buf, actions, actions_f64);  // (a handful of items at most)
         }
     } else if (rs) {
@@ -185,12 +179,12 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
         // dependency on a kernel that is just ending costs ~15 us, one that ended long ago next to nothing)
         if (hipEventRecord(sim->ev_fork, st) != hipSuccess) return fail(PCC_EHIP, "hipEventRecord failed");
         (void)hipStreamWaitEvent(sim->aux_wave, sim->ev_fork, 0);
-        pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, sim->aux_wave, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+        pcc::launch_send(d, tr, light_grid, wave_grid, sim->aux_wave, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
         (void)hipEventRecord(sim->ev_wave, sim->aux_wave);
         launch_send_restart(d, tr, restart_grid, st, read_buf, actions, actions_f64);
         (void)hipStreamWaitEvent(st, sim->ev_wave, 0);
     } else {
-        pcc::launch_send(d, tr, light_grid, wave_grid, sim->light_front_wgs, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+        pcc::launch_send(d, tr, light_grid, wave_grid, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
     }
     if (rs && !warm) sim->restarts_pending = false;  // this launch runs what the restart list's envs were owed
     return check_hip(hipGetLastError(), "send kernel launch");
@@ -210,8 +204,10 @@ int launch_retire_half(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm
     // grid is sized for retire_grid_frac of the envs being wide (default 1/8: about 3 % are) and the workgroups loop if there
     // are more -- the worst case, twice n / 16, is ~8 200 workgroups for 65 536 envs, which the command processor needs
     // 0.1 ms to dispatch even when half of them find nothing to do
+    // (with lists: that many for every partition's share, pcc_dev.h "partitions")
     const int64_t narrow = (d.n + kRetireEnvsPerBlockNarrow - 1) / kRetireEnvsPerBlockNarrow;
-    const unsigned grid = (unsigned)(read >= 0 ? narrow + (int64_t)(sim->retire_grid_frac * (double)narrow) + 1 : narrow);
+    const int64_t narrow_part = ((int64_t)d.part_envs + kRetireEnvsPerBlockNarrow - 1) / kRetireEnvsPerBlockNarrow;
+    const unsigned grid = (unsigned)(read >= 0 ? (int64_t)d.parts * (narrow_part + (int64_t)(sim->retire_grid_frac * (double)narrow_part) + 1) : narrow);
     const int fill = (warm || !lists) ? -1 : sim->fill_buf;
     launch_retire(d, false, grid, st, read, fill, warm, warm_mi, last_warm, gate, restart, obs_out, reward_out, done_out, steps_out,
                   nullptr, 0);
@@ -296,7 +292,6 @@ int alloc_tier(pcc_sim_t *sim, int c, unsigned divisor) {
     if (slots < 256) slots = senders < 256 ? senders : 256;
     if (c == 0) slots = senders;
     if (sim->tier_blob[c]) { (void)hipFree(sim->tier_blob[c]); sim->tier_blob[c] = nullptr; sim->ring_bytes -= sim->tier_bytes[c]; }
-    if (sim->tier_free_blob[c]) { (void)hipFree(sim->tier_free_blob[c]); sim->tier_free_blob[c] = nullptr; }
     sim->tier_bytes[c] = 0;
     sim->tier_slots[c] = (uint32_t)slots;
     d.tier_slots[c] = (uint32_t)slots;
@@ -311,18 +306,43 @@ int alloc_tier(pcc_sim_t *sim, int c, unsigned divisor) {
     if (hipMemset(sim->tier_blob[c], 0, bytes) != hipSuccess) return fail(PCC_EHIP, "hipMemset of the tier-%d rings failed", c);
     size_t total = bytes;
     d.tier_base[c] = static_cast<char *>(sim->tier_blob[c]);
-    if (c >= 1) {
-        std::vector<uint32_t> ids(slots);
-        for (size_t j = 0; j < slots; j++) ids[j] = (uint32_t)(slots - 1 - j);  // slot 0 is popped first
-        if (hipMalloc(&sim->tier_free_blob[c], slots * sizeof(uint32_t)) != hipSuccess ||
-            hipMemcpy(sim->tier_free_blob[c], ids.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
-            return fail(PCC_ENOMEM, "allocating the tier-%d free list failed", c);
-        total += slots * sizeof(uint32_t);
-        d.tier_free[c] = static_cast<uint32_t *>(sim->tier_free_blob[c]);
-    }
     sim->tier_bytes[c] = total;
     sim->ring_bytes += total;
     return PCC_OK;
+}
+
+// Every pool's free stacks, full: one stack per partition of the batch over its contiguous share of the pool's slots
+// (pcc_dev.h "partitions"), the share's lowest slot on top.  (Slots beyond parts * share, fewer than `parts`, stay unused.)
+int init_pool_stacks(pcc_sim_t *sim) {
+    Dev &d = sim->d;
+    std::vector<int32_t> tops((size_t)kMaxTiers * kParts * kTopStride, 0);
+    uint32_t shares[kMaxTiers] = {0, 0, 0, 0};
+    for (int c = 1; c < d.n_tiers; c++) {
+        const uint32_t share = sim->tier_slots[c] / d.parts;
+        shares[c] = share;
+        std::vector<uint32_t> ids(sim->tier_slots[c], 0u);
+        for (uint32_t p = 0; p < d.parts; p++) {
+            for (uint32_t j = 0; j < share; j++) ids[(size_t)p * share + j] = p * share + (share - 1u - j);
+            tops[(size_t)(c * kParts + p) * kTopStride] = (int32_t)share;
+        }
+        if (hipMemcpy(d.pool_free + (size_t)c * d.pool_free_stride, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(PCC_EHIP, "filling the tier-%d free stacks failed", c);
+    }
+    if (hipMemcpy(d.tier_top, tops.data(), tops.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d.pool_share, shares, sizeof shares, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(PCC_EHIP, "resetting the pool stacks failed");
+    return PCC_OK;
+}
+
+// The batch as `parts` partitions (1 or kParts) of part_envs consecutive env ids each (a multiple of 64: an index-order item
+// or retire workgroup never straddles two).
+void set_parts(pcc_sim_t *sim, uint32_t parts) {
+    Dev &d = sim->d;
+    d.parts = parts;
+    d.parts_shift = 0;
+    while ((1u << d.parts_shift) < parts) d.parts_shift++;
+    const int64_t per = (d.n + parts - 1) / parts;
+    d.part_envs = (uint32_t)((per + 63) / 64 * 64);
 }
 
 }  // namespace
@@ -438,13 +458,14 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         const int rc = alloc_tier(sim, c, div[c]);
         if (rc != PCC_OK) { pcc_destroy(sim); return rc; }
     }
-    int32_t tops[kMaxTiers] = {0, 0, 0, 0};
-    for (int c = 1; c < d.n_tiers; c++) tops[c] = (int32_t)sim->tier_slots[c];
-    if (hipMemset(sim->state_blob, 0, sim->state_bytes) != hipSuccess ||
-        hipMemcpy(d.tier_top, tops, sizeof tops, hipMemcpyHostToDevice) != hipSuccess) {
+    // partitions: batches that run with work lists (every XCD then keeps to its own eighth of the rings); smaller ones and
+    // whatever runs without lists gain nothing from them
+    set_parts(sim, n_envs >= 8192 ? kParts : 1u);
+    if (hipMemset(sim->state_blob, 0, sim->state_bytes) != hipSuccess) {
         pcc_destroy(sim);
         return fail(PCC_EHIP, "initialising the env state failed");
     }
+    if (init_pool_stacks(sim) != PCC_OK) { pcc_destroy(sim); return PCC_EHIP; }
     if (kProfile && getenv("PCC_DEBUG_TIMELINE") && atoi(getenv("PCC_DEBUG_TIMELINE"))) {  // profile build only
         sim->timeline_bytes = (size_t)n_envs * 4 * 8 * sizeof(uint64_t);
         if (hipMalloc(&sim->timeline_blob, sim->timeline_bytes) != hipSuccess ||
@@ -457,7 +478,8 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         d.pass_counters = atoi(getenv("PCC_DEBUG_TIMELINE")) >= 2;
     }
     // the send half's work lists: two buffers of kClasses lists, each able to hold every env
-    sim->list_bytes = (size_t)2 * kListRows * (size_t)n_envs * sizeof(uint32_t);
+    // (room for either partitioning: kParts partitions of part_envs rounded up to 64, or one of n_envs)
+    sim->list_bytes = (size_t)2 * kListRows * ((size_t)n_envs + 64 * kParts) * sizeof(uint32_t);
     if (hipMalloc(&sim->list_blob, sim->list_bytes) != hipSuccess) {
         pcc_destroy(sim);
         return fail(PCC_ENOMEM, "hipMalloc(%zu) for the send work lists failed", sim->list_bytes);
@@ -467,8 +489,6 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     sim->fill_buf = 0;
     sim->list_min_envs = 8192;
     sim->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    sim->split_streams = 0;
-    sim->light_front_wgs = 0;   // (measured on one handle: 0 -> 0.1076 ms, 8 -> 0.1107, 64 -> 0.1112)
     sim->retire_grid_frac = 0.125;
     sim->restart_fork = 0;   // (measured, bench --stagger: behind the main launch 0.153 ms, beside it 0.166)
     if (hipStreamCreateWithFlags(&sim->aux_wave, hipStreamNonBlocking) != hipSuccess ||
@@ -538,7 +558,6 @@ void pcc_destroy(pcc_sim_t *sim) {
     if (sim->state_blob) (void)hipFree(sim->state_blob);
     for (int c = 0; c < kMaxTiers; c++) {
         if (sim->tier_blob[c]) (void)hipFree(sim->tier_blob[c]);
-        if (sim->tier_free_blob[c]) (void)hipFree(sim->tier_free_blob[c]);
     }
     delete sim;
 }
@@ -632,14 +651,27 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             if (!(value >= 0.0 && value <= 1.0)) return fail(PCC_EINVAL, "retire_grid_frac must be in [0, 1]");
             sim->retire_grid_frac = value;
             return PCC_OK;
-        case PCC_TUNE_LIGHT_FRONT_WGS:
-            if (!(value >= 0.0 && value <= 65536.0)) return fail(PCC_EINVAL, "light_front_wgs out of range");
-            sim->light_front_wgs = (unsigned)value;
-            return PCC_OK;
+        case PCC_TUNE_LIGHT_FRONT_WGS:   // (round 4 experiments; measured slower and removed: profiles/r04_experiments.json)
         case PCC_TUNE_SPLIT_STREAMS:
-            if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_tuning(SPLIT_STREAMS) between pcc_step_send and pcc_step_retire");
-            sim->split_streams = value != 0.0 ? 1 : 0;
+            if (value != 0.0) return fail(PCC_EINVAL, "tuning key %d was an experiment of round 4 and is gone (only 0 is accepted)", key);
             return PCC_OK;
+        case PCC_TUNE_PARTS: {
+            if (value != 1.0 && value != (double)kParts) return fail(PCC_EINVAL, "parts must be 1 or %u", kParts);
+            if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_tuning(PARTS) between pcc_step_send and pcc_step_retire");
+            if ((uint32_t)value == sim->d.parts) return PCC_OK;
+            // the pool stacks are per partition: everybody back into tier 0, the stacks rebuilt -- a reset must follow
+            DeviceGuard guard(sim->device);
+            if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "hipDeviceSynchronize failed");
+            set_parts(sim, (uint32_t)value);
+            const int rc = init_pool_stacks(sim);
+            if (rc != PCC_OK) return rc;
+            launch_forget_ring_slots(sim->d, nullptr);
+            if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "forget_ring_slots_kernel failed");
+            sim->ever_reset = false;
+            sim->restarts_pending = false;
+            sim->read_buf = -1;
+            return PCC_OK;
+        }
         case PCC_TUNE_RETIRE_WIDE_PREDICT:
             if (!(value >= 0.0)) return fail(PCC_EINVAL, "retire_wide_predict out of range");
             sim->d.retire_wide_predict = value >= 1e9 ? 1e9f : (float)value;
@@ -669,13 +701,11 @@ int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t di
     DeviceGuard guard(sim->device);
     if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "hipDeviceSynchronize failed");
     Dev &d = sim->d;
-    int32_t tops[kMaxTiers] = {0, 0, 0, 0};
     for (int c = 1; c < d.n_tiers; c++) {
         const int rc = alloc_tier(sim, c, div[c]);
         if (rc != PCC_OK) return rc;
-        tops[c] = (int32_t)sim->tier_slots[c];
     }
-    if (hipMemcpy(d.tier_top, tops, sizeof tops, hipMemcpyHostToDevice) != hipSuccess) return fail(PCC_EHIP, "resetting the pool stacks failed");
+    { const int rc = init_pool_stacks(sim); if (rc != PCC_OK) return rc; }
     launch_forget_ring_slots(d, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "forget_ring_slots_kernel failed");
     sim->ever_reset = false;  // whatever was in flight lived in the old pools: a reset must follow

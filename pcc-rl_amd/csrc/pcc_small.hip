@@ -81,9 +81,10 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
     const int64_t i = (int64_t)blockIdx.x * kWave + threadIdx.x;
     if (all_envs) {
         for (int c = 1; c < D.n_tiers; c++) {
-            const int64_t slots = (int64_t)D.tier_slots[c];
-            for (int64_t j = i; j < slots; j += (int64_t)gridDim.x * kWave) D.tier_free[c][j] = (uint32_t)(slots - 1 - j);
-            if (i == 0) D.tier_top[c] = (int32_t)slots;
+            const int64_t share = (int64_t)D.pool_share[c], slots = share * D.parts;   // (every partition's stack: its lowest slot on top)
+            for (int64_t j = i; j < slots; j += (int64_t)gridDim.x * kWave)
+                D.pool_free[(size_t)c * D.pool_free_stride + j] = (uint32_t)(j / share * share + (share - 1 - j % share));
+            if (i < (int64_t)D.parts) D.tier_top[(size_t)(c * kParts + i) * kTopStride] = (int32_t)share;
         }
     }
     if (i >= D.n) return;

@@ -526,16 +526,18 @@ def test_two_senders_out_of_lockstep_match_oracle():
     env.close()
 
 
-@pytest.mark.parametrize("knobs", [dict(split_streams=1), dict(light_snake=0, wave_oldest_first=0, light_front_wgs=0), dict(light_front_wgs=3),
-                                   dict(prio_level=2, prio_light_items=8, prio_wave_items=8, prio_team=1, team_predict=600.0),
-                                   dict(send_waves=1), dict(send_waves=32, heavy_item_packets=0.0)])
+@pytest.mark.parametrize("knobs", [dict(), dict(parts=8), dict(parts=8, send_waves=1), dict(parts=8, retire_wide_predict=0.0),
+                                   dict(parts=8, retire_sorted=0), dict(light_snake=0, wave_oldest_first=0),
+                                   dict(parts=8, prio_level=2, prio_light_items=8, prio_wave_items=8, prio_team=1, team_predict=600.0),
+                                   dict(send_waves=1), dict(parts=8, send_waves=32, heavy_item_packets=0.0)])
 def test_launch_shape_of_the_send_half_does_not_matter(knobs):
-    """The send half is one launch with two kinds of workgroup (or, split_streams, two kernels on two streams); which
-    workgroup or wavefront sends an env, in which order and at which priority, must never change a result (and every env must
-    be sent exactly once: a dealing that is not a bijection would send an env twice or not at all)."""
+    """The send half is one launch with two kinds of workgroup, every workgroup working for one partition of the batch (1 or
+    8 of them); which workgroup or wavefront sends or retires an env, in which order and at which priority, must never change
+    a result (and every env must be handled exactly once: a dealing that is not a bijection would send an env twice or not
+    at all).  3 000 envs with work lists forced on: partitions of 384 envs, the last one partly filled."""
     n_envs, n_steps, seed = 3000, 40, 17
     env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=False)
-    env.set_tuning(**knobs)
+    env.set_tuning(list_min_envs=0, **knobs)
     env.reset()
     acts = np.random.RandomState(seed).uniform(-1, 1.5, (n_envs, n_steps))
     steps, obs, done = run_gpu(env, acts, n_steps)
