@@ -210,7 +210,10 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     stacks of their own; workgroup b of a launch works for partition b % 8, i.e. an XCD keeps to
                                     one eighth of the rings (a scattered access costs 2.5x as much once the addresses an XCD
                                     touches span more than ~2 GB).  Default 8 from 8 192 envs up, else 1.  Changing it puts every
-                                    sender back into its own tier-0 rings: pcc_reset must follow */ };
+                                    sender back into its own tier-0 rings: pcc_reset must follow */,
+       PCC_TUNE_LIGHT_HALF_PREDICT = 25 /* send launch: light items of the classes from this many predicted packets per interval up
+                                    hold 32 envs instead of 64 (a lane-round iteration costs ~3.3 ns per lane that stores, and the
+                                    longest light items are the launch's critical path); >= 1e9 = none */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* Sizes of the shared ring pools (see pcc_create): tiers 1, 2, 3 get a slot for one sender in div1, div2, div3 (defaults

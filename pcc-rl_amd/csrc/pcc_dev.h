@@ -176,6 +176,7 @@ struct Dev {
     double heavy_predict;  // predicted packets per MI above which an env goes to the heavy wave
     double team_predict;   // ... above which a whole workgroup sends it (team pass)
     float heavy_item_packets;  // a heavy work item is as many envs of its class as make up about this many packets (1..8 envs)
+    float light_half_predict;  // light items of the classes from this many predicted packets up hold 32 envs instead of 64
     float retire_wide_predict; // retire half: envs predicted above this many packets per interval get 16 lanes instead of 8
     double lo[5], hi[5];
     int rng_mode;

@@ -30,8 +30,7 @@ __global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIR
     __shared__ uint32_t s_env[kRetireMaxPerBlock], s_cls[kRetireMaxPerBlock], s_arrived;
     const uint32_t tid = threadIdx.x;
     if (prof_on(D) && !warm) {  // profile build: the send items' timeline slots are cleared for the next send launch
-        const int64_t tl_slots = 2 * D.n + 64 * kParts < 3 * D.n ? 2 * D.n + 64 * kParts : 3 * D.n;   // (pcc_send.hip / pcc_send_bodies.h: tl_base)
-        for (int64_t slot = (int64_t)blockIdx.x * kRetireBlock + tid; slot < tl_slots; slot += (int64_t)gridDim.x * kRetireBlock)
+        for (int64_t slot = (int64_t)blockIdx.x * kRetireBlock + tid; slot < 2 * D.n; slot += (int64_t)gridDim.x * kRetireBlock)
             D.timeline[slot * 8] = 0;
     }
     const uint32_t lane = tid & (kWave - 1);

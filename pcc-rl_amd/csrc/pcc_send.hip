@@ -51,8 +51,8 @@ __global__ __launch_bounds__(4 * kWave, NS == 2 ? PCC_SEND_OCC2 : PCC_SEND_OCC) 
     if (b < wave_wgs) {
         wave_body<NS, TRACE>(D, lds, lane, wv, wave_wgs, read_buf, actions, actions_f64);
     } else {
-        // profile build: the timeline slots of a partition's light items (at most part_envs / 64 + a partial one per class)
-        const uint32_t tl_base = part * (D.part_envs / 64u + (uint32_t)kClasses + 1u);
+        // profile build: the timeline slots of a partition's light items (at most part_envs / 32 + a partial one per class)
+        const uint32_t tl_base = part * (D.part_envs / 32u + (uint32_t)kClasses + 1u);
         light_body<NS, TRACE>(D, lds, lane, wv, (b - wave_wgs) / P, (gridDim.x - wave_wgs) / P, (int)list_view(D, read_buf, part), tl_base,
                               warm, warm_mi, actions, actions_f64);
     }

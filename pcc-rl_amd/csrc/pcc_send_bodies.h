@@ -35,12 +35,18 @@ __device__ __forceinline__ void light_body(const Dev &D, SendLds<NS> &lds, const
     const uint32_t E = D.send_envs_per_wave;
     const bool listed = view >= 0;
     const int cls_heavy = D.use_cwnd ? kClasses : (D.heavy_predict >= 1e9 ? kClasses : class_of((float)D.heavy_predict));
-    // lane l looks after light class cls_heavy - 1 - l (longest first); inclusive prefix of the items per class
+    // lane l looks after light class cls_heavy - 1 - l (longest first); inclusive prefix of the items per class.
+    // The longest classes (from light_half_predict packets up) go 32 envs to an item instead of 64: an iteration of the lane
+    // rounds is one scattered store instruction, which costs the wavefront ~3.3 ns per line it touches (64 lanes: ~215 ns;
+    // 32: ~100 ns, below the ~160 ns of arithmetic) -- and the longest light items are the launch's critical path, while
+    // two thirds of the launch's wavefront slots idle (tools/microbench/store_bench5, tools/send_timeline.py)
     const int cls_mine = cls_heavy - 1 - (int)lane;
+    const int cls_half = D.light_half_predict >= 1e9f ? kClasses : class_of(D.light_half_predict);
+    const uint32_t E_mine = (cls_mine >= cls_half && E >= 2u) ? E / 2u : E;
     uint32_t n_mine = 0, items_mine = 0;
     if (listed && cls_mine >= 0) {
         n_mine = *cls_count_of(D, (uint32_t)view, (uint32_t)cls_mine);
-        items_mine = (n_mine + E - 1) / E;
+        items_mine = (n_mine + E_mine - 1) / E_mine;
     }
     uint32_t incl = items_mine;
     for (int o = 1; o < kClasses; o <<= 1) {
@@ -60,8 +66,9 @@ __device__ __forceinline__ void light_body(const Dev &D, SendLds<NS> &lds, const
             const uint32_t off = t - (rl_u32(incl, L) - rl_u32(items_mine, L));
             const uint32_t n_cls = rl_u32(n_mine, L);
             const uint32_t *list = cls_list_of(D, (uint32_t)view, (uint32_t)(cls_heavy - 1 - (int)L));
-            const uint32_t idx = off * E + lane;
-            has = lane < E && idx < n_cls;
+            const uint32_t E_cls = rl_u32(E_mine, L);
+            const uint32_t idx = off * E_cls + lane;
+            has = lane < E_cls && idx < n_cls;
             i = has ? (int64_t)list[idx] : 0;
         } else {
             i = (int64_t)t * E + lane;
@@ -137,8 +144,9 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // profile build: timeline slots of this partition's items (the light items' come first, pcc_send.hip)
-        const uint32_t tl_base = (uint32_t)D.n + pv * D.part_envs;
+        // profile build: timeline slots of this partition's items (the light items' come first, pcc_send.hip; the item slots
+        // end at 2 n: the last partition's range is cut there when n is not a multiple of 64 * parts)
+        const uint32_t tl_base = (uint32_t)D.n + pv * D.part_envs, tl_end = 2u * (uint32_t)D.n;
         // ---- team items
         const uint32_t n_tw = n_team < team_wgs_max ? n_team : team_wgs_max;  // workgroups that have team items
         if constexpr (kTeams) {
@@ -150,7 +158,7 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
                     const uint32_t off = tt - (uni_u32(tab[4][L]) - uni_u32(tab[5][L]));
                     const uint32_t *list = cls_list_of(D, view, kClasses - 1u - L);
                     const int64_t i = lane == 0 ? (int64_t)list[off] : 0;
-                    (void)send_wave_item<NS, TRACE, kTeams ? kTeamMax : 1>(D, lane, i, lane == 0, true, tl_base + n_items + tt, 0, 0, actions,
+                    (void)send_wave_item<NS, TRACE, kTeams ? kTeamMax : 1>(D, lane, i, lane == 0, true, tl_base + n_items + tt < tl_end ? tl_base + n_items + tt : 0xFFFFFFFFu, 0, 0, actions,
                                                                            actions_f64, lds.slots[wv], wv, &lds.team);
                 }
                 if (D.prio_team) set_prio(0u);
@@ -195,7 +203,7 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
             const int64_t i = has ? (int64_t)list[idx] : 0;
             const bool prio = t < D.prio_wave_items;
             if (prio) set_prio(D.prio_level);
-            (void)send_wave_item<NS, TRACE, 1>(D, lane, i, has, true, tl_base + t, 0, 0, actions, actions_f64, lds.slots[wv]);
+            (void)send_wave_item<NS, TRACE, 1>(D, lane, i, has, true, tl_base + t < tl_end ? tl_base + t : 0xFFFFFFFFu, 0, 0, actions, actions_f64, lds.slots[wv]);
             if (prio) set_prio(0u);
             t = n_items;  // forces a claim
         }

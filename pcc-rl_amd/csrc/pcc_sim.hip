@@ -147,7 +147,9 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
         return check_hip(hipGetLastError(), "send kernel launch");
     }
     const int64_t P = d.parts;
-    const int64_t light_items_part = ((int64_t)d.part_envs + E - 1) / E + kClasses;
+    // (the classes from light_half_predict up go E / 2 envs to an item: the worst case is all of them)
+    const int64_t E_min = d.light_half_predict < 1e9f && E >= 2 ? E / 2 : E;
+    const int64_t light_items_part = ((int64_t)d.part_envs + E_min - 1) / E_min + kClasses;
     const unsigned light_grid = (unsigned)(P * ((light_items_part + 3) / 4));
     // restart items can only be in lists that a retire launch with `restart` filed
     const bool rs = sim->read_has_restarts;
@@ -406,12 +408,16 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.send_waves = 12;  // persistent wavefronts of the wave kernel per compute unit (beside them: the light kernel's items)
     d.send_envs_per_wave = 64;
     // (two senders: the lane rounds cost about the same per packet as with one, the wave passes more -- 64 positions per pass)
-    d.heavy_predict = n_senders == 2 ? 1024.0 : 512.0;
+    // (measured on one handle each, profiles/r04_experiments.json -- heavy_predict / heavy_item_packets: config 5
+    // 1024 / 2048 -> 0.252 ms per send launch, 640-768 / 768-1024 -> 0.219-0.223; config 3 512 / 2048 -> 0.0988,
+    // 384 / 1024 -> 0.0942, 320 / 768 -> 0.105: the longest light items are the launch's critical path down to ~384)
+    d.heavy_predict = n_senders == 2 ? 640.0 : 384.0;
     d.team_predict = 4096.0;
-    d.heavy_item_packets = 2048.0f;
+    d.heavy_item_packets = 1024.0f;
     // (the wide classes are cut by COUNT in the end: the grid has room for retire_grid_frac of the envs at 16 lanes, the
     // largest; measured on one handle, r04_experiments.json: threshold 1024 -> 0.097 ms, 200-512 with the cut -> 0.091)
     d.retire_wide_predict = 256.0f;
+    d.light_half_predict = 1e9f;
     d.retire_sorted = 1u;
     d.light_snake = 1u;
     d.wave_oldest_first = 1u;
@@ -654,6 +660,10 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
         case PCC_TUNE_LIGHT_FRONT_WGS:   // (round 4 experiments; measured slower and removed: profiles/r04_experiments.json)
         case PCC_TUNE_SPLIT_STREAMS:
             if (value != 0.0) return fail(PCC_EINVAL, "tuning key %d was an experiment of round 4 and is gone (only 0 is accepted)", key);
+            return PCC_OK;
+        case PCC_TUNE_LIGHT_HALF_PREDICT:
+            if (!(value >= 0.0)) return fail(PCC_EINVAL, "light_half_predict out of range");
+            sim->d.light_half_predict = value >= 1e9 ? 1e9f : (float)value;
             return PCC_OK;
         case PCC_TUNE_PARTS: {
             if (value != 1.0 && value != (double)kParts) return fail(PCC_EINVAL, "parts must be 1 or %u", kParts);

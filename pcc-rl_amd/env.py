@@ -182,13 +182,13 @@ class BatchedNetworkEnv(object):
     def set_tuning(self, round_packets=None, takeover_lanes=None, send_envs_per_wave=None, heavy_predict=None,
                    send_waves=None, team_predict=None, heavy_item_packets=None, retire_wide_predict=None, list_min_envs=None,
                    retire_sorted=None, light_snake=None, wave_oldest_first=None, prio_level=None, prio_light_items=None,
-                   prio_wave_items=None, prio_team=None, retire_grid_frac=None, restart_fork=None, parts=None):
+                   prio_wave_items=None, prio_team=None, retire_grid_frac=None, restart_fork=None, parts=None, light_half_predict=None):
         """Performance knobs (results do not depend on them); see pcc_set_tuning in include/pcc_sim.h.  `parts` (the
         partitioning of the batch) must be followed by reset()."""
         for key, value in ((2, round_packets), (3, takeover_lanes), (4, send_envs_per_wave), (5, heavy_predict),
                            (8, send_waves), (9, team_predict), (10, heavy_item_packets), (11, retire_wide_predict), (12, list_min_envs),
                            (13, retire_sorted), (14, light_snake), (15, wave_oldest_first), (16, prio_level), (17, prio_light_items),
-                           (18, prio_wave_items), (19, prio_team), (22, retire_grid_frac), (23, restart_fork), (24, parts)):
+                           (18, prio_wave_items), (19, prio_team), (22, retire_grid_frac), (23, restart_fork), (24, parts), (25, light_half_predict)):
             if value is not None:
                 check(self._L.pcc_set_tuning(self._h, key, float(value)))
 

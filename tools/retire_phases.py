@@ -17,12 +17,16 @@ env.reset()
 names = {3: "state loads", 4: "boundary search", 5: "candidates+repairs", 6: "ending event", 7: "write-back",
          8: "rtt_means", 9: "metrics+batch loads", 10: "history+obs", 11: "outputs"}
 out = []
+prev = None
 for t in range(310):
     env.step(acts[t % 64])
+    if t in (19, 99, 199, 299):
+        prev = env.debug_timeline().astype(np.int64)[2 * N:].reshape(-1, 16)
     if t in (20, 100, 200, 300):
         raw = env.debug_timeline().astype(np.int64)
-        n_items = int(env.debug_pass_stats(reset=False)["items"])
-        bl = raw[n_items:].reshape(-1, 16)          # one row per retire workgroup
+        # one row per retire workgroup, behind the 2 n item slots of the send half; the phase sums (and the search counters)
+        # accumulate over the launches: this launch's share is the difference to the step before
+        bl = raw[2 * N:].reshape(-1, 16) - prev
         waves = (N + 3) // 4                        # 16 lanes per env
         rec = {"step": t, "us_per_wavefront": {v: float(bl[:, k].sum()) / 100.0 / waves for k, v in names.items()}}
         rec["us_per_wavefront"]["total"] = sum(rec["us_per_wavefront"].values())
