@@ -221,3 +221,38 @@ def test_saturating_policy_at_full_size_with_default_pools():
     assert not problem, problem
     print("saturating policy: senders by ring tier", [int((tiers == c).sum()) for c in range(4)], "device GB", env.device_bytes / 1e9)
     env.close()
+
+
+def test_a_partition_that_outgrows_its_share_of_a_pool_takes_the_others():
+    """The ring pools are cut into one stack per partition of the batch (pcc_dev.h "partitions": an XCD keeps to one eighth of
+    every pool).  Here only the envs of partition 0 are driven to the rate limit, with pools of a quarter of the senders: they
+    need four times their own share of tiers 1 and 2 and take it from the other partitions' stacks -- no flag, slots of
+    foreign shares in use, results equal to the oracle -- and when the pools are made too small for them the exhaustion is
+    flagged, never silent."""
+    n, steps, M = 8192, 160, 192
+    native = pcc_rl_amd.native
+    for divisors, expect_flag in (((4, 4, 4), False), ((64, 64, 64), True)):
+        env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=5, record_steps=True, auto_reset=False, ring_pools=divisors)
+        env.reset()
+        part0 = torch.arange(n, device=DEV) < n // 8
+        gen = torch.Generator(device=DEV).manual_seed(7)
+        rows, acts = [], []
+        for t in range(steps):
+            up = torch.rand((n,), generator=gen, device=DEV, dtype=torch.float32) * 2          # U(0, 2): towards MAX_RATE
+            a = torch.where(part0, up, torch.full_like(up, -1.0))                              # everybody else towards MIN_RATE
+            o, r, d, info = env.step(a)
+            rows.append(info["steps"][:M].clone())
+            acts.append(a[:M].clone())
+        torch.cuda.synchronize()
+        flags = env.state("flags").cpu().numpy()
+        tiers = env.state("ring_tier").cpu().numpy()
+        if expect_flag:
+            assert ((flags & native.PCC_FLAG_POOL_EXHAUSTED) != 0).any(), "pools of 256 slots per tier cannot hold 1 024 saturated senders"
+        else:
+            assert not flags.any(), "flagged envs: %d" % int((flags != 0).sum())
+            promoted = int((tiers[: n // 8] >= 1).sum())
+            assert promoted > n // 8 // 4 * 2, "partition 0 holds %d pool slots: not beyond its own share of %d" % (promoted, n // 8 // 4)
+            ref = oracle.run_batch(torch.stack(acts, 1).to(torch.float64).cpu().numpy(), rng_mode=oracle.RNG_PHILOX, seed=5, want_obs=False)
+            problem = _first_mismatch(torch.stack(rows, 1).cpu().numpy(), ref["steps"], "partition 0 on borrowed pool slots, first %d envs" % M)
+            assert not problem, problem
+        env.close()
