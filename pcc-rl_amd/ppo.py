@@ -9,9 +9,12 @@ buffers, advantage estimation, updates -- lives on the GPU and the env never lea
 
 This is a caller of the hot path, not part of it: stable-baselines is not available in this
 image, so there is nothing to check agent-level parity against.  What is
-checked: the GAE recursion and the clipped objective against plain loops (CPU tests), that a short
-run on the GPU improves the return, and what the whole loop costs next to the env alone
-(tools/ppo_throughput.py).
+checked (tests/test_ppo.py): the GAE recursion and the clipped objective against plain loops (CPU
+tests); on the GPU the HIP kernels of the fused path -- policy forward (pcc_policy.hip), the
+fp32-MFMA gradient kernel and the Adam step (pcc_ppo.hip: pcc_ppo_minibatch_step), the GAE kernel
+-- against float64 autograd, torch.optim.Adam and the loop; that a short run on the GPU improves
+the return; and what the whole loop costs next to the env alone (tools/ppo_throughput.py,
+profiles/r04_v2_ppo_throughput.json).
 """
 import math
 
