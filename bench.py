@@ -267,6 +267,11 @@ def main():
     ap.add_argument("--groups", type=int, default=0,
                     help="also measure the same envs as this many independent groups on their own streams "
                          "(supplementary field async_groups)")
+    ap.add_argument("--event-stride", type=int, default=7,
+                    help="HIP events around the two kernels on every this-many-th timed step (recording an event costs the "
+                         "stream ~4.5 us, three per step are 7 %% of a step of config 3: the timed region carries them on a "
+                         "sample of its steps -- 7 is coprime to the episode length, so every episode phase is sampled over a run -- "
+                         "1 = every step)")
     ap.add_argument("--stagger", action="store_true",
                     help="spread the envs' episode phases uniformly over the 400 steps before timing (masked resets "
                          "during an untimed pre-roll): every window then sees the episode-average load, and the "
@@ -397,7 +402,8 @@ def main():
     # HIP events on the launch stream (torch's current stream IS the stream the library launches on); all of them are
     # made before the first run and the packet counters stay on the device until the last one is over, so that the GPU
     # does not sit idle (and clock down) between the warm-up steps and a timed region that may be only a few ms long
-    all_ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)] for _ in range(R)]
+    ES = max(1, args.event_stride)
+    all_ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] if k % ES == 0 else None for k in range(K)] for _ in range(R)]
     sent_marks = [env.state("total_sent").sum()]
     for r in range(R):
         ev = all_ev[r]
@@ -407,7 +413,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(K):
-            one_step(t_global, ev[k])
+            one_step(t_global, ev[k] if k % ES == 0 else None)
             t_global += 1
         torch.cuda.synchronize()
         if world > 1:
@@ -421,10 +427,12 @@ def main():
         runs[r]["elapsed"] = pdist.max_over_ranks(runs[r]["elapsed"], device=dev)     # MAX over ranks (bench contract)
         runs[r]["packets"] = float((sent_marks[r + 1] - sent_marks[r]).item())
         # steps that also ran the episode-boundary reset kernels are kept out of the retire average
-        plain = [k for k in range(K) if (first + k + 1) % max_steps != 0] if not args.stagger else list(range(K))
-        runs[r]["send_ms"] = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
+        timed_k = [k for k in range(K) if k % ES == 0]   # the steps that carry events
+        plain = [k for k in timed_k if (first + k + 1) % max_steps != 0] if not args.stagger else timed_k
+        runs[r]["send_ms"] = sum(ev[k][0].elapsed_time(ev[k][1]) for k in timed_k) / len(timed_k)
         runs[r]["retire_ms"] = sum(ev[k][1].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))
-        runs[r]["first_steps_ms"] = [ev[k][0].elapsed_time(ev[k][2]) for k in range(min(K, 6))]
+        runs[r]["event_steps"] = len(timed_k)
+        runs[r]["first_steps_ms"] = [ev[k][0].elapsed_time(ev[k][2]) for k in timed_k[:6]]
     many = None
     if fused and world == 1 and not args.stagger:
         # a small batch: one step is a 25 us launch, less than a trip around the Python loop above.  Supplementary: the same K
@@ -480,7 +488,10 @@ def main():
             "ms_per_step": 1e3 * med["elapsed"] / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": R, "runs_ms_per_step": [1e3 * r["elapsed"] / K for r in runs],
-            "median_run_kernel_ms": {"send": med["send_ms"], "retire": med["retire_ms"], "first_steps": med["first_steps_ms"]},
+            "median_run_kernel_ms": {"send": med["send_ms"], "retire": med["retire_ms"], "first_steps": med["first_steps_ms"],
+                                     "steps_with_events": med["event_steps"], "event_stride": ES,
+                                     "note": "HIP events around the two kernels on every event_stride-th timed step (an event record "
+                                             "costs the stream ~4.5 us; three on every step are 7 % of a step of config 3)"},
             "spread": (max(r["elapsed"] for r in runs) - min(r["elapsed"] for r in runs)) / med["elapsed"],
             "window": window,
             "config": {"workload": ("BASELINE config %d: %d envs/GPU, %s, U(-1,1) actions, 400-step episodes, auto-reset%s"
