@@ -236,48 +236,59 @@ __device__ __forceinline__ void rotate_to_front(double2 *ring, uint32_t mask, ui
     st_rec(ring + (p & mask), r);
 }
 
-// Records around a search transition b that may be out of event order: b-1 and b themselves plus
-// everything chained to them by near-equal times.  [g0, g1) with h <= g0 <= b <= g1 <= tail.
-__device__ __forceinline__ void near_window(const double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t b,
-                                            uint32_t &g0, uint32_t &g1) {
-    g0 = b;
-    g1 = b;
-    if (b > h) {
-        g0 = b - 1;
-        double t = ld_t1(ring + (g0 & mask));
-        while (g0 > h) {
-            const double tp = ld_t1(ring + ((g0 - 1) & mask));
-            if (!near_time(tp, t)) break;
-            t = tp;
-            g0--;
-        }
-    }
-    if (b < tail) {
-        g1 = b + 1;
-        double t = ld_t1(ring + (b & mask));
-        while (g1 < tail) {
-            const double tn = ld_t1(ring + (g1 & mask));
-            if (!near_time(tn, t)) break;
-            t = tn;
-            g1++;
-        }
-    }
-}
-
-// Exact retire boundary of the dropped ring: on return records [h, p) are exactly those with
-// t1 + dl < end (members of the boundary window that pass are moved in front, the rest keep
-// their order).  Also reports the best hop-2 candidate (smallest (t2, lat2) key) among the
-// window's unretired records that are already past the forward hop (t1 < end).
+// Repairs around a search transition b on the dropped ring, where records may be out of event order: b-1 and b themselves
+// plus everything chained to them by near-equal times -- the near window [g0, g1), h <= g0 <= b <= g1 <= tail.
+//   fix_drop_boundary: the exact retire boundary.  On return records [h, p) are exactly those with t1 + dl < end (members of
+//     the window that pass are moved in front, the rest keep their order); also the best hop-2 candidate (smallest
+//     (t2, lat2) key) among the window's unretired records that are already past the forward hop (t1 < end).
+//   drop_hop1_candidate: smallest (t1, lat) among the window's records still on the forward hop (t1 >= end); c = the search
+//     transition for `t1 < end`.
 // (results by value: reference out-parameters of an out-of-line function live in scratch memory)
 struct DropFix { uint32_t p, cand_idx; double cand_t, cand_lat; };
 struct Cand { double t, lat; };
 
-__device__ __noinline__ DropFix fix_drop_boundary(double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t b,
-                                                  double dl, double end) {
-    uint32_t cand_idx;
-    double cand_t, cand_lat;
-    uint32_t g0, g1;
-    near_window(ring, mask, h, tail, b, g0, g1);
+// ---- by the whole group: G records per memory round trip -------------------------------------------------------------
+// Rounds 1-3 walked a near group record by record on the lead lane, a dependent load each; the envs that overdrive their links --
+// the largest of a launch, the ones it waits for -- drop packets in runs, and their near groups are 5-20 records: 9-22 us of
+// a wide workgroup's 85-90 (tools/retire_timeline.py, profiles/r04_experiments.json).  Here lane l of the group holds record
+// l of the window: the chain of near pairs is a ballot, the stable partition of fix_drop_boundary a pair of prefix counts,
+// the candidates a min-reduction.  Windows of more than G records (rare) are walked by the lead lane, record by record.
+// Every lane returns the same values.
+template <int G>
+__device__ __forceinline__ void near_window_g(const Group &g, const double2 *ring, uint32_t mask, uint32_t h, uint32_t tail,
+                                              uint32_t b, uint32_t &g0, uint32_t &g1) {
+    g0 = b;
+    g1 = b;
+    if (b > h) {
+        g0 = b - 1;
+        for (;;) {
+            // lane l: record g0 - l; pair l = (record g0 - l - 1, record g0 - l), tested as near_time(earlier, later)
+            const bool has = g0 - h >= g.lane;
+            const double t = has ? ld_t1(ring + ((g0 - g.lane) & mask)) : 0.0;
+            const double tp = __shfl(t, (int)((g.lane + 1u) & (uint32_t)(G - 1)), G);
+            const bool nr = g.lane + 1u < (uint32_t)G && g0 - h >= g.lane + 1u && near_time(tp, t);
+            const uint32_t run = (uint32_t)__ffs((int)~gballot<G>(g, nr)) - 1u;  // near pairs from pair 0 on (pair G-1 never is)
+            g0 -= run;
+            if (run < (uint32_t)G - 1u) break;
+        }
+    }
+    if (b < tail) {
+        g1 = b + 1;
+        for (;;) {
+            // lane l: record g1 - 1 + l; pair l = (record g1 - 1 + l, record g1 + l), tested as near_time(later, earlier)
+            const bool has = g1 - 1u + g.lane < tail;
+            const double t = has ? ld_t1(ring + ((g1 - 1u + g.lane) & mask)) : 0.0;
+            const double tn = __shfl(t, (int)((g.lane + 1u) & (uint32_t)(G - 1)), G);
+            const bool nr = g.lane + 1u < (uint32_t)G && g1 + g.lane < tail && near_time(tn, t);
+            const uint32_t run = (uint32_t)__ffs((int)~gballot<G>(g, nr)) - 1u;
+            g1 += run;
+            if (run < (uint32_t)G - 1u) break;
+        }
+    }
+}
+
+// the serial tail of fix_drop_boundary over a window that is already known
+__device__ __forceinline__ DropFix fix_drop_window(double2 *ring, uint32_t mask, uint32_t g0, uint32_t g1, double dl, double end) {
     uint32_t p = g0;
     for (uint32_t k = g0; k < g1; k++) {
         const double2 r = ld_rec(ring + (k & mask));
@@ -286,36 +297,103 @@ __device__ __noinline__ DropFix fix_drop_boundary(double2 *ring, uint32_t mask, 
             p++;
         }
     }
-    cand_idx = 0xFFFFFFFFu;
-    cand_t = INFINITY;
-    cand_lat = 0.0;
+    DropFix out;
+    out.p = p; out.cand_idx = 0xFFFFFFFFu; out.cand_t = INFINITY; out.cand_lat = 0.0;
     for (uint32_t k = p; k < g1; k++) {
         const double2 r = ld_rec(ring + (k & mask));
         if (r.x < end) {
             const double t2 = r.x + dl, l2 = r.y + dl;
-            if (cand_idx == 0xFFFFFFFFu || t2 < cand_t || (t2 == cand_t && l2 < cand_lat)) {
-                cand_idx = k; cand_t = t2; cand_lat = l2;
+            if (out.cand_idx == 0xFFFFFFFFu || t2 < out.cand_t || (t2 == out.cand_t && l2 < out.cand_lat)) {
+                out.cand_idx = k; out.cand_t = t2; out.cand_lat = l2;
             }
         }
     }
-    DropFix out;
-    out.p = p; out.cand_idx = cand_idx; out.cand_t = cand_t; out.cand_lat = cand_lat;
     return out;
 }
 
-// Best hop-1 candidate of the dropped ring: smallest (t1, lat) among the records still on the
-// forward hop (t1 >= end); c = search transition for `t1 < end`.
-__device__ __noinline__ Cand drop_hop1_candidate(const double2 *ring, uint32_t mask, uint32_t h, uint32_t tail, uint32_t c,
-                                                 double end) {
-    uint32_t g0, g1;
-    near_window(ring, mask, h, tail, c, g0, g1);
-    double cand_t = INFINITY, cand_lat = 0.0;
-    for (uint32_t k = g0; k < g1; k++) {
-        const double2 r = ld_rec(ring + (k & mask));
-        if (!(r.x < end) && (r.x < cand_t || (r.x == cand_t && r.y < cand_lat))) { cand_t = r.x; cand_lat = r.y; }
+// smallest (t, lat, idx) over the group's lanes that have one (idx 0xFFFFFFFF: none); every lane gets the result
+template <int G>
+__device__ __forceinline__ void gmin_key(double &t, double &lat, uint32_t &idx) {
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) {
+        const double ot = __shfl_xor(t, o, G), ol = __shfl_xor(lat, o, G);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)idx, o, G);
+        const bool take = oi != 0xFFFFFFFFu && (idx == 0xFFFFFFFFu || ot < t || (ot == t && (ol < lat || (ol == lat && oi < idx))));
+        if (take) { t = ot; lat = ol; idx = oi; }
     }
+}
+
+// fix_drop_boundary by the group (all its lanes call; the caller fences before anybody reads the ring again)
+template <int G>
+__device__ __noinline__ DropFix fix_drop_boundary_g(uint32_t g_lane, uint32_t g_shift, double2 *ring, uint32_t mask, uint32_t h,
+                                                    uint32_t tail, uint32_t b, double dl, double end) {
+    Group g;   // (scalars in, not the struct: a struct argument of an out-of-line function goes through scratch memory)
+    g.lane = g_lane; g.shift = g_shift;
+    uint32_t g0, g1;
+    near_window_g<G>(g, ring, mask, h, tail, b, g0, g1);
+    const uint32_t n = g1 - g0;
+    DropFix out;
+    if (n > (uint32_t)G) {
+        if (g.lane == 0) out = fix_drop_window(ring, mask, g0, g1, dl, end);
+        out.p = gbcast<G>(out.p, 0); out.cand_idx = gbcast<G>(out.cand_idx, 0);
+        out.cand_t = gbcast<G>(out.cand_t, 0); out.cand_lat = gbcast<G>(out.cand_lat, 0);
+        return out;
+    }
+    const bool in = g.lane < n;
+    double2 r;
+    r.x = 0.0; r.y = 0.0;
+    if (in) r = ld_rec(ring + ((g0 + g.lane) & mask));
+    const bool pass = in && (r.x + dl < end);
+    const uint32_t below = (1u << g.lane) - 1u;
+    const uint32_t mp = gballot<G>(g, pass), mf = gballot<G>(g, in && !pass);
+    const uint32_t npass = (uint32_t)__popc(mp);
+    // stable partition: the passing records to the front in their order, the others behind them in theirs (what moving each
+    // passing record in front of the first one that does not pass, one by one, comes to)
+    const uint32_t newpos = pass ? (uint32_t)__popc(mp & below) : npass + (uint32_t)__popc(mf & below);
+    if (in && newpos != g.lane) st_rec(ring + ((g0 + newpos) & mask), r);
+    out.p = g0 + npass;
+    // best hop-2 candidate among the unretired records of the window that are past the forward hop; ties: the first in ring order
+    const bool elig = in && !pass && r.x < end;
+    double ct = elig ? r.x + dl : INFINITY, cl = elig ? r.y + dl : 0.0;
+    uint32_t ci = elig ? g0 + newpos : 0xFFFFFFFFu;
+    gmin_key<G>(ct, cl, ci);
+    out.cand_idx = ci;
+    out.cand_t = ci != 0xFFFFFFFFu ? ct : INFINITY;
+    out.cand_lat = ci != 0xFFFFFFFFu ? cl : 0.0;
+    return out;
+}
+
+// drop_hop1_candidate by the group
+template <int G>
+__device__ __noinline__ Cand drop_hop1_candidate_g(uint32_t g_lane, uint32_t g_shift, const double2 *ring, uint32_t mask, uint32_t h,
+                                                   uint32_t tail, uint32_t c, double end) {
+    Group g;
+    g.lane = g_lane; g.shift = g_shift;
+    uint32_t g0, g1;
+    near_window_g<G>(g, ring, mask, h, tail, c, g0, g1);
+    const uint32_t n = g1 - g0;
     Cand out;
-    out.t = cand_t; out.lat = cand_lat;
+    if (n > (uint32_t)G) {
+        out.t = INFINITY; out.lat = 0.0;
+        if (g.lane == 0) {
+            for (uint32_t k = g0; k < g1; k++) {
+                const double2 r = ld_rec(ring + (k & mask));
+                if (!(r.x < end) && (r.x < out.t || (r.x == out.t && r.y < out.lat))) { out.t = r.x; out.lat = r.y; }
+            }
+        }
+        out.t = gbcast<G>(out.t, 0); out.lat = gbcast<G>(out.lat, 0);
+        return out;
+    }
+    const bool in = g.lane < n;
+    double2 r;
+    r.x = 0.0; r.y = 0.0;
+    if (in) r = ld_rec(ring + ((g0 + g.lane) & mask));
+    const bool elig = in && !(r.x < end);
+    double ct = elig ? r.x : INFINITY, cl = elig ? r.y : 0.0;
+    uint32_t ci = elig ? g.lane : 0xFFFFFFFFu;
+    gmin_key<G>(ct, cl, ci);
+    out.t = ci != 0xFFFFFFFFu ? ct : INFINITY;
+    out.lat = ci != 0xFFFFFFFFu ? cl : 0.0;
     return out;
 }
 
@@ -1003,12 +1081,11 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             if (bnd[2].clean) {
                 if (pd < td[s] && bnd[2].t < end) { dk = pd; d2_t = bnd[2].t + dl; d2_l = bnd[2].lat + dl; }
             } else {
-                if (lead) {
-                    const DropFix fx = fix_drop_boundary(rd[s], dmasks[s], hd[s], td[s], bnd[2].b, dl, end);
+                {   // (by the whole group: a near group is one round trip, not one per record)
+                    const DropFix fx = fix_drop_boundary_g<G>(g.lane, g.shift, rd[s], dmasks[s], hd[s], td[s], bnd[2].b, dl, end);
                     pd = fx.p; dk = fx.cand_idx; d2_t = fx.cand_t; d2_l = fx.cand_lat;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                pd = gbcast<G>(pd, 0); dk = gbcast<G>(dk, 0); d2_t = gbcast<G>(d2_t, 0); d2_l = gbcast<G>(d2_l, 0);
                 rotated = true;  // records may have moved inside the window
             }
             lost[s] = pd - hd[s];                                    // ns:141-143
@@ -1019,11 +1096,8 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             } else if (td[s] != pd) {
                 const uint32_t cd = rotated ? search_boundary<G>(g, rd[s], dmasks[s], pd, td[s], 0.0, end)
                                             : (bnd[3].b < pd ? pd : bnd[3].b);
-                if (lead) {
-                    const Cand c1 = drop_hop1_candidate(rd[s], dmasks[s], pd, td[s], cd, end);
-                    d1_t = c1.t; d1_l = c1.lat;
-                }
-                d1_t = gbcast<G>(d1_t, 0); d1_l = gbcast<G>(d1_l, 0);
+                const Cand c1 = drop_hop1_candidate_g<G>(g.lane, g.shift, rd[s], dmasks[s], pd, td[s], cd, end);
+                d1_t = c1.t; d1_l = c1.lat;
             }
             // ---- best of each kind by the heap key (time, latency, dropped): ns:111,161,178
             t_h1[s] = (d1_t < a1_t || (d1_t == a1_t && d1_l < a1_l)) ? d1_t : a1_t;
