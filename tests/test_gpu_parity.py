@@ -410,6 +410,34 @@ def test_edge_links_match_oracle(params, feats, hist):
     env.close()
 
 
+@pytest.mark.parametrize("params", [
+    (100.0, 0.1, 3.0, 0.0, 1000.0),     # ten times overdriven: ~9 drops between two accepted packets
+    (45.0, 0.08, 2.0, 0.01, 1000.0),    # twenty-two times: near groups longer than a 16-lane group
+    (250.0, 0.05, 1.0, 0.03, 900.0),    # a queue of one packet, random losses in between
+])
+@pytest.mark.parametrize("wide", [0.0, 1e9])
+def test_long_drop_runs_match_oracle(params, wide):
+    """Overdriven links drop packets in runs, and consecutive drops arrive at mathematically equal times: the retire half
+    orders such near groups exactly around its boundaries (fix_drop_boundary_g / drop_hop1_candidate_g: a group of 8 or 16
+    lanes looks at a window of records at a time, the lead lane walks windows longer than the group).  Every env retired
+    by 16 lanes (wide = 0) and every env by 8 (1e9); windows shorter and longer than either; ns:111, 141-146, 161, 178
+    (the heap orders equal times by latency, then by the dropped flag)."""
+    n_envs, n_steps = 192, 70
+    rs = np.random.RandomState(21)
+    acts = rs.uniform(-0.5, 1.5, (n_envs, n_steps))
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=8, record_steps=True, auto_reset=False, link_params=params)
+    env.set_tuning(retire_wide_predict=wide, list_min_envs=0)
+    obs0 = env.reset().cpu().numpy()
+    steps, obs, done = run_gpu(env, acts, n_steps)
+    p = np.tile(np.array(params)[None, :], (n_envs, 1))
+    ref = oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=8, params=p)
+    assert np.array_equal(obs0, ref["obs0"].astype(np.float32))
+    assert steps[..., 2].sum() > 5 * steps[..., 1].sum() or params[0] > 200, "the links are meant to lose most of their packets"
+    assert np.array_equal(steps, ref["steps"])
+    assert np.array_equal(obs, ref["obs"].astype(np.float32))
+    env.close()
+
+
 def test_masked_reset_only_touches_selected_envs():
     n = 128
     env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=2, record_steps=True, auto_reset=False)
