@@ -86,27 +86,35 @@ __device__ __forceinline__ float mlp_forward_fixed(const float *p, const float (
     return out;
 }
 
+// Weights straight from the parameter block with compile-time offsets: every lane reads the same address, so the loads are
+// scalar (s_load into SGPRs, which the FMAs take as operands) -- no LDS copy, no LDS read per FMA (the first form of this
+// kernel staged the parameters in LDS and read one weight per FMA from there: 32 us for 65 536 envs, LDS-issue-bound with one
+// wavefront per SIMD).  The two networks of an env run in two lanes of different workgroups (blockIdx.y = 0: pi -> mean,
+// action, log-probability; 1: vf -> value): twice the wavefronts, half the chain.
 template <int D, int H1, int H2>
-__global__ __launch_bounds__(256) void policy_act_fixed_kernel(const float *obs, int64_t n, const float *params, int n_params,
-                                                               const float *noise, float *mean_out, float *act_out,
-                                                               float *logp_out, float *value_out) {
-    __shared__ float sp[kMaxParams];
-    for (int k = threadIdx.x; k < n_params; k += blockDim.x) sp[k] = params[k];
-    __syncthreads();
+__global__ __launch_bounds__(256) void policy_act_fixed_kernel(const float *__restrict__ obs, int64_t n,
+                                                               const float *__restrict__ params, int n_params,
+                                                               const float *__restrict__ noise, float *__restrict__ mean_out,
+                                                               float *__restrict__ act_out, float *__restrict__ logp_out,
+                                                               float *__restrict__ value_out) {
+    (void)n_params;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x[D];
 #pragma unroll
     for (int k = 0; k < D; k++) x[k] = obs[i * D + k];
     constexpr int n_pi = H1 * D + H1 + H2 * H1 + H2 + H2 + 1;   // without log_std
-    const float mu = mlp_forward_fixed<D, H1, H2>(sp, x);
-    const float log_std = sp[n_pi];
-    const float v = mlp_forward_fixed<D, H1, H2>(sp + n_pi + 1, x);
-    const float eps = noise ? noise[i] : 0.0f;
-    if (mean_out) mean_out[i] = mu;
-    if (act_out) act_out[i] = mu + expf(log_std) * eps;
-    if (logp_out) logp_out[i] = -0.5f * eps * eps - log_std - 0.918938533204672742f;
-    if (value_out) value_out[i] = v;
+    if (blockIdx.y == 0) {
+        const float mu = mlp_forward_fixed<D, H1, H2>(params, x);
+        const float log_std = params[n_pi];
+        const float eps = noise ? noise[i] : 0.0f;
+        if (mean_out) mean_out[i] = mu;
+        if (act_out) act_out[i] = mu + expf(log_std) * eps;
+        if (logp_out) logp_out[i] = -0.5f * eps * eps - log_std - 0.918938533204672742f;
+    } else {
+        const float v = mlp_forward_fixed<D, H1, H2>(params + n_pi + 1, x);
+        if (value_out) value_out[i] = v;
+    }
 }
 
 }  // namespace
@@ -125,7 +133,7 @@ extern "C" int pcc_policy_act(const float *obs, int64_t n_envs, int obs_dim, con
         switch (obs_dim) {
 #define PCC_POLICY_FIXED(DD)                                                                                             \
     case DD:                                                                                                             \
-        hipLaunchKernelGGL((policy_act_fixed_kernel<DD, 32, 16>), grid, block, 0, st, obs, n_envs, params, n_params, noise, \
+        hipLaunchKernelGGL((policy_act_fixed_kernel<DD, 32, 16>), dim3(grid.x, 2), block, 0, st, obs, n_envs, params, n_params, noise, \
                            mean_out, act_out, logp_out, value_out);                                                     \
         return hipGetLastError() == hipSuccess ? 0 : -3;
             PCC_POLICY_FIXED(30)

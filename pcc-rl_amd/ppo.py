@@ -169,6 +169,8 @@ class PPO(object):
         self.env, self.gamma, self.lam, self.clip, self.ent_coef = env, gamma, lam, clip, ent_coef
         self.epochs, self.minibatch, self.horizon = epochs, minibatch, horizon
         torch.manual_seed(seed)
+        if hasattr(env, "groups"):   # GroupedNetworkEnv: the surface of a BatchedNetworkEnv, from its groups
+            env.obs_dim, env.n_senders = env.groups[0].obs_dim, env.groups[0].n_senders
         self.policy = MlpPolicy(env.obs_dim, 1, arch).to(env.device)
         self.lr, self.adam_eps = lr, 1e-5
         # the fused optimiser step (pcc_ppo_minibatch_step: gradient + Adam in two launches) when the library has a kernel
@@ -205,7 +207,29 @@ class PPO(object):
         done_b = torch.empty((T, N), dtype=torch.bool, device=dev)
         obs_b[0] = self.obs
         fused = self.policy.fused_ok(obs_b[0]) and env.n_senders == 1
-        if fused:
+        groups = getattr(env, "groups", None)
+        if fused and groups is not None:
+            # Double-buffered sampling (GroupedNetworkEnv: the same envs as G groups on their own streams): group g's
+            # policy kernel and env step are queued on stream g, nothing joins the groups inside the rollout -- while one
+            # group's env launches run out their tails (a third of the wavefront slots busy), the
+            # other group's policy kernel and launches fill the machine.  Same numbers as one batch: a group holds the
+            # global env ids g * n .. and reads its own rows of every buffer.
+            params = self.policy.flat_params()
+            noise = torch.randn((T, N), device=dev)
+            n = env.group_size
+            cur = torch.cuda.current_stream(dev)
+            for s in env.streams:
+                s.wait_stream(cur)                                 # the buffers and the noise were made on this stream
+            for t in range(T):
+                for g, eg in enumerate(groups):
+                    lo, hi = g * n, (g + 1) * n
+                    with torch.cuda.stream(env.streams[g]):
+                        self.policy.act_fused(obs_b[t, lo:hi], True, params, noise[t, lo:hi],
+                                              (act_b[t, lo:hi].reshape(n), logp_b[t, lo:hi], val_b[t, lo:hi]))
+                        eg.step_into(act_b[t, lo:hi], obs_b[t + 1, lo:hi], rew_b[t, lo:hi], done_b[t, lo:hi])
+            for s in env.streams:
+                cur.wait_stream(s)
+        elif fused:
             params = self.policy.flat_params()                     # once per rollout, not per step
             noise = torch.randn((T, N), device=dev)                # the horizon's draws in one launch
             for t in range(T):

@@ -212,3 +212,26 @@ def test_gae_kernel_matches_the_loop():
     a1, r1 = gae(r, v, d, lv, 0.99, 0.95)
     a2, r2 = gae_fused(r, v, d, lv, 0.99, 0.95)
     assert torch.allclose(a1, a2, atol=1e-5) and torch.allclose(r1, r2, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_grouped_rollout_is_the_same_rollout():
+    """PPO.collect() over a GroupedNetworkEnv (the same envs as two groups on their own streams, policy kernel and env step
+    of a group queued on its stream, no join inside the rollout: double-buffered sampling) gathers exactly what it gathers
+    over one batch: same observations, actions, log-probabilities, rewards, advantages -- and the update after it leaves the
+    same weights."""
+    import pcc_rl_amd
+    from pcc_rl_amd.ppo import PPO
+    N, T = 2048, 12
+    out = []
+    for grouped in (False, True):
+        env = (pcc_rl_amd.GroupedNetworkEnv(N, 2, device="cuda:0", seed=3) if grouped
+               else pcc_rl_amd.BatchedNetworkEnv(N, device="cuda:0", seed=3))
+        agent = PPO(env, horizon=T, seed=1, minibatch=N * T // 2, epochs=1)
+        obs_b, act_b, logp_b, adv, ret, rew = agent.collect()
+        agent.update(obs_b, act_b, logp_b, adv, ret)
+        torch.cuda.synchronize()
+        out.append([t.clone() for t in (obs_b, act_b, logp_b, adv, ret, rew, agent.policy.flat_params())])
+        env.close()
+    for a, b, name in zip(out[0], out[1], ("obs", "actions", "logp", "advantages", "returns", "rewards", "weights after the update")):
+        assert torch.equal(a, b), name

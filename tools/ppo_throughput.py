@@ -31,11 +31,28 @@ t_upd = timed(update, 2)
 agent_fw = PPO(env, horizon=T, seed=0, minibatch=max(2048, N * T // 4), fused_update=False)
 def update_fw(): agent_fw.update(*batch["b"][:5])
 t_upd_fw = timed(update_fw, 1)
+# the same rollout double-buffered: the envs as two groups on their own streams, a group's policy kernel and env step queued
+# on its stream, no join inside the rollout (PPO.collect over a GroupedNetworkEnv: bit-identical data, tests/test_ppo.py)
+env.close()
+del agent_fw
+genv = pcc_rl_amd.GroupedNetworkEnv(N, 2, device=dev, seed=0)
+if os.environ.get("PCC_GROUP_SEND_WAVES"):
+    for e in genv.groups:
+        e.set_tuning(send_waves=float(os.environ["PCC_GROUP_SEND_WAVES"]))
+agent_g = PPO(genv, horizon=T, seed=0, minibatch=max(2048, N * T // 4))
+gbatch = {}
+def rollout_g(): gbatch["b"] = agent_g.collect()
+t_roll_g = timed(rollout_g, 3)
+def update_g(): agent_g.update(*gbatch["b"][:5])
+t_upd_g = timed(update_g, 2)
 out = {"n_envs": N, "horizon": T,
        "env_only": {"env_steps_per_s": N * T / t_env, "ms_per_step": 1e3 * t_env / T},
        "rollout": {"env_steps_per_s": N * T / t_roll, "ms_per_step": 1e3 * t_roll / T, "env_share_of_time": t_env / t_roll},
        "rollout_plus_update": {"env_steps_per_s": N * T / (t_roll + t_upd), "update_s": t_upd, "fused_update": agent.fused_update,
                                "env_share_of_time": t_env / (t_roll + t_upd)},
+       "two_groups": {"rollout_env_steps_per_s": N * T / t_roll_g, "rollout_ms_per_step": 1e3 * t_roll_g / T, "update_s": t_upd_g,
+                      "rollout_plus_update_env_steps_per_s": N * T / (t_roll_g + t_upd_g),
+                      "note": "PPO.collect over GroupedNetworkEnv(N, 2): double-buffered sampling, the same data as one batch"},
        "framework_update": {"update_s": t_upd_fw, "rollout_plus_update_env_steps_per_s": N * T / (t_roll + t_upd_fw)},
        "note": "PPO with the reference script's policy shape and hyper-parameters (pi/vf MLP 32-16, minibatch 2048, 4 epochs); "
                "minibatch = N*T/4 keeps the reference's 4 minibatches per epoch (8192 samples / 2048) at this batch size"}
