@@ -250,6 +250,25 @@ def test_old_gym_adapter_drop_in():
         t += 1
     assert t == 400 and total == 625.6196947931776   # SURVEY.md section 8(c) KAT
     assert len(env.event_record["Events"]) == 400
+    # dump_events_to_file (ns:493-496): the JSON the reference writes -- {"Events": [one dict per step]}, its nine fields in
+    # its order (ns:422-436), the numbers of the golden step record
+    import json, tempfile
+    from pcc_rl_amd import native
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "pcc_env_log_run_0.json")
+        env.dump_events_to_file(path)
+        with open(path) as f:
+            log = json.load(f)
+    assert list(log.keys()) == ["Events"] and len(log["Events"]) == 400
+    col = native.STEP_COLUMNS.index
+    fields = [("Reward", "reward"), ("Send Rate", "send rate"), ("Throughput", "recv rate"), ("Latency", "avg latency"),
+              ("Loss Rate", "loss ratio"), ("Latency Inflation", "sent latency inflation"), ("Latency Ratio", "latency ratio"),
+              ("Send Ratio", "send ratio")]
+    for k, ev in enumerate(log["Events"]):
+        assert list(ev.keys()) == ["Name", "Time"] + [name for name, _ in fields]
+        assert ev["Name"] == "Step" and ev["Time"] == k + 1
+        for name, column in fields:
+            assert ev[name] == d["steps"][0, k, col(column)], (k, name)   # (json round-trips a float64 exactly)
     env.close()
 
 
