@@ -130,3 +130,22 @@ def test_hot_kernels_do_not_spill():
         if name != "send_kernel<1, true>":   # (the trace build reserves 20 bytes it never touches: no scratch instruction in its code)
             assert r["scratch"] == 0, (name, r)
     assert res["send_kernel<1, false>"]["occupancy"] == 4 and res["retire_kernel<1, false>"]["occupancy"] == 4
+
+
+def test_no_built_binary_is_tracked():
+    """History holds sources only: shared libraries, objects and executables are built on the spot (they still travel to
+    the GPU box with the snapshot).  Skipped outside a git checkout."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        files = subprocess.run(["git", "ls-files"], cwd=root, capture_output=True, text=True, check=True).stdout.split("\n")
+    except Exception:
+        pytest.skip("not a git checkout")
+    elf = []
+    for f in files:
+        p = os.path.join(root, f)
+        if f and os.path.isfile(p):
+            with open(p, "rb") as fh:
+                if fh.read(4) == b"\x7fELF":
+                    elf.append(f)
+    assert not elf, "built binaries in the index: %s" % elf
