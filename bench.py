@@ -354,26 +354,37 @@ def main():
     t_global = 0
     whole = None
     if K < max_steps and not args.stagger:
-        # ---- one whole episode first (the section-8d metric), per-step HIP events: where in the episode do K steps
+        # ---- whole episodes first (the section-8d metric), timed in segments of 5 steps: where in the episode do K steps
         # take the episode-mean time per step?  (All ranks do the same work; rank 0's times place the window.)
         # (episodes differ -- a handful of envs whose queue limit sits just above a power of two send on the slow exact
         # path and can be a launch's critical path: 0.113 / 0.150 / 0.125 ms per send launch for the first three episodes of
         # seed 0 -- so the figure is taken over kWhole episodes)
         kWhole = 3
         sent0 = env.state("total_sent").sum()
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(kWhole * max_steps)]
+        # Events are not free (an event record costs the stream ~4.5 us): a boundary event every SEG steps places the window,
+        # and every HALVES-th step carries the two more that time its send and its retire launch apart
+        SEG, HALVES = (5 if max_steps % 5 == 0 else 1), 14
+        n_all = kWhole * max_steps
+        ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(n_all // SEG + 1)]
+        ev_h = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, n_all, HALVES)}
         torch.cuda.synchronize()
         c0 = time.perf_counter()
-        for k in range(kWhole * max_steps):
-            one_step(t_global, evs[k])
+        for k in range(n_all):
+            if k % SEG == 0:
+                ev_b[k // SEG].record()
+            one_step(t_global, ev_h.get(k))
             t_global += 1
+        ev_b[n_all // SEG].record()
         torch.cuda.synchronize()
         el = time.perf_counter() - c0
-        fold = lambda f: [sum(f(e * max_steps + k) for e in range(kWhole)) / kWhole for k in range(max_steps)]   # mean over the episodes, by step
-        send_t = fold(lambda k: evs[k][0].elapsed_time(evs[k][1]))
-        ret_t = fold(lambda k: evs[k][1].elapsed_time(evs[k][2]))
-        step_t = [a + b for a, b in zip(send_t, ret_t)]
-        mean_t = sum(step_t[:-1]) / (max_steps - 1)            # (the last step also runs the episode-boundary reset)
+        seg_t = [ev_b[j].elapsed_time(ev_b[j + 1]) / SEG for j in range(n_all // SEG)]       # ms per step, by segment
+        per_ep = max_steps // SEG
+        # mean over the episodes, by step of the episode (a step takes its segment's mean)
+        step_t = [sum(seg_t[e * per_ep + k // SEG] for e in range(kWhole)) / kWhole for k in range(max_steps)]
+        mean_t = sum(step_t[:-SEG]) / (max_steps - SEG)        # (the last segment also runs the episode-boundary reset)
+        halves = sorted(ev_h)
+        send_s = [ev_h[k][0].elapsed_time(ev_h[k][1]) for k in halves]
+        ret_s = [ev_h[k][1].elapsed_time(ev_h[k][2]) for k in halves if (k + 1) % max_steps != 0]
         span = W + K
         best, best_err = 0, None
         csum = [0.0]
@@ -384,7 +395,7 @@ def main():
             if best_err is None or err < best_err:
                 best, best_err = st, err
         whole = {"ms_per_step": 1e3 * el / (kWhole * max_steps), "value": world * N * kWhole * max_steps / el, "episodes": kWhole,
-                 "send_ms": sum(send_t) / max_steps, "retire_ms": sum(ret_t[:-1]) / (max_steps - 1),
+                 "send_ms": sum(send_s) / len(send_s), "retire_ms": sum(ret_s) / len(ret_s), "steps_with_kernel_events": len(send_s),
                  "packets_per_env_step": float((env.state("total_sent").sum() - sent0).item()) / (N * kWhole * max_steps),
                  "window_start": best}
         if world > 1:   # every rank must pre-roll alike
