@@ -80,7 +80,7 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
     // retired what the last one did) the whole search is this one round trip, 2-3 lines per ring instead of the 12-16 of
     // a descent from the ring's ends.
     uint32_t lo[K], hi[K];
-    bool inside[K];
+    bool inside[K], below[K];   // below: the predicted window missed and the transition lies under it
     bool all_inside = true;
     auto window = [&](const bool (&need)[K], const bool last) {
         double2 r[K][R];
@@ -121,6 +121,7 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
             const bool lo_ok = lo[k] == lo0[k] || ((mpass >> (lo[k] - 1u - base[k])) & 1u);
             const bool hi_ok = hi[k] == hi0[k] || !((mpass >> (hi[k] - base[k])) & 1u);
             inside[k] = last || (lo_ok && hi_ok);  // (after the descent the window holds the transition by construction)
+            below[k] = !lo_ok;
             if (!inside[k]) {  // the descent goes on in the part of the ring the window points to
                 if (!lo_ok) { hi[k] = lo[k] - 1u; lo[k] = lo0[k]; }
                 else { lo[k] = hi[k] + 1u; hi[k] = hi0[k]; }
@@ -177,6 +178,13 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
     const double2 *ring_m = q == 0 ? ring[0] : q == 1 ? ring[1] : q == 2 ? ring[2] : ring[3];
     const uint32_t mask_m = q == 0 ? mask[0] : q == 1 ? mask[1] : q == 2 ? mask[2] : mask[3];
     const double add_m = q == 0 ? add[0] : q == 1 ? add[1] : q == 2 ? add[2] : add[3];
+    const bool below_m = q == 0 ? below[0] : q == 1 ? below[1] : q == 2 ? below[2] : below[3];
+    // The first round gallops away from the predicted window instead of cutting the whole remaining range in four: a
+    // prediction that missed has mostly missed by little, and the transition then sits within a few dozen records of the
+    // window's edge -- probes at distances 12, 48, 192, 768 from that edge bracket it in one round (range <= 12, 36, 144, ...)
+    // where four equal parts of a ring holding hundreds of records need two or three.  Any ascending probes narrow a
+    // bracket of a monotone predicate exactly.
+    bool first = true;
     for (;;) {
         const bool active = !done_m && hi_m - lo_m > 12u;
         if (!gballot<G>(g, active)) break;
@@ -185,10 +193,21 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
         uint32_t passbits = 0;  // bit p: probe p of my search passes (probes j * PL + e of lane j)
 #pragma unroll
         for (int e = 0; e < PL; e++) {
-            uint32_t x = lo_m + (j * PL + (uint32_t)e + 1u) * stride;
+            const uint32_t pr = j * PL + (uint32_t)e;   // probe 0..3, ascending record indices
+            uint32_t x = lo_m + (pr + 1u) * stride;
             if (x > hi_m) x = hi_m;
+            if (first) {
+                if (below_m) {   // from the top of the range down: records hi - 768, hi - 192, hi - 48, hi - 12
+                    const uint32_t dist = 12u << (2u * (3u - pr));
+                    x = hi_m - lo_m > dist ? hi_m - dist + 1u : lo_m + 1u;
+                } else {         // from the bottom up: records lo + 11, lo + 47, lo + 191, lo + 767
+                    const uint32_t dist = 12u << (2u * pr);
+                    x = hi_m - lo_m > dist ? lo_m + dist : hi_m;
+                }
+            }
             sidx[e] = x - 1u;
         }
+        first = false;
         double tsamp[PL];
 #pragma unroll
         for (int e = 0; e < PL; e++) {
@@ -209,9 +228,10 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
         if (PL > 1) { mine_f = (f % PL) ? sidx[PL - 1] : sidx[0]; mine_p = (fp % PL) ? sidx[PL - 1] : sidx[0]; }
         const uint32_t s_f = gbcast<G>(mine_f, LQ * q + f / PL);
         const uint32_t s_p = gbcast<G>(mine_p, LQ * q + fp / PL);
+        const uint32_t s_last = gbcast<G>(sidx[PL - 1], LQ * q + LQ - 1);   // the highest probe of my search
         if (active) {
             if (!mfail) {
-                lo_m = hi_m;  // the last sample is record hi-1: everything passes
+                lo_m = s_last + 1u;  // every probe passes: the transition is above the last one (a cut in four ends at record hi - 1)
             } else {
                 if (f) lo_m = s_p + 1u;
                 hi_m = s_f < lo_m ? lo_m : s_f;
