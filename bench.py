@@ -272,6 +272,9 @@ def main():
                          "stream ~4.5 us, three per step are 7 %% of a step of config 3: the timed region carries them on a "
                          "sample of its steps -- 7 is coprime to the episode length, so every episode phase is sampled over a run -- "
                          "1 = every step)")
+    ap.add_argument("--two-launch", action="store_true",
+                    help="step a full-size batch as a send launch and a retire launch (pcc_step_send / pcc_step_retire, timed apart) "
+                         "instead of the one-launch step (step_fused_kernel: the default since round 5)")
     ap.add_argument("--stagger", action="store_true",
                     help="spread the envs' episode phases uniformly over the 400 steps before timing (masked resets "
                          "during an untimed pre-roll): every window then sees the episode-average load, and the "
@@ -330,7 +333,12 @@ def main():
     returns_gathered = 0
     gather_buf = torch.empty((world * N,), dtype=torch.float32, device=dev) if world > 1 else None
 
-    fused = N < 8192   # the library steps a batch this small in ONE launch (step_small_kernel): no halves to time apart
+    small = N < 8192   # the library steps a batch this small in ONE launch (step_small_kernel): no halves to time apart
+    if args.two_launch:
+        env.set_tuning(fused=0)
+    # one launch per step: a small batch, or the fused step of a full-size one (step_fused_kernel; out of lockstep -- --stagger --
+    # the library falls back to two launches inside the same call)
+    fused = small or not (args.two_launch or args.stagger)   # (--stagger: the halves timed apart, as the library launches them)
 
     def one_step(t, ev=None):
         nonlocal returns_gathered
@@ -383,6 +391,8 @@ def main():
         step_t = [sum(seg_t[e * per_ep + k // SEG] for e in range(kWhole)) / kWhole for k in range(max_steps)]
         mean_t = sum(step_t[:-SEG]) / (max_steps - SEG)        # (the last segment also runs the episode-boundary reset)
         halves = sorted(ev_h)
+        if fused:   # (the step after a reset runs without work lists, as two launches; the last one of an episode also runs the reset)
+            halves = [k for k in halves if k % max_steps != 0 and (k + 1) % max_steps != 0]
         send_s = [ev_h[k][0].elapsed_time(ev_h[k][1]) for k in halves]
         ret_s = [ev_h[k][1].elapsed_time(ev_h[k][2]) for k in halves if (k + 1) % max_steps != 0]
         span = W + K
@@ -440,12 +450,14 @@ def main():
         # steps that also ran the episode-boundary reset kernels are kept out of the retire average
         timed_k = [k for k in range(K) if k % ES == 0]   # the steps that carry events
         plain = [k for k in timed_k if (first + k + 1) % max_steps != 0] if not args.stagger else timed_k
+        if fused and not args.stagger:
+            timed_k = [k for k in plain if (first + k) % max_steps != 0] or timed_k
         runs[r]["send_ms"] = sum(ev[k][0].elapsed_time(ev[k][1]) for k in timed_k) / len(timed_k)
         runs[r]["retire_ms"] = sum(ev[k][1].elapsed_time(ev[k][2]) for k in plain) / max(1, len(plain))
         runs[r]["event_steps"] = len(timed_k)
         runs[r]["first_steps_ms"] = [ev[k][0].elapsed_time(ev[k][2]) for k in timed_k[:6]]
     many = None
-    if fused and world == 1 and not args.stagger:
+    if small and world == 1 and not args.stagger:
         # a small batch: one step is a 25 us launch, less than a trip around the Python loop above.  Supplementary: the same K
         # steps queued by ONE library call (pcc_step_many: the loop runs in C); `value` stays the one-call-per-step figure
         acts_many = torch.stack([actions[(t_global + k) % pool] for k in range(K)])
@@ -460,6 +472,7 @@ def main():
     if not os.environ.get("PCC_BENCH_IGNORE_FLAGS"):   # experiments only: an overflowed ring means invalid results
         env.check_flags()
     restart_stats = env.restart_stats() if args.stagger else None
+    fused_steps = env.fused_steps()
     env.close()
     coll = pdist.collective_info()
     numa_all = None
@@ -531,7 +544,7 @@ def main():
             send_gbps = send_bytes / (send_ms * 1e-3) / 1e9
             retire_gbps, retire_ms = 0.0, 0.0
             both = send_gbps
-        out["roofline"] = {"bound": "hbm", "kernel": ("step_small_kernel<%d, false>" if fused else "send_kernel<%d, false>") % S, "achieved": send_gbps,
+        out["roofline"] = {"bound": "hbm", "kernel": ("step_small_kernel<%d, false>" if small else "step_fused_kernel<%d, false>" if fused else "send_kernel<%d, false>") % S, "achieved": send_gbps,
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": send_gbps / HBM_PEAK_GBPS,
                            "traffic": None, "kernel_ms": send_ms, "algorithmic_bytes_per_launch": send_bytes,
                            "measured_over": roof_src,
@@ -571,6 +584,10 @@ def main():
             out["roofline"]["traffic_source"] = "none: " + str(why)
         if restart_stats is not None:
             out["restarts_out_of_lockstep"] = restart_stats
+        out["config"]["step_launches"] = ("one (step_small_kernel)" if small else "one (step_fused_kernel: an env's retire half follows its own send "
+                                          "half inside the launch); %d of this handle's steps ran that way, the others -- the step after "
+                                          "each reset, steps out of lockstep -- as send + retire launches" % fused_steps if fused else
+                                          "two (send_kernel, retire_kernel): --two-launch")
         if many is not None:
             out["many_steps_per_call"] = many
         if world == 1 and args.groups > 1:

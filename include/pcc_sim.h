@@ -213,8 +213,28 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     sender back into its own tier-0 rings: pcc_reset must follow */,
        PCC_TUNE_LIGHT_HALF_PREDICT = 25 /* send launch: light items of the classes from this many predicted packets per interval up
                                     hold 32 envs instead of 64 (a lane-round iteration costs ~3.3 ns per lane that stores, and the
-                                    longest light items are the launch's critical path); >= 1e9 = none */ };
+                                    longest light items are the launch's critical path); >= 1e9 = none */,
+       PCC_TUNE_FUSED = 26 /* both halves of a full-size step in ONE launch, an env's retire half running as soon as its own send
+                                    half is done (pcc_step only; whenever the step has work lists to read and no restart list to
+                                    serve): 1 (default) / 0 = always the send launch and the retire launch */,
+       PCC_TUNE_FUSED_ACQUIRE = 27 /* fused step, debug: 2 = an agent-scope acquire (buffer_inv sc1) between the poll that finds an env
+                                    ready and the first load of its state; 0 (default) = none: the ready queues are per physical XCD, so
+                                    producer and consumer share an L2 (pcc-rl_amd/csrc/pcc_dev.h "ready queues") */,
+       PCC_TUNE_FUSED_LIGHT_WGS = 28 /* fused step: workgroups per partition that start with the light items (dispatched last);
+                                    default 32 */,
+       PCC_TUNE_FUSED_MAX_NAPS = 29 /* fused step: a wavefront that finds no env ready looks again after 1, 2, 4, ... up to this many
+                                    naps of ~0.9 us; default 4 */,
+       PCC_TUNE_FUSED_PARTIAL_NAPS = 30 /* fused step: a wavefront that finds fewer envs ready than its lanes hold (8 at 8 lanes, 4 at
+                                    16) takes them anyway once it has waited this many naps; default 2 */,
+       PCC_TUNE_FUSED_LIGHT_FRONT = 32 /* fused step: so many of the light-first workgroups per partition are dispatched in FRONT of the
+                                    wave-path workgroups (a compute unit's memory pipeline serves its oldest wavefronts first); default 0 */,
+       PCC_TUNE_FUSED_DEBUG = 31 /* fused step, debug: bit 0 = an agent-scope release (buffer_wbl2) in front of every publication, bit 1 =
+                                    a consumer waits ~5 us before it reads a ready env; default 0 */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
+
+/* How many steps of this handle ran as one launch so far (PCC_TUNE_FUSED; the others ran as a send and a retire launch):
+ * what the tests and the bench check to know which path they measured.  No reference counterpart. */
+int pcc_fused_steps(pcc_sim_t *sim, uint64_t *out);
 
 /* Sizes of the shared ring pools (see pcc_create): tiers 1, 2, 3 get a slot for one sender in div1, div2, div3 (defaults
  * 2, 8, 32, measured on U(-1, 1) policies; 1 = a slot for every sender -- what a policy that drives every env to its

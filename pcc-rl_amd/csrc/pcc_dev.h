@@ -154,9 +154,21 @@ struct Dev {
     uint32_t key0, key1, gid_base;
     double delta_scale;
     uint32_t max_steps;
-    uint32_t *cls_count;  // [2][parts][kClsStride] work lists of the send half (two buffers, a set per partition): envs per class
-    uint32_t *cls_list;   // [2][parts][kListRows][part_envs] env ids by class
-    uint32_t *cursors;    // [2][parts][kShards][kCursorStride] item cursors of the list buffers
+    uint32_t *cls_count;  // [3][parts][kClsStride] work lists of the send half (three buffers in rotation -- read / filed / cleared for the step after -- a set per partition): envs per class
+    uint32_t *cls_list;   // [3][parts][kListRows][part_envs] env ids by class
+    uint32_t *cursors;    // [3][parts][kShards][kCursorStride] item cursors of the list buffers
+    // the fused step (pcc_fused.hip: one launch, an env's retire half runs as soon as ITS send half is done): per list buffer
+    // and partition the light-item cursor and the heads / tails of the two ready queues, a 128-byte line each; and the queues'
+    // entries -- 8-byte granules (step sequence number << 32 | env id), written when an env's send half is complete
+    uint32_t *fctl;                   // [3][kXcds][kFctlWords][kCursorStride]: word 0 of entry p = partition p's light-item cursor, words 1..4 of
+                                      // entry x = heads and tails of XCD x's two queues, word 5 of entry 0 = envs published so far
+    unsigned long long *q_entries;    // [2][kXcds][q_cap]: queue 0 = the envs of the light classes (retired 8 lanes per env), 1 = wave-path classes (16 lanes)
+    uint32_t q_cap;                   // entries per queue (every env may end up in one)
+    uint32_t fused_acquire;           // debug: 2 = an agent-scope acquire (L1 invalidate) before a ready env's state is read (see fused_retire_unit); 0 = none (default)
+    uint32_t fused_spin_ticks;        // a wait of the fused step gives up (PCC_FLAG_INTERNAL) after this many 100 MHz ticks
+    uint32_t fused_debug;             // debug: bit 0 = an agent-scope release (buffer_wbl2) in front of every publication, bit 1 = a consumer waits ~5 us before it reads a ready env
+    uint32_t fused_partial_naps;      // tuning: ... and takes a unit of fewer envs than its lanes hold once it has waited this many naps
+    uint32_t fused_max_naps;          // tuning: an idle wavefront of the fused step looks at the ready queues every 1, 2, 4 .. this many naps of ~0.9 us
     // [1] the retire half writes the step's sequence number (step_seq, below) here when an env finishes its episode;
     // the gated auto-reset launches of that step run only if they find it.  Nobody ever clears the word: a clear by one
     // workgroup of a launch races with the sets of the others (the L2 of every XCD writes back on its own schedule)
@@ -528,6 +540,54 @@ __device__ __forceinline__ uint32_t *cls_list_of(const Dev &D, const uint32_t vi
     return D.cls_list + ((size_t)view * kListRows + row) * (size_t)D.part_envs;
 }
 __device__ __forceinline__ uint32_t *cursors_of(const Dev &D, const uint32_t view) { return D.cursors + (size_t)view * kShards * kCursorStride; }
+constexpr int kListBufs = 3;   // list buffers in rotation: the one a step reads, the one it files into, the one it clears for the next step
+// the fused step's words of a list buffer (a line each; Dev::fctl): per partition the light-item cursor, per XCD the ready queues'
+// heads (claimed) and tails (reserved), and the count of published envs
+constexpr uint32_t kFctlWords = 8;
+constexpr uint32_t kFLight = 0, kFHead = 1 /* + queue */, kFTail = 3 /* + queue */;
+// ---- the fused step's ready queues (pcc_fused.hip) ----------------------------------------
+// Per-XCD L2s are write-back and NOT coherent with each other, and making a send half's stores visible across XCDs costs more
+// than the fused step gains (measured: write-through record stores +0.05 ms, one buffer_wbl2 per light item +0.09 ms, a
+// buffer_inv per retire unit +0.03 ms on a 0.18 ms step).  So the queues are per PHYSICAL XCD: a wavefront publishes an env in
+// the queue of the XCD it runs on (XCC_ID, read from the hardware) and takes envs only from that queue -- producer and
+// consumer then share one L2 BY CONSTRUCTION, wherever the dispatcher put their workgroups, and inside one L2 a plain store
+// is visible once the storing wavefront's s_waitcnt vmcnt(0) has passed (the gfx90a rule: one L2 = the coherence point).  The
+// consumer's L1 cannot hold a line of the env unless its own compute unit ran the env's send half (nobody else loads an env's
+// lines in a launch), and a compute unit's L1 is coherent with that unit's own stores.
+// An entry is one 8-byte granule: step sequence number << 32 | env id (the data is its own flag).
+constexpr uint32_t kXcds = 8;              // XCC_ID & 7: the MI355X has 8
+constexpr uint32_t kFPushed = 5;           // fctl word of XCD x: envs published on x so far (one counter for all XCDs is ~7 000
+                                           // atomics on one word per step: 80 us of the L2 channel that owns it)
+__device__ __forceinline__ void fused_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return xcc & (kXcds - 1u);
+}
+// the words of buffer `buf` that belong to XCD x (heads, tails), and the entries of its queue q
+__device__ __forceinline__ uint32_t *fq_word(const Dev &D, const int buf, const uint32_t x, const uint32_t word) {
+    return D.fctl + (((size_t)buf * kXcds + x) * kFctlWords + word) * kCursorStride;
+}
+__device__ __forceinline__ unsigned long long *fused_entries(const Dev &D, const uint32_t q, const uint32_t x) {
+    return D.q_entries + ((size_t)q * kXcds + x) * (size_t)D.q_cap;
+}
+// The envs of the lanes in `mask` (lane l: env i) are sent -- every wavefront that stored for them has waited for vmcnt(0)
+// -- : into ready queue q of this wavefront's XCD.  The XCD's count of published envs goes up AFTER the granules are out: who
+// reads the counts of all XCDs and finds every env of the step knows that every queue's tail is final.
+__device__ __forceinline__ void fused_push(const Dev &D, const int buf, const uint32_t xcc, const uint32_t q, const uint64_t mask,
+                                           const uint32_t lane, const int64_t i) {
+    if (!mask) return;
+    if (D.fused_debug & 1u) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    const uint32_t n = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (lane == 0) base = __hip_atomic_fetch_add(fq_word(D, buf, xcc, kFTail + q), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if ((mask >> lane) & 1ull)
+        __hip_atomic_store(fused_entries(D, q, xcc) + base + count_below(mask), ((unsigned long long)D.step_seq << 32) | (uint32_t)i,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fused_drain();
+    if (lane == 0) (void)__hip_atomic_fetch_add(fq_word(D, buf, xcc, kFPushed), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // (send_kernel itself follows retire_env below: a restart item runs the env's warm-up intervals through both halves)
 

@@ -18,6 +18,12 @@ void launch_refill(const Dev &d, unsigned grid, hipStream_t st, uint32_t row, ui
 void launch_retire(const Dev &d, bool noise, unsigned grid, hipStream_t st, int read_buf, int fill_buf, int warm, uint32_t warm_mi,
                    int last_warm, int gate, int restart, float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out,
                    const void *actions, int actions_f64);
+// pcc_fused.hip: both halves of a full-size step in one launch (an env's retire half follows its own send half); grid =
+// wave_wgs workgroups that start with the wave-path work + the rest, both multiples of Dev::parts
+void launch_step_fused(const Dev &d, bool trace, unsigned grid, unsigned wave_wgs, unsigned light_front, hipStream_t st, int read_buf, int fill_buf, int zero_buf,
+                       int retire_on, const void *actions, int actions_f64, float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out);
+void launch_clear_list_buffer(const Dev &d, hipStream_t st, int buf);
+int fused_resident_blocks(int ns, bool trace);   // workgroups of step_fused_kernel a compute unit holds at once (0: unknown)
 // pcc_small.hip
 // n_steps steps inside one launch: step t takes actions + t * act_stride bytes and writes row t of every output
 void launch_step_small(const Dev &d, bool trace, hipStream_t st, const void *actions, int actions_f64, float *obs_out,

@@ -27,6 +27,20 @@ template <int G>
 __device__ __forceinline__ double gbcast(double v, uint32_t src) { return __shfl(v, (int)src, G); }
 template <int G>
 __device__ __forceinline__ uint32_t gbcast(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, G); }
+// ... the same with the group's position taken from `g` instead of from the lane id __shfl reads: in the fused step
+// (pcc_fused.hip) retire_env sits in a loop, and everything derived from the lane id -- the shuffle addresses of every
+// __shfl with a width -- is otherwise hoisted out of it and kept in registers across the whole body (the caller passes a
+// lane index the compiler cannot see through)
+template <int G>
+__device__ __forceinline__ uint32_t gbcast(const Group &g, uint32_t v, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((g.shift + (src & (uint32_t)(G - 1))) << 2), (int)v);
+}
+template <int G>
+__device__ __forceinline__ double gbcast(const Group &g, double v, uint32_t src) {
+    const int idx = (int)((g.shift + (src & (uint32_t)(G - 1))) << 2);
+    const int lo = __builtin_amdgcn_ds_bpermute(idx, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(idx, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 // First index k in [lo, hi) whose record fails `t1 + add < end` (hi if none), by G-ary search:
 // every round the G lanes sample the ends of G equal sub-ranges.  Exact for a monotone
@@ -44,8 +58,8 @@ __device__ __forceinline__ uint32_t search_boundary(const Group &g, const double
         const uint32_t mfail = ~gballot<G>(g, pass) & ((1u << G) - 1u);
         if (!mfail) return hi;  // the last sample is record hi-1
         const uint32_t f = (uint32_t)__ffs((int)mfail) - 1u;
-        const uint32_t s_f = gbcast<G>(sidx, f);
-        if (f) lo = gbcast<G>(sidx, f - 1) + 1;
+        const uint32_t s_f = gbcast<G>(g, sidx, f);
+        if (f) lo = gbcast<G>(g, sidx, f - 1) + 1;
         hi = s_f;
         if (hi < lo) hi = lo;
     }
@@ -107,9 +121,9 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
                 mpass |= gballot<G>(g, passes) << (h * G);
                 m |= gballot<G>(g, in && idx >= lo[k] && idx < hi[k] && !passes) << (h * G);
                 // near flag of record idx: records idx and idx + 1 both exist (in the window) and are within rounding distance
-                double tn = __shfl(r[k][h].x, (int)((g.lane + 1u) & (G - 1)), G);
+                double tn = gbcast<G>(g, r[k][h].x, (g.lane + 1u) & (uint32_t)(G - 1));
                 if (h + 1 < R) {
-                    const double tw = __shfl(r[k][h + 1 < R ? h + 1 : h].x, 0, G);  // the first record of the next row
+                    const double tw = gbcast<G>(g, r[k][h + 1 < R ? h + 1 : h].x, 0u);  // the first record of the next row
                     if (g.lane == (uint32_t)G - 1u) tn = tw;
                 }
                 const bool has_next = (h + 1 < R) || g.lane + 1 < (uint32_t)G;
@@ -138,8 +152,8 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
             const uint32_t lb = b - base[k] < 16u ? b - base[k] : 0u;  // (the group's own value)
             double bx = r[k][0].x, by = r[k][0].y;
             if (R > 1 && lb >= (uint32_t)G) { bx = r[k][R - 1].x; by = r[k][R - 1].y; }
-            out[k].t = gbcast<G>(bx, lb & (G - 1));
-            out[k].lat = gbcast<G>(by, lb & (G - 1));
+            out[k].t = gbcast<G>(g, bx, lb & (G - 1));
+            out[k].lat = gbcast<G>(g, by, lb & (G - 1));
         }
     };
     // ---- 1. the predicted windows
@@ -226,9 +240,9 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
         const uint32_t fp = f ? f - 1u : 0u;
         uint32_t mine_f = sidx[0], mine_p = sidx[0];
         if (PL > 1) { mine_f = (f % PL) ? sidx[PL - 1] : sidx[0]; mine_p = (fp % PL) ? sidx[PL - 1] : sidx[0]; }
-        const uint32_t s_f = gbcast<G>(mine_f, LQ * q + f / PL);
-        const uint32_t s_p = gbcast<G>(mine_p, LQ * q + fp / PL);
-        const uint32_t s_last = gbcast<G>(sidx[PL - 1], LQ * q + LQ - 1);   // the highest probe of my search
+        const uint32_t s_f = gbcast<G>(g, mine_f, LQ * q + f / PL);
+        const uint32_t s_p = gbcast<G>(g, mine_p, LQ * q + fp / PL);
+        const uint32_t s_last = gbcast<G>(g, sidx[PL - 1], LQ * q + LQ - 1);   // the highest probe of my search
         if (active) {
             if (!mfail) {
                 lo_m = s_last + 1u;  // every probe passes: the transition is above the last one (a cut in four ends at record hi - 1)
@@ -242,7 +256,7 @@ __device__ __forceinline__ void search_many(const Group &g, const double2 *const
 #pragma unroll
     for (int k = 0; k < K; k++) {
         need[k] = !inside[k];
-        if (need[k]) { lo[k] = gbcast<G>(lo_m, LQ * k); hi[k] = gbcast<G>(hi_m, LQ * k); }
+        if (need[k]) { lo[k] = gbcast<G>(g, lo_m, LQ * k); hi[k] = gbcast<G>(g, hi_m, LQ * k); }
     }
     window(need, true);
 }
@@ -285,7 +299,7 @@ __device__ __forceinline__ void near_window_g(const Group &g, const double2 *rin
             // lane l: record g0 - l; pair l = (record g0 - l - 1, record g0 - l), tested as near_time(earlier, later)
             const bool has = g0 - h >= g.lane;
             const double t = has ? ld_t1(ring + ((g0 - g.lane) & mask)) : 0.0;
-            const double tp = __shfl(t, (int)((g.lane + 1u) & (uint32_t)(G - 1)), G);
+            const double tp = gbcast<G>(g, t, (g.lane + 1u) & (uint32_t)(G - 1));
             const bool nr = g.lane + 1u < (uint32_t)G && g0 - h >= g.lane + 1u && near_time(tp, t);
             const uint32_t run = (uint32_t)__ffs((int)~gballot<G>(g, nr)) - 1u;  // near pairs from pair 0 on (pair G-1 never is)
             g0 -= run;
@@ -298,7 +312,7 @@ __device__ __forceinline__ void near_window_g(const Group &g, const double2 *rin
             // lane l: record g1 - 1 + l; pair l = (record g1 - 1 + l, record g1 + l), tested as near_time(later, earlier)
             const bool has = g1 - 1u + g.lane < tail;
             const double t = has ? ld_t1(ring + ((g1 - 1u + g.lane) & mask)) : 0.0;
-            const double tn = __shfl(t, (int)((g.lane + 1u) & (uint32_t)(G - 1)), G);
+            const double tn = gbcast<G>(g, t, (g.lane + 1u) & (uint32_t)(G - 1));
             const bool nr = g.lane + 1u < (uint32_t)G && g1 + g.lane < tail && near_time(tn, t);
             const uint32_t run = (uint32_t)__ffs((int)~gballot<G>(g, nr)) - 1u;
             g1 += run;
@@ -643,11 +657,11 @@ __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, u
         }
     }
     if (G == 16) {
-        mean_all = gbcast<G>(res0, 0) / (double)n;
-        lat_inc = halves ? gbcast<G>(res1, 8) / (double)(n - half) - gbcast<G>(res0, 8) / (double)half : 0.0;
+        mean_all = gbcast<G>(g, res0, 0u) / (double)n;
+        lat_inc = halves ? gbcast<G>(g, res1, 8u) / (double)(n - half) - gbcast<G>(g, res0, 8u) / (double)half : 0.0;
     } else {
-        mean_all = gbcast<G>(res0, 0) / (double)n;
-        lat_inc = halves ? gbcast<G>(res2, 0) / (double)(n - half) - gbcast<G>(res1, 0) / (double)half : 0.0;
+        mean_all = gbcast<G>(g, res0, 0u) / (double)n;
+        lat_inc = halves ? gbcast<G>(g, res2, 0u) / (double)(n - half) - gbcast<G>(g, res1, 0u) / (double)half : 0.0;
     }
 }
 

@@ -40,6 +40,8 @@ __global__ __launch_bounds__(4 * kWave, NS == 2 ? PCC_SEND_OCC2 : PCC_SEND_OCC) 
             *cls_count_of(D, list_view(D, zero_buf, w / (uint32_t)(kClasses + 1)), w % (uint32_t)(kClasses + 1)) = 0u;
         for (uint32_t w = threadIdx.x; w < D.parts * kShards; w += blockDim.x)
             cursors_of(D, list_view(D, zero_buf, w / kShards))[(w % kShards) * kCursorStride] = 0u;
+        for (uint32_t w = threadIdx.x; w < kXcds * kFctlWords; w += blockDim.x)   // (a fused step may read this buffer: pcc_fused.hip)
+            *fq_word(D, zero_buf, w / kFctlWords, w % kFctlWords) = 0u;
     }
     __shared__ SendLds<NS> lds;
     const uint32_t b = blockIdx.x;

@@ -101,13 +101,16 @@ __device__ __forceinline__ void light_body(const Dev &D, SendLds<NS> &lds, const
 // off 16 sharded cursors (one returning atomic on one word saturates near 90 claims/us).  (A wavefront that finds its
 // partition's cursors empty stops: going on with the next partition's items was built -- a loop around all of this -- and
 // cost the kernel its spill-free register budget whichever way the hop count was kept.)
-template <int NS, bool TRACE>
+// FUSED (pcc_fused.hip): every env that is sent goes into the ready queue of the wave-path classes of this wavefront's XCD
+// (fused_push), after the wavefronts that stored for it have drained their stores.
+template <int NS, bool TRACE, bool FUSED = false>
 __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const uint32_t lane, const uint32_t wv, const uint32_t wave_wgs,
-                                          const int read_buf, const void *actions, const int actions_f64) {
+                                          const int read_buf, const void *actions, const int actions_f64, const uint32_t xcc = 0u,
+                                          const uint32_t blk = blockIdx.x) {
     // workgroup blockIdx.x of the wave_wgs wave-path workgroups: number b_wg of the G of its partition.  (Computed from
     // the block index here: nothing of the launch's bookkeeping need stay in registers across
     // the items: the kernel sits at its register budget.)
-    const uint32_t b_wg = blockIdx.x >> D.parts_shift, G = wave_wgs >> D.parts_shift;
+    const uint32_t b_wg = blk >> D.parts_shift, G = wave_wgs >> D.parts_shift;   // (blk: this workgroup's number among the wave-path workgroups)
     const uint32_t wave = b_wg * 4u + wv;
     constexpr bool kTeams = NS == 1;
     const int cls_heavy = D.heavy_predict >= 1e9 ? kClasses : class_of((float)D.heavy_predict);
@@ -117,7 +120,7 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
     uint32_t (*tab)[kClasses] = lds.tab[wv];
     {
         constexpr bool home = true;
-        const uint32_t pv = blockIdx.x & (D.parts - 1u);
+        const uint32_t pv = blk & (D.parts - 1u);
         const uint32_t view = list_view(D, read_buf, pv);
         // lane l < kClasses looks after class kClasses - 1 - l: largest class first
         const int cls_mine = kClasses - 1 - (int)lane;
@@ -160,6 +163,11 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
                     const int64_t i = lane == 0 ? (int64_t)list[off] : 0;
                     (void)send_wave_item<NS, TRACE, kTeams ? kTeamMax : 1>(D, lane, i, lane == 0, true, tl_base + n_items + tt < tl_end ? tl_base + n_items + tt : 0xFFFFFFFFu, 0, 0, actions,
                                                                            actions_f64, lds.slots[wv], wv, &lds.team);
+                    if constexpr (FUSED) {   // all four wavefronts stored records: each drains, then wavefront 0 publishes
+                        fused_drain();
+                        __syncthreads();
+                        if (wv == 0u) fused_push(D, read_buf, xcc, 1u, 1ull, lane, i);
+                    }
                 }
                 if (D.prio_team) set_prio(0u);
             }
@@ -180,6 +188,24 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
         for (;;) {
             if (t >= n_items) {
                 t = 0xFFFFFFFFu;
+                if constexpr (FUSED) {
+                    // every shard's cursor looked at side by side (lane k: shard s_mine + k), then ONE claim -- the serial look
+                    // below is 16 dependent round trips for a wavefront that finds everything empty, and here that wavefront
+                    // has retire work waiting
+                    for (uint32_t tries = 0; tries < 4u && t == 0xFFFFFFFFu; tries++) {
+                        const uint32_t sh = (s_mine + lane) % kShards;
+                        const uint32_t seen = lane < kShards ? __hip_atomic_load(cursors + sh * kCursorStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+                        const uint64_t open = __ballot(lane < kShards && (uint64_t)seen * kShards + sh + n_static < (uint64_t)n_items);
+                        if (!open) break;
+                        const uint32_t k = (uint32_t)__ffsll((unsigned long long)open) - 1u;
+                        uint32_t got = 0xFFFFFFFFu;
+                        if (lane == k) {
+                            const uint64_t cand = (uint64_t)atomicAdd(cursors + sh * kCursorStride, 1u) * kShards + sh + n_static;
+                            if (cand < (uint64_t)n_items) got = (uint32_t)cand;
+                        }
+                        t = rl_u32(got, k);
+                    }
+                } else
                 if (lane == 0) {
                     for (uint32_t k = 0; k < kShards && t == 0xFFFFFFFFu; k++) {
                         const uint32_t sh = (s_mine + k) % kShards;
@@ -204,6 +230,10 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
             const bool prio = t < D.prio_wave_items;
             if (prio) set_prio(D.prio_level);
             (void)send_wave_item<NS, TRACE, 1>(D, lane, i, has, true, tl_base + t < tl_end ? tl_base + t : 0xFFFFFFFFu, 0, 0, actions, actions_f64, lds.slots[wv]);
+            if constexpr (FUSED) {
+                fused_drain();
+                fused_push(D, read_buf, xcc, 1u, __ballot(has), lane, i);
+            }
             if (prio) set_prio(0u);
             t = n_items;  // forces a claim
         }

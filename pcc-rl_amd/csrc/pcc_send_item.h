@@ -39,8 +39,11 @@ __device__ __forceinline__ LaneEnv<NS> load_env(const Dev &D, const uint32_t lan
                                                 const int actions_f64, const uint32_t wv, const bool no_promote = false) {
     LaneEnv<NS> E;
     const bool writer = W == 1 || wv == 0u;
-    E.live = in_range && !(warm && !D.env[in_range ? i : 0].resetting);
-    const int64_t ii = E.live ? i : 0;
+    E.live = in_range && !(warm && !D.env[in_range ? i : D.n].resetting);
+    // A lane without an env reads block N (env 0's shadow: always there, never sent by this launch) -- not env 0's: in the
+    // fused step (pcc_fused.hip) a compute unit must not load lines of an env it does not send, or its L1 holds a copy that is
+    // stale by the time it retires that env (observed: env 0 retired from the L1 copy a neighbour's idle lanes had loaded)
+    const int64_t ii = E.live ? i : D.n;
     E.dl = D.env[ii].dl; E.lr = D.env[ii].lr; E.maxq = D.env[ii].maxq; E.ebw = D.env[ii].ebw;
     E.q = D.env[ii].q; E.tu = D.env[ii].tu;
     const double now = D.env[ii].now;
@@ -168,7 +171,7 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
     LaneEnv<NS> E = load_env<NS, TRACE, 1>(D, lane, i, in_range, true, warm, warm_mi, actions, actions_f64, 0u);
     if (!__ballot(E.live)) return 0ull;
     const uint64_t tl0 = prof_on(D) ? wall_clock64() : 0;
-    const int64_t ii = E.live ? i : 0;
+    const int64_t ii = E.live ? i : D.n;   // (see load_env)
     bool active = false;
     if (NS == 1) {
         const double dl = E.dl, lr = E.lr, maxq = E.maxq, ebw = E.ebw, end = E.end;

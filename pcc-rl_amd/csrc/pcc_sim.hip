@@ -69,6 +69,14 @@ struct pcc_sim {
     hipEvent_t ev_ret, ev_refill[4];
     bool refill_recorded[4];
     hipStream_t last_stream; // the stream of the last pcc_reset / pcc_step (what pcc_set_tuning's flush is queued on)
+    // the fused step (pcc_fused.hip): on / off (tuning), the list buffer known to be clean (-1: none), workgroups of the
+    // kernel a compute unit holds at once (per rng mode; 0 = not asked yet, -1 = unknown), light-first workgroups per partition
+    int fused;
+    int clean_buf;
+    int fused_blocks[2];
+    uint32_t fused_light_wgs;
+    uint32_t fused_light_front;   // ... of which so many per partition are dispatched in FRONT of the wave-path workgroups
+    unsigned long long fused_steps;  // steps that ran as one launch (pcc_debug_fused_steps)
 };
 
 namespace {
@@ -106,8 +114,13 @@ size_t carve_state(Dev &d, char *base) {
     d.refill_count = c.take<uint32_t>(4 * kCntStride);
     d.refill_list = c.take<uint32_t>(4 * n);
     d.restart_stats = c.take<unsigned long long>(2);
-    d.cls_count = c.take<uint32_t>(2 * kParts * kClsStride);
-    d.cursors = c.take<uint32_t>(2 * kParts * kShards * kCursorStride);
+    d.cls_count = c.take<uint32_t>(kListBufs * kParts * kClsStride);
+    d.cursors = c.take<uint32_t>(kListBufs * kParts * kShards * kCursorStride);
+    d.fctl = c.take<uint32_t>(kListBufs * kXcds * kFctlWords * kCursorStride);
+    // the fused step's ready queues: two per XCD, each able to hold every env (who retires an env is decided by where its send
+    // half ran); batches beyond 4 M envs go without (and are stepped by two launches)
+    d.q_cap = n <= ((size_t)1 << 22) ? (uint32_t)n : 0u;
+    d.q_entries = c.take<unsigned long long>((size_t)2 * kXcds * d.q_cap);
     d.any_done = c.take<uint32_t>(1);
     d.tier_top = c.take<int32_t>(kMaxTiers * kParts * kTopStride);
     d.pool_share = c.take<uint32_t>(kMaxTiers);
@@ -216,11 +229,71 @@ int launch_retire_half(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm
     const int rc = check_hip(hipGetLastError(), "retire kernel launch");
     if (rc == PCC_OK && !warm && lists) {
         sim->read_buf = sim->fill_buf;
-        sim->fill_buf ^= 1;
+        sim->fill_buf = (sim->fill_buf + 1) % kListBufs;
+        sim->clean_buf = -1;   // (the send launch cleared the buffer this launch filed; the next one is as its last reader left it)
         sim->read_has_restarts = restart != 0;  // the buffer just filed may hold a restart list
         if (restart) sim->restarts_pending = true;
     }
     return rc;
+}
+
+// Both halves of a step as ONE launch (pcc_fused.hip) -- whenever the step is an ordinary one: work lists to read, no warm-up
+// interval, no restart list to serve or to fill (lockstep, or the caller resets), none of the engine options.  Returns
+// PCC_OK + *done = true when the step was launched; *done = false: the caller launches the two halves.
+int try_launch_fused(pcc_sim_t *sim, int restart, const void *actions, int actions_f64, float *obs_out, float *reward_out,
+                     uint8_t *done_out, double *steps_out, hipStream_t st, bool *done) {
+    const Dev &d = sim->d;
+    *done = false;
+    if (!sim->fused || d.engine || d.use_cwnd || restart || sim->read_has_restarts || sim->restarts_pending) return PCC_OK;
+    if (d.n < (int64_t)sim->list_min_envs || sim->read_buf < 0 || !d.retire_sorted) return PCC_OK;
+    if (d.q_cap == 0u) return PCC_OK;
+    const bool tr = d.rng_mode == PCC_RNG_TRACE;
+    int &blocks = sim->fused_blocks[tr ? 1 : 0];
+    if (blocks == 0) { blocks = fused_resident_blocks(d.ns, tr); if (blocks <= 0) blocks = -1; }
+    if (blocks < 0) return PCC_OK;
+    // grid: what the device holds at once (every item is claimed dynamically, so a grid that is NOT all resident is only
+    // slower: its late workgroups find nothing left), a multiple of the partitions: the light-first workgroups last
+    const int64_t P = d.parts;
+    int64_t cap = (int64_t)blocks * sim->cu_count / P * P;
+    int64_t light = P * (int64_t)sim->fused_light_wgs;
+    if (cap < 2 * P) cap = 2 * P;
+    if (light > cap / 2) light = cap / 2 / P * P;
+    if (light < P) light = P;
+    const bool wave = d.heavy_predict < 1e9;
+    int64_t waves = (int64_t)sim->cu_count * d.send_waves;
+    if (waves > d.n) waves = d.n;
+    int64_t wave_wgs = wave ? P * (((waves + 3) / 4 + P - 1) / P) : 0;
+    if (wave_wgs > cap - light) wave_wgs = cap - light;
+    // (a small batch: no more workgroups than a wavefront per 8 envs and per light item need)
+    int64_t light_need = P * (((int64_t)d.part_envs / (int64_t)(d.send_envs_per_wave ? d.send_envs_per_wave : 1) + kClasses + 3) / 4);
+    int64_t grid = cap;
+    const int64_t by_envs = P * (((int64_t)d.part_envs / 8 + 3) / 4 + 1);
+    if (grid > wave_wgs + (light_need > by_envs ? light_need : by_envs)) grid = wave_wgs + (light_need > by_envs ? light_need : by_envs);
+    if (grid < wave_wgs + P) grid = wave_wgs + P;
+    const int read = sim->read_buf, fill = sim->fill_buf, zero = (sim->fill_buf + 1) % kListBufs;
+    // light-first workgroups in front of the wave-path ones (a multiple of the partitions; the others behind them)
+    unsigned light_front = (unsigned)(P * (int64_t)sim->fused_light_front);
+    if ((int64_t)light_front > grid - wave_wgs) light_front = (unsigned)((grid - wave_wgs) / P * P);
+    if (sim->fused == 2) {   // experiment: the fused kernel's send part as the send launch, then the retire launch
+        launch_step_fused(d, tr, (unsigned)grid, (unsigned)wave_wgs, light_front, st, read, fill, fill, 0, actions, actions_f64, obs_out, reward_out, done_out,
+                          steps_out);
+        const int rc2 = check_hip(hipGetLastError(), "fused step kernel launch");
+        if (rc2 != PCC_OK) return rc2;
+        *done = true;
+        return launch_retire_half(sim, 0, 0, 0, 0, 0, obs_out, reward_out, done_out, steps_out, st);
+    }
+    if (sim->clean_buf != fill) launch_clear_list_buffer(d, st, fill);
+    launch_step_fused(d, tr, (unsigned)grid, (unsigned)wave_wgs, light_front, st, read, fill, zero, 1, actions, actions_f64, obs_out, reward_out, done_out,
+                      steps_out);
+    const int rc = check_hip(hipGetLastError(), "fused step kernel launch");
+    if (rc != PCC_OK) return rc;
+    sim->read_buf = fill;
+    sim->fill_buf = zero;
+    sim->clean_buf = zero;
+    sim->read_has_restarts = false;
+    sim->fused_steps++;
+    *done = true;
+    return PCC_OK;
 }
 
 int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gate, int restart, const void *actions,
@@ -233,6 +306,11 @@ int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gat
         launch_retire(d, true, grid, st, -1, -1, warm, warm_mi, last_warm, gate, 0, obs_out, reward_out, done_out, steps_out,
                       actions, actions_f64);
         return check_hip(hipGetLastError(), "event-loop kernel launch");
+    }
+    if (!warm && !gate) {
+        bool done = false;
+        const int rf = try_launch_fused(sim, restart, actions, actions_f64, obs_out, reward_out, done_out, steps_out, st, &done);
+        if (rf != PCC_OK || done) return rf;
     }
     const int rc = launch_send(sim, warm, warm_mi, gate, actions, actions_f64, st);
     if (rc != PCC_OK) return rc;
@@ -485,7 +563,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     }
     // the send half's work lists: two buffers of kClasses lists, each able to hold every env
     // (room for either partitioning: kParts partitions of part_envs rounded up to 64, or one of n_envs)
-    sim->list_bytes = (size_t)2 * kListRows * ((size_t)n_envs + 64 * kParts) * sizeof(uint32_t);
+    sim->list_bytes = (size_t)kListBufs * kListRows * ((size_t)n_envs + 64 * kParts) * sizeof(uint32_t);
     if (hipMalloc(&sim->list_blob, sim->list_bytes) != hipSuccess) {
         pcc_destroy(sim);
         return fail(PCC_ENOMEM, "hipMalloc(%zu) for the send work lists failed", sim->list_bytes);
@@ -493,6 +571,13 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.cls_list = static_cast<uint32_t *>(sim->list_blob);
     sim->read_buf = -1;
     sim->fill_buf = 0;
+    sim->clean_buf = -1;
+    sim->fused = 1;
+    sim->fused_light_wgs = 32;   // light-first workgroups per partition (4 wavefronts each: a partition of 8 192 envs has ~105 light items)
+    d.fused_acquire = 0u;
+    d.fused_spin_ticks = 100000000u;   // 1 s of the 100 MHz clock
+    d.fused_max_naps = 4u;
+    d.fused_partial_naps = 2u;
     sim->list_min_envs = 8192;
     sim->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     sim->retire_grid_frac = 0.125;
@@ -522,13 +607,18 @@ int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words) {
     const unsigned long long items = 2ull * (unsigned long long)sim->d.n;
     if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "reading the debug timeline failed");
     const int64_t rblocks = (sim->d.n + 7) / 8 + 1;  // (the largest retire grid)
-    const int64_t total = (int64_t)items * 8 + rblocks * 16;
+    // ... and the retire units of the fused step (pcc_fused.hip: a running counter at word 19 n, then 4 words per unit --
+    // sequence number << 32 | queue << 31 | envs, claimed, ready, done -- the last n / 2 units)
+    const int64_t units = sim->d.n >= 1024 ? 8 + 2 * sim->d.n : 0;
+    const int64_t total = (int64_t)items * 8 + rblocks * 16 + units;
     if (!out || n_words <= 0) return total;
     if (n_words < total) return fail(PCC_EINVAL, "pcc_debug_timeline needs room for %lld words", (long long)total);
     const char *src = static_cast<const char *>(sim->timeline_blob);
     if (hipMemcpy(out, src, (size_t)items * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(out + items * 8, src + (size_t)sim->d.n * 2 * 8 * sizeof(uint64_t), (size_t)rblocks * 16 * sizeof(uint64_t),
-                  hipMemcpyDeviceToHost) != hipSuccess)
+                  hipMemcpyDeviceToHost) != hipSuccess ||
+        (units && hipMemcpy(out + items * 8 + rblocks * 16, src + (size_t)sim->d.n * 19 * sizeof(uint64_t), (size_t)units * sizeof(uint64_t),
+                            hipMemcpyDeviceToHost) != hipSuccess))
         return fail(PCC_EHIP, "reading the debug timeline failed");
     return total;
 }
@@ -639,6 +729,7 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             const int rc = flush_restarts(sim, sim->last_stream);
             if (rc != PCC_OK) return rc;
             sim->list_min_envs = (uint32_t)value;
+            sim->clean_buf = -1;
             sim->read_buf = -1;  // (whatever was filed is dropped: the next step walks the envs in index order)
             return PCC_OK;
         }
@@ -680,6 +771,7 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             sim->ever_reset = false;
             sim->restarts_pending = false;
             sim->read_buf = -1;
+            sim->clean_buf = -1;   // (the views of the list buffers moved)
             return PCC_OK;
         }
         case PCC_TUNE_RETIRE_WIDE_PREDICT:
@@ -697,6 +789,28 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
         case PCC_TUNE_TAKEOVER_LANES:
             if (value < 0 || value > 64) return fail(PCC_EINVAL, "takeover_lanes out of range");
             sim->d.takeover_lanes = (uint32_t)value;
+            return PCC_OK;
+        case PCC_TUNE_FUSED: sim->fused = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0); return PCC_OK;
+        case PCC_TUNE_FUSED_ACQUIRE:
+            if (value != 0.0 && value != 2.0) return fail(PCC_EINVAL, "fused_acquire must be 0 or 2");
+            sim->d.fused_acquire = (uint32_t)value;
+            return PCC_OK;
+        case PCC_TUNE_FUSED_LIGHT_FRONT:
+            if (!(value >= 0.0 && value <= 4096.0)) return fail(PCC_EINVAL, "fused_light_front out of range");
+            sim->fused_light_front = (uint32_t)value;
+            return PCC_OK;
+        case PCC_TUNE_FUSED_DEBUG: sim->d.fused_debug = (uint32_t)value; return PCC_OK;
+        case PCC_TUNE_FUSED_PARTIAL_NAPS:
+            if (!(value >= 0.0 && value <= 1e6)) return fail(PCC_EINVAL, "fused_partial_naps out of range");
+            sim->d.fused_partial_naps = (uint32_t)value;
+            return PCC_OK;
+        case PCC_TUNE_FUSED_MAX_NAPS:
+            if (!(value >= 1.0 && value <= 1024.0)) return fail(PCC_EINVAL, "fused_max_naps out of range");
+            sim->d.fused_max_naps = (uint32_t)value;
+            return PCC_OK;
+        case PCC_TUNE_FUSED_LIGHT_WGS:
+            if (!(value >= 1.0 && value <= 4096.0)) return fail(PCC_EINVAL, "fused_light_wgs out of range");
+            sim->fused_light_wgs = (uint32_t)value;
             return PCC_OK;
         default: return fail(PCC_EINVAL, "unknown tuning key %d", key);
     }
@@ -961,6 +1075,12 @@ int pcc_step_many(pcc_sim_t *sim, const void *actions, int actions_f64, int n_st
             return fail(rc, "pcc_step_many stopped after %d of %d steps: %s", t, n_steps, why);
         }
     }
+    return PCC_OK;
+}
+
+int pcc_fused_steps(pcc_sim_t *sim, uint64_t *out) {
+    if (!sim || !out) return fail(PCC_EINVAL, "NULL argument");
+    *out = sim->fused_steps;
     return PCC_OK;
 }
 

@@ -42,5 +42,11 @@ def work_lists_for_small_batches():
     import pcc_rl_amd
     old = pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS
     pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = 0
+    # the step as one launch (the default) or as two (PCC_TEST_FUSED=0), and the fused step's acquire mode: tests/test_variants.py
+    # runs slices of the parity suite through each
+    if os.environ.get("PCC_TEST_FUSED") is not None:
+        pcc_rl_amd.BatchedNetworkEnv.DEFAULT_FUSED = int(os.environ["PCC_TEST_FUSED"])
+    if os.environ.get("PCC_TEST_FUSED_ACQUIRE") is not None:
+        pcc_rl_amd.BatchedNetworkEnv.DEFAULT_FUSED_ACQUIRE = int(os.environ["PCC_TEST_FUSED_ACQUIRE"])
     yield
     pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = old
