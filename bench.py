@@ -272,9 +272,10 @@ def main():
                          "stream ~4.5 us, three per step are 7 %% of a step of config 3: the timed region carries them on a "
                          "sample of its steps -- 7 is coprime to the episode length, so every episode phase is sampled over a run -- "
                          "1 = every step)")
-    ap.add_argument("--two-launch", action="store_true",
-                    help="step a full-size batch as a send launch and a retire launch (pcc_step_send / pcc_step_retire, timed apart) "
-                         "instead of the one-launch step (step_fused_kernel: the default since round 5)")
+    ap.add_argument("--fused", action="store_true",
+                    help="step a full-size batch by the one-launch step (step_fused_kernel, PCC_TUNE_FUSED: an env's retire half follows "
+                         "its own send half inside the launch; measured slower, off by default) instead of a send launch and a retire "
+                         "launch (pcc_step_send / pcc_step_retire, timed apart)")
     ap.add_argument("--stagger", action="store_true",
                     help="spread the envs' episode phases uniformly over the 400 steps before timing (masked resets "
                          "during an untimed pre-roll): every window then sees the episode-average load, and the "
@@ -334,11 +335,11 @@ def main():
     gather_buf = torch.empty((world * N,), dtype=torch.float32, device=dev) if world > 1 else None
 
     small = N < 8192   # the library steps a batch this small in ONE launch (step_small_kernel): no halves to time apart
-    if args.two_launch:
-        env.set_tuning(fused=0)
-    # one launch per step: a small batch, or the fused step of a full-size one (step_fused_kernel; out of lockstep -- --stagger --
-    # the library falls back to two launches inside the same call)
-    fused = small or not (args.two_launch or args.stagger)   # (--stagger: the halves timed apart, as the library launches them)
+    if args.fused:
+        env.set_tuning(fused=1)
+    # one launch per step: a small batch, or (--fused) the fused step of a full-size one (step_fused_kernel; out of lockstep --
+    # --stagger -- the library steps by two launches inside the same call)
+    fused = small or (args.fused and not args.stagger)
 
     def one_step(t, ev=None):
         nonlocal returns_gathered
@@ -587,7 +588,7 @@ def main():
         out["config"]["step_launches"] = ("one (step_small_kernel)" if small else "one (step_fused_kernel: an env's retire half follows its own send "
                                           "half inside the launch); %d of this handle's steps ran that way, the others -- the step after "
                                           "each reset, steps out of lockstep -- as send + retire launches" % fused_steps if fused else
-                                          "two (send_kernel, retire_kernel): --two-launch")
+                                          "two (send_kernel, retire_kernel)")
         if many is not None:
             out["many_steps_per_call"] = many
         if world == 1 and args.groups > 1:

@@ -216,7 +216,10 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     longest light items are the launch's critical path); >= 1e9 = none */,
        PCC_TUNE_FUSED = 26 /* both halves of a full-size step in ONE launch, an env's retire half running as soon as its own send
                                     half is done (pcc_step only; whenever the step has work lists to read and no restart list to
-                                    serve): 1 (default) / 0 = always the send launch and the retire launch */,
+                                    serve; pcc-rl_amd/csrc/pcc_fused.hip): 0 (default) = the send launch and the retire launch -- the
+                                    one-launch step is exact (the parity suite runs through it) and measured SLOWER at full size
+                                    (0.33 ms per step against 0.18: profiles/r05_fused_experiments.json); 1 = on; 2 = experiment: its
+                                    send part as the send launch, then the retire launch */,
        PCC_TUNE_FUSED_ACQUIRE = 27 /* fused step, debug: 2 = an agent-scope acquire (buffer_inv sc1) between the poll that finds an env
                                     ready and the first load of its state; 0 (default) = none: the ready queues are per physical XCD, so
                                     producer and consumer share an L2 (pcc-rl_amd/csrc/pcc_dev.h "ready queues") */,
@@ -228,8 +231,9 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     16) takes them anyway once it has waited this many naps; default 2 */,
        PCC_TUNE_FUSED_LIGHT_FRONT = 32 /* fused step: so many of the light-first workgroups per partition are dispatched in FRONT of the
                                     wave-path workgroups (a compute unit's memory pipeline serves its oldest wavefronts first); default 0 */,
-       PCC_TUNE_FUSED_DEBUG = 31 /* fused step, debug: bit 0 = an agent-scope release (buffer_wbl2) in front of every publication, bit 1 =
-                                    a consumer waits ~5 us before it reads a ready env; default 0 */ };
+       PCC_TUNE_FUSED_DEBUG = 31 /* fused step, experiments: bit 0 (1) = an agent-scope release (buffer_wbl2) in front of every publication,
+                                    bit 2 (4) = no retire work before every env is sent (the halves one after the other inside the launch);
+                                    default 0 */ };
 int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
 
 /* How many steps of this handle ran as one launch so far (PCC_TUNE_FUSED; the others ran as a send and a retire launch):

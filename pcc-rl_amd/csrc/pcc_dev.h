@@ -166,7 +166,7 @@ struct Dev {
     uint32_t q_cap;                   // entries per queue (every env may end up in one)
     uint32_t fused_acquire;           // debug: 2 = an agent-scope acquire (L1 invalidate) before a ready env's state is read (see fused_retire_unit); 0 = none (default)
     uint32_t fused_spin_ticks;        // a wait of the fused step gives up (PCC_FLAG_INTERNAL) after this many 100 MHz ticks
-    uint32_t fused_debug;             // debug: bit 0 = an agent-scope release (buffer_wbl2) in front of every publication, bit 1 = a consumer waits ~5 us before it reads a ready env
+    uint32_t fused_debug;             // debug: bit 0 = an agent-scope release (buffer_wbl2) in front of every publication, bit 2 = no retire work before every env is sent (the halves one after the other inside the launch)
     uint32_t fused_partial_naps;      // tuning: ... and takes a unit of fewer envs than its lanes hold once it has waited this many naps
     uint32_t fused_max_naps;          // tuning: an idle wavefront of the fused step looks at the ready queues every 1, 2, 4 .. this many naps of ~0.9 us
     // [1] the retire half writes the step's sequence number (step_seq, below) here when an env finishes its episode;

@@ -112,29 +112,41 @@ __device__ __forceinline__ bool fused_retire_unit(const Dev &D, const uint32_t l
     const uint32_t slot = lane / (uint32_t)G;
     // (a claim can run past the queue's tail -- fused_retire_loop -- and, in a small batch with hundreds of idle wavefronts, past
     // the queue's storage: such an entry can never be filled)
-    bool has = slot < n_unit && c + slot < D.q_cap;
+    // The unit's granules, ONE load instruction per look for the whole wavefront: lane k < n_unit reads entry c + k (a look
+    // that every lane of every group executes for itself costs the compute unit's address path 16 cycles per instruction, and
+    // with a few thousand wavefronts waiting that was most of its capacity: the lane rounds next to them ran 3x slower).
+    // An entry below the queue's tail is reserved, its granule is on its way; one past it is filled by a later push -- or
+    // never, when the step is complete: then it is dropped.  (A claim can also run past the queue's storage in a small batch
+    // with hundreds of idle wavefronts: such an entry can never be filled.)
+    const bool mine = lane < n_unit && c + lane < D.q_cap;
     unsigned long long e = 0ull;
+    uint64_t ready = 0ull, valid = __ballot(mine);
     bool gave_up = false;
-    if (has) {   // (an entry below the queue's tail is reserved, its granule is on its way; one past it is filled by a later push --
-                 // or never, when the step is complete: then it is dropped)
-        e = __hip_atomic_load(ent + c + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(e >> 32) != D.step_seq) {
-            const uint64_t t0 = wall_clock64();
-            for (uint32_t spins = 0;; spins++) {
-                if (spins < 8u) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(32);   // (~0.1 us, then ~0.9 us)
-                e = __hip_atomic_load(ent + c + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(e >> 32) == D.step_seq) break;
-                uint32_t pushed = 0;
-                for (uint32_t x = 0; x < kXcds; x++) pushed += ld_u32_agent(fq_word(D, read_buf, x, kFPushed));
-                if (pushed >= total && c + slot >= ld_u32_agent(fq_word(D, read_buf, xcc, kFTail + q))) { has = false; break; }
+    {
+        const uint64_t t0 = wall_clock64();
+        for (uint32_t spins = 0;; spins++) {
+            if (mine && !((ready >> lane) & 1ull)) e = __hip_atomic_load(ent + c + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ready = __ballot(mine && (uint32_t)(e >> 32) == D.step_seq);
+            if ((ready & valid) == valid) break;
+            if (spins < 4u) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);   // (~0.2 us, then ~1.7 us)
+            if ((spins & 7u) == 7u) {   // now and then: is the step complete, and does the unit reach past the final tail?
+                uint32_t pushed = lane < kXcds ? ld_u32_agent(fq_word(D, read_buf, lane, kFPushed)) : 0u;
+                for (int o = 4; o; o >>= 1) pushed += (uint32_t)__shfl_xor((int)pushed, o);
+                pushed = uni_u32(pushed);
+                if (pushed >= total) {
+                    const uint32_t tail = uni_u32(ld_u32_agent(fq_word(D, read_buf, xcc, kFTail + q)));
+                    valid &= tail > c ? (tail - c >= 64u ? ~0ull : (1ull << (tail - c)) - 1ull) : 0ull;
+                }
                 if (wall_clock64() - t0 > (uint64_t)D.fused_spin_ticks) { gave_up = true; break; }
             }
         }
     }
-    if (__ballot(gave_up)) return false;
+    // lane l of group `slot` gets the group's env (entry c + slot) from the lane that read it
+    const bool has = ((valid >> slot) & 1ull) != 0ull;
+    e = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(e >> 32), (int)slot) << 32) | (uint32_t)__shfl((int)(uint32_t)e, (int)slot);
+    if (gave_up) return false;
     // Nothing to acquire across XCDs (the queue is this XCD's: pcc_dev.h).  The workgroup-scope fence keeps the compiler from
     // moving the env's loads above the poll; fused_acquire = 2 (debug) invalidates this compute unit's L1 as well.
-    if (D.fused_debug & 2u) for (int k = 0; k < 6; k++) __builtin_amdgcn_s_sleep(32);
     if (D.fused_acquire >= 2u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint64_t t_ready = prof_on(D) ? wall_clock64() : 0;
@@ -186,42 +198,55 @@ __device__ __forceinline__ void fused_retire_loop(const Dev &D, const uint32_t l
     for (int o = 32; o; o >>= 1) total += (uint32_t)__shfl_xor((int)total, o);
     total = uni_u32(total);
     uint32_t *head0 = fq_word(D, read_buf, xcc, kFHead), *head1 = fq_word(D, read_buf, xcc, kFHead + 1u);
-    const uint32_t *tail0 = fq_word(D, read_buf, xcc, kFTail), *tail1 = fq_word(D, read_buf, xcc, kFTail + 1u);
+    // what a look reads, ONE load instruction for the wavefront: lanes 0..3 the heads and tails of this XCD's queues, lanes
+    // 8..15 every XCD's count of published envs
+    const uint32_t *look = lane < 4u ? fq_word(D, read_buf, xcc, lane < 2u ? kFHead + lane : kFTail + (lane - 2u))
+                                     : fq_word(D, read_buf, (lane - 8u) & (kXcds - 1u), kFPushed);
+    const bool looks = lane < 4u || (lane >= 8u && lane < 8u + kXcds);
     const uint64_t t_start = wall_clock64();
     bool all = false;   // every env of the step has been published (then every tail is final)
     for (;;) {
         uint32_t q = 3u, c = 0u, n_unit = 0u;
-        if (lane == 0) {
+        {
             uint32_t naps = 1u, waited = 0u;   // (a nap: 32 x 64 cycles, ~0.9 us)
             for (;;) {
-                if (!all) {   // (read BEFORE the tails: found complete, the tails read after it are final)
-                    uint32_t pushed = 0;
-                    for (uint32_t x = 0; x < kXcds; x++) pushed += ld_u32_agent(fq_word(D, read_buf, x, kFPushed));
-                    all = pushed >= total;
+                // (the counts are read by the same instruction as the tails; found complete they are read once more, tails AFTER
+                // counts, so that the tails are final)
+                uint32_t v = looks ? ld_u32_agent(look) : 0u;
+                uint32_t pushed = (lane >= 8u && lane < 8u + kXcds) ? v : 0u;
+                for (int o = 4; o; o >>= 1) pushed += (uint32_t)__shfl_xor((int)pushed, o);
+                pushed = rl_u32(pushed, 8u);
+                if (!all && pushed >= total) {
+                    all = true;
+                    v = looks ? ld_u32_agent(look) : 0u;
                 }
-                const uint32_t h1 = ld_u32_agent(head1), t1 = ld_u32_agent(tail1), h0 = ld_u32_agent(head0), t0 = ld_u32_agent(tail0);
+                const uint32_t h0 = rl_u32(v, 0u), h1 = rl_u32(v, 1u), t0 = rl_u32(v, 2u), t1 = rl_u32(v, 3u);
                 const bool eager = all || waited >= D.fused_partial_naps;
+                if ((D.fused_debug & 4u) && !all) {   // (experiment: no retire work before every env is sent)
+                    for (uint32_t k = 0; k < naps; k++) __builtin_amdgcn_s_sleep(32);
+                    if (naps < D.fused_max_naps) naps *= 2u;
+                    if (wall_clock64() - t_start > (uint64_t)D.fused_spin_ticks) break;
+                    continue;
+                }
                 // A claim is one fetch-add of what was seen to be there; two wavefronts that saw the same envs both add, and the
-                // later one's share runs past the tail it saw: entries that are not reserved yet.  It keeps the part below the
-                // tail and gives nothing back -- the head then stands ahead of the tail for a while, and whoever publishes next
-                // fills entries that are already spoken for: so a claim past the tail is kept too, as long as the step is not
-                // complete (fused_retire_unit waits for the granules, and drops what lies past a final tail).
+                // later one's share runs past the tail it saw: entries that are not reserved yet.  It keeps them -- whoever
+                // publishes next fills entries that are already spoken for, and the wavefront that holds them starts at once
+                // (fused_retire_unit waits for the granules, and drops what lies past a final tail).
                 // (the wave-path classes first: their envs are the long ones)
                 if (h1 < t1 && (t1 - h1 >= (uint32_t)(kWave / 16) || eager)) {
                     n_unit = min(t1 - h1, (uint32_t)(kWave / 16));
-                    c = atomicAdd(head1, n_unit);
+                    if (lane == 0) c = atomicAdd(head1, n_unit);
                     q = 1u;
                     break;
                 }
                 if (h0 < t0 && (t0 - h0 >= (uint32_t)(kWave / 8) || eager)) {
                     n_unit = min(t0 - h0, (uint32_t)(kWave / 8));
-                    c = atomicAdd(head0, n_unit);
+                    if (lane == 0) c = atomicAdd(head0, n_unit);
                     q = 0u;
                     break;
                 }
                 if (all && h1 >= t1 && h0 >= t0) { q = 2u; break; }
-                // nothing (or too little) ready: back off -- thousands of idle wavefronts looking at the same lines every few hundred
-                // cycles keep the L2 channels that own them busy, and everybody's claims and pushes queue behind the looks
+                // nothing (or too little) ready: back off
                 for (uint32_t k = 0; k < naps; k++) __builtin_amdgcn_s_sleep(32);
                 waited += naps;
                 if (naps < D.fused_max_naps) naps *= 2u;
@@ -269,6 +294,10 @@ __global__ __launch_bounds__(4 * kWave, NS == 2 ? PCC_FUSED_OCC2 : PCC_FUSED_OCC
                                                                                               double *steps_out) {
     const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     if (blockIdx.x == 0) clear_list_buffer(D, zero_buf);
+    if (prof_on(D) && blockIdx.x == 0 && threadIdx.x == 0 && D.n >= 1024) {   // profile build: when this launch started, and which it is
+        D.timeline[(int64_t)19 * D.n + 1] = wall_clock64();
+        D.timeline[(int64_t)19 * D.n + 2] = D.step_seq;
+    }
     __shared__ SendLds<NS> lds;
     const uint32_t part = blockIdx.x & (D.parts - 1u);
     const uint32_t xcc = xcc_id();
@@ -279,6 +308,7 @@ __global__ __launch_bounds__(4 * kWave, NS == 2 ? PCC_FUSED_OCC2 : PCC_FUSED_OCC
     fused_light_loop<NS, TRACE>(D, lds, lane, wv, read_buf, part, actions, actions_f64, xcc);
     // (retire_on = 0, PCC_TUNE_FUSED = 2: an experiment -- this launch is the send half only, a retire launch follows)
     if (retire_on) fused_retire_loop<NS>(D, lane, read_buf, fill_buf, xcc, obs_out, reward_out, done_out, steps_out);
+
 }
 
 // (the fused step needs the buffer it files into clean BEFORE it starts; it clears the next one itself, so this runs only

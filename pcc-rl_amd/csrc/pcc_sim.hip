@@ -572,7 +572,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     sim->read_buf = -1;
     sim->fill_buf = 0;
     sim->clean_buf = -1;
-    sim->fused = 1;
+    sim->fused = 0;   // (measured slower than the two launches at full size: profiles/r05_fused_experiments.json)
     sim->fused_light_wgs = 32;   // light-first workgroups per partition (4 wavefronts each: a partition of 8 192 envs has ~105 light items)
     d.fused_acquire = 0u;
     d.fused_spin_ticks = 100000000u;   // 1 s of the 100 MHz clock

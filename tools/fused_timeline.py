@@ -36,16 +36,16 @@ for t in range(max(sample) + 1):
     raw = env.debug_timeline().astype(np.int64)
     items = raw[:2 * N]
     rblocks = (N + 7) // 8 + 1
-    units = raw[2 * N + 2 * rblocks + 1:].reshape(-1, 4)   # (the first row of the region is the running counter)
+    head = raw[2 * N + 2 * rblocks]                          # (the first row of the region: running counter, launch start, sequence number)
+    units = raw[2 * N + 2 * rblocks + 1:].reshape(-1, 4)
     tag = units[:, 0] >> 32
-    cur = units[tag == tag.max()]
+    cur = units[tag == int(head[2])]
     q = (cur[:, 0] >> 31) & 1
     envs = cur[:, 0] & 0x7FFFFFFF    # envs of the unit
     claim, ready, done = cur[:, 1], cur[:, 2], cur[:, 3]
-    # this launch's send items: the slots are not cleared between launches, the ones of this launch start after the launch before ended
-    lo = claim.min() - 20000      # 200 us before the first claim
-    it = items[(items[:, 0] > lo) & (items[:, 2] >= items[:, 0])]
-    t0 = min(it[:, 0].min(), claim.min())
+    # this launch's send items: the slots are not cleared between launches; block 0 stamps the launch's start (the others start within a microsecond)
+    t0 = int(head[1]) - 100
+    it = items[(items[:, 0] >= t0) & (items[:, 2] >= items[:, 0])]
     us = lambda x: (x - t0) / 100.0
     light = it[it[:, 3] == 0] if len(it) else it
     wavep = it[it[:, 3] > 0] if len(it) else it
