@@ -96,7 +96,7 @@ def pmc_passes(config, timeout_s=150):
             d = os.path.join(tmp, counter.lower())
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--config", str(config), "--steps", "400", "--warmup", "20", "--repeats", "1",
-                   "--no-cpu-baseline", "--no-pmc"]
+                   "--no-cpu-baseline", "--no-pmc", "--no-policy"]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s)
             except subprocess.TimeoutExpired:
@@ -219,6 +219,41 @@ def cpu_baseline(seconds_budget=15.0):
     return res
 
 
+def policy_in_loop(pcc_rl_amd, torch, N, dev, horizon=64):
+    """The real use of the env, timed in the same run: env-steps/s of PPO.collect() -- the fused policy kernel (pcc_policy_act: both
+    MLPs, the Gaussian sample from N(0, 1) noise, log-probability, value) writing the action row the env's step reads, `horizon`
+    steps -- and of rollout + GAE + the PPO epochs (pcc_ppo_minibatch_step), at the bench size.  An untrained policy's N(0, 1)
+    actions spread the rates further than the bench's U(-1, 1) do, so the env's own launches are slower here than in `value`."""
+    from pcc_rl_amd.ppo import PPO
+    env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
+    agent = PPO(env, horizon=horizon, seed=0, minibatch=max(2048, N * horizon // 4))
+    box = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def rollout():
+        box["b"] = agent.collect()
+
+    t_roll = timed(rollout, 3)
+    t_upd = timed(lambda: agent.update(*box["b"][:5]), 2)
+    env.check_flags()
+    env.close()
+    return {"rollout": {"value": N * horizon / t_roll, "unit": "env steps/s", "ms_per_step": 1e3 * t_roll / horizon},
+            "rollout_plus_update": {"value": N * horizon / (t_roll + t_upd), "unit": "env steps/s", "update_s": t_upd,
+                                    "fused_update": bool(agent.fused_update)},
+            "envs": N, "horizon": horizon,
+            "note": "PPO.collect() over %d envs x %d steps (fused policy kernel + step_into, N(0,1)-sampled actions of the untrained "
+                    "32-16 policy), then GAE + 4 epochs x 4 minibatches of the fused gradient step; 3 / 2 repetitions after one "
+                    "untimed; supplementary -- `value` is the env with pre-generated U(-1,1) actions (SURVEY.md section 8d)" % (N, horizon)}
+
+
 def async_groups(pcc_rl_amd, torch, N, dev, K, W, n_groups=4):
     """Supplementary figure, NOT the headline: the same N envs as independent groups on their own
     streams, stepped without a per-step synchronization between the groups (double-buffered
@@ -262,6 +297,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself")
     ap.add_argument("--ring-capacity", type=int, default=0, help="records per accepted ring (0 = library default)")
+    ap.add_argument("--no-policy", action="store_true",
+                    help="skip the supplementary policy_in_loop figures (PPO rollout and rollout + update at the bench size)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 counter passes that measure roofline.traffic (HBM bytes per launch)")
     ap.add_argument("--groups", type=int, default=0,
@@ -485,6 +522,16 @@ def main():
         order = sorted(range(R), key=lambda r: runs[r]["elapsed"])
         med = runs[order[R // 2]]
         value = world * N * K / med["elapsed"]
+        ms_per_step = 1e3 * med["elapsed"] / K
+        window_fields = None
+        if whole is not None:
+            # fewer timed steps than an episode: the K-step window has no episode boundary inside, and SURVEY.md section 8d's
+            # metric includes the auto-resets -- so `value` is the whole episodes' figure (three 400-step episodes with their
+            # boundary resets, timed by this run just before the window), and the window is reported next to it
+            window_fields = {"value": value, "ms_per_step": ms_per_step, "steps": K,
+                             "note": "the %d timed steps after the warm-up (the bench contract's K), placed where an episode has its mean "
+                                     "step time; no episode boundary inside" % K}
+            value, ms_per_step = whole["value"], whole["ms_per_step"]
         pk_per_step = med["packets"] / (N * K)
         send_ms, retire_ms = med["send_ms"], med["retire_ms"]
         roof_src = "the timed steps"
@@ -510,7 +557,7 @@ def main():
         out = {
             "metric": "env steps/sec (whole node) at 64k parallel envs",
             "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * med["elapsed"] / K, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": R, "runs_ms_per_step": [1e3 * r["elapsed"] / K for r in runs],
             "median_run_kernel_ms": {"send": med["send_ms"], "retire": med["retire_ms"], "first_steps": med["first_steps_ms"],
@@ -532,11 +579,16 @@ def main():
         out["distributed"] = {"backend": coll["backend"], "dist_world_size": coll["dist_world_size"], "rccl_version": coll["rccl_version"],
                               "per_rank_ms_per_step": med.get("per_rank_ms_per_step"), "rank_cpu_binding": numa_all,
                               "launcher": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else "plain"}
+        if window_fields is not None:
+            out["timed_window"] = window_fields
+            out["value_source"] = ("whole_episode: %d whole %d-step episodes with their boundary resets, run and timed before the %d-step "
+                                   "window (--steps < one episode); the window itself is `timed_window`" % (whole["episodes"], max_steps, K))
         if whole is not None:
             out["whole_episode"] = dict(whole, unit="env steps/s", steps=whole["episodes"] * max_steps,
-                                        note="%d whole %d-step episodes run before the timed steps (per-step HIP events on the "
-                                             "launch stream): the section-8d metric; `value` is the K-step window placed at "
-                                             "episode step window_start + warmup of the next episode" % (whole["episodes"], max_steps))
+                                        note="%d whole %d-step episodes run before the timed steps (a boundary event every 5 steps, the "
+                                             "kernels' own events on every 14th): the section-8d metric and, with --steps below one "
+                                             "episode, the line's `value`; the K-step window (`timed_window`) sits at episode step "
+                                             "window_start + warmup of the next episode" % (whole["episodes"], max_steps))
         send_gbps = send_bytes / (send_ms * 1e-3) / 1e9
         retire_gbps = retire_bytes / (retire_ms * 1e-3) / 1e9
         both = (send_bytes + retire_bytes) / ((send_ms + retire_ms) * 1e-3) / 1e9
@@ -591,6 +643,11 @@ def main():
                                           "two (send_kernel, retire_kernel)")
         if many is not None:
             out["many_steps_per_call"] = many
+        if world == 1 and cfg == 3 and not args.stagger and not args.no_policy and N >= 8192:
+            try:
+                out["policy_in_loop"] = policy_in_loop(pcc_rl_amd, torch, N, dev)
+            except Exception as e:   # (supplementary: never in the way of the line)
+                out["policy_in_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and args.groups > 1:
             out["async_groups"] = async_groups(pcc_rl_amd, torch, N, dev, K, W, args.groups)
         if not args.no_cpu_baseline and world == 1:

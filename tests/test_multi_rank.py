@@ -195,7 +195,7 @@ def test_one_rank_through_torchrun_equals_the_plain_run():
     """`--gpus 1` launched the way the driver launches N ranks (torch.distributed.run, RCCL process group of one rank)
     must measure what the plain single-process run measures: same value within a few per cent, and the line says which
     launcher and backend it went through."""
-    common = ["--gpus", "1", "--steps", "400", "--warmup", "20", "--repeats", "3", "--no-cpu-baseline", "--no-pmc"]
+    common = ["--gpus", "1", "--steps", "400", "--warmup", "20", "--repeats", "3", "--no-cpu-baseline", "--no-pmc", "--no-policy"]
     envv = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
 
     def run(cmd):

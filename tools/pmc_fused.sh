@@ -16,7 +16,7 @@ for mode in fused two; do
              "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
              "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum"; do
     rm -rf /tmp/pf_$i
-    timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pf_$i -o t -- python $R/bench.py $flag --steps 200 --warmup 20 --repeats 1 --no-cpu-baseline --no-pmc > /tmp/pf_$i.log 2>&1
+    timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pf_$i -o t -- python $R/bench.py $flag --steps 200 --warmup 20 --repeats 1 --no-cpu-baseline --no-pmc --no-policy > /tmp/pf_$i.log 2>&1
     echo "$mode" > /tmp/pf_$i/mode
     i=$((i+1))
   done

@@ -9,7 +9,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INST_CYCLES_SALU" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p -- python $R/bench.py --steps 400 --warmup 20 --repeats 1 --no-cpu-baseline --no-pmc > $O/p$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p -- python $R/bench.py --steps 400 --warmup 20 --repeats 1 --no-cpu-baseline --no-pmc --no-policy > $O/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections, json

@@ -9,7 +9,7 @@ for set in "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE" "TA_ADDR_STALLED_BY_TC_CYCL
            "TA_FLAT_WRITE_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM"; do
   rm -rf /tmp/ta_$i
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/ta_$i -o t -- python $R/bench.py --steps 60 --warmup 20 --repeats 1 --no-cpu-baseline > /tmp/ta_$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/ta_$i -o t -- python $R/bench.py --steps 60 --warmup 20 --repeats 1 --no-cpu-baseline --no-policy > /tmp/ta_$i.log 2>&1
   i=$((i+1))
 done
 python - "$OUT" <<'PY'
