@@ -232,7 +232,7 @@ def gen_single(ns, name, seeds, action_fn, n_steps=400, **kw):
         name, len(cases), n_steps, os.path.basename(path), os.path.getsize(path) / 1024.0))
 
 
-def gen_two_sender(ns, name, seeds, n_steps=200, cwnd=False, noise=False):
+def gen_two_sender(ns, name, seeds, n_steps=200, cwnd=False, noise=False, features=None, history_len=10):
     """Engine-level two-sender cases.
 
     SimulatedNetworkEnv never builds a second sender, so the harness drives the
@@ -243,11 +243,15 @@ def gen_two_sender(ns, name, seeds, n_steps=200, cwnd=False, noise=False):
     cwnd / noise switch the engine's dormant USE_CWND / USE_LATENCY_NOISE module flags on (ns:51-54: they are read by
     Network.run_for_dur for whatever senders it holds); with cwnd every sender gets its own [rate action, cwnd action]
     per step, applied like the env applies sender 0's (ns:412-414).
+
+    features / history_len (round 5): another observation shape for BOTH senders (the default three features and ten intervals
+    otherwise); such a file also keeps every sender's whole observation of every step (obs_full) and names its shape.
     """
     ns.Sender.__lt__ = lambda a, b: a.id < b.id
     ns.USE_CWND = bool(cwnd)
     ns.USE_LATENCY_NOISE = bool(noise)
-    feats = DEFAULT_FEATURES.split(",")
+    feats = (features or DEFAULT_FEATURES).split(",")
+    nf = len(feats)
     all_cases = []
     for seed in seeds:
         rng = CountingRandom(seed)
@@ -259,18 +263,23 @@ def gen_two_sender(ns, name, seeds, n_steps=200, cwnd=False, noise=False):
         r0 = rng.uniform(0.3, 1.5) * bw * 0.5
         r1 = rng.uniform(0.3, 1.5) * bw * 0.5
         links = [ns.Link(bw, lat, queue, loss), ns.Link(bw, lat, queue, loss)]
-        senders = [ns.Sender(r0, [links[0], links[1]], 0, feats, history_len=10),
-                   ns.Sender(r1, [links[0], links[1]], 0, feats, history_len=10)]
+        senders = [ns.Sender(r0, [links[0], links[1]], 0, feats, history_len=history_len),
+                   ns.Sender(r1, [links[0], links[1]], 0, feats, history_len=history_len)]
         net = ns.Network(senders, links)
         run_dur = 3 * lat
         net.run_for_dur(run_dur)
         net.run_for_dur(run_dur)
         warm = [net.cur_time, len(net.q)]
+        # the env's reset() ends with the observation of every sender (ns:484): the metrics of the history's empty intervals are
+        # evaluated (and cached, so:44-53) HERE, before the connection has a latency minimum -- not at the first step's get_obs()
+        for s_ in senders:
+            s_.get_obs()
         rs = np.random.RandomState(seed)
         actions = rs.uniform(-1.0, 1.0, (n_steps, 2))
         cwnd_actions = rs.uniform(-1.0, 3.0, (n_steps, 2)) if cwnd else np.zeros((n_steps, 2))
         rows = [[], []]
         obs_tail = [[], []]
+        obs_full = [[], []]
         cwnds = []
         for t in range(n_steps):
             for i in range(2):
@@ -288,7 +297,8 @@ def gen_two_sender(ns, name, seeds, n_steps=200, cwnd=False, noise=False):
                 reward = (10.0 * thr / (8 * ns.BYTES_PER_PACKET) - 1e3 * la - 2e3 * lo) * ns.REWARD_SCALE
                 vals = [mi.get(m) for m in METRICS]
                 obs = senders[i].get_obs()
-                obs_tail[i].append(np.asarray(obs, dtype=np.float64)[-3:])
+                obs_tail[i].append(np.asarray(obs, dtype=np.float64)[-nf:])
+                obs_full[i].append(np.asarray(obs, dtype=np.float64))
                 rows[i].append([senders[i].sent, senders[i].acked, senders[i].lost,
                                 senders[i].rate, net.cur_time, 0.0, reward] + [float(v) for v in vals])
             lat0 = mis[0].get("avg latency")
@@ -300,7 +310,7 @@ def gen_two_sender(ns, name, seeds, n_steps=200, cwnd=False, noise=False):
                               rng=[6, rng.n],
                               actions=actions, cwnd_actions=cwnd_actions, cwnd=np.array(cwnds, dtype=np.int64),
                               steps=np.array(rows, dtype=np.float64),
-                              obs_tail=np.array(obs_tail, dtype=np.float64)))
+                              obs_tail=np.array(obs_tail, dtype=np.float64), obs_full=np.array(obs_full, dtype=np.float64)))
     d = dict(seed=np.array([c["seed"] for c in all_cases], dtype=np.int64),
              params=np.array([c["params"] for c in all_cases], dtype=np.float64),
              warm=np.array([c["warm"] for c in all_cases], dtype=np.float64),
@@ -312,6 +322,10 @@ def gen_two_sender(ns, name, seeds, n_steps=200, cwnd=False, noise=False):
              obs_tail=np.stack([c["obs_tail"] for c in all_cases]),    # [case, sender, step, 3]
              columns=np.array(["sent", "acked", "lost", "rate", "cur_time", "run_dur",
                                "reward"] + METRICS))
+    if features is not None or history_len != 10:
+        d["obs_full"] = np.stack([c["obs_full"] for c in all_cases])   # [case, sender, step, history_len * features]
+        d["features"] = np.array(feats)
+        d["history_len"] = np.int64(history_len)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **d)
     print("%-28s %3d cases x %d steps  -> %s (%.0f KiB)" % (
@@ -364,6 +378,8 @@ def main():
         gen_two_sender(ns, "two_sender_cwnd", range(800, 804), cwnd=True)
         gen_two_sender(ns, "two_sender_noise", range(820, 824), noise=True)
         gen_two_sender(ns, "two_sender_cwnd_noise", range(840, 843), cwnd=True, noise=True)
+        # two senders with another observation shape: all 12 features, three intervals of history (both senders)
+        gen_two_sender(ns, "two_sender_allfeat_h3", range(860, 864), features=",".join(METRICS), history_len=3)
     finally:
         os.chdir(cwd)
 

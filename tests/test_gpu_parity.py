@@ -119,6 +119,44 @@ def test_two_sender_golden_bit_exact():
     env.close()
 
 
+def test_two_sender_golden_with_another_observation_shape_bit_exact():
+    """tests/golden/two_sender_allfeat_h3.npz (the reference's engine with two senders, all 12 features, three intervals of
+    history): every column and the WHOLE observation of both senders at every step -- the history / observation writer with
+    S = 2, F != 3, H != 10."""
+    d = load("two_sender_allfeat_h3")
+    env = golden_env(d, history_len=int(d["history_len"]), n_senders=2)
+    env.reset()
+    assert np.array_equal(env.state("now").cpu().numpy(), d["warm"][:, 0])
+    T = d["actions"].shape[1]
+    steps, obs, _ = run_gpu(env, d["actions"], T)
+    assert np.array_equal(steps[..., :3], d["steps"][..., :3])
+    assert np.array_equal(steps, d["steps"])
+    assert obs.shape == d["obs_full"].shape, (obs.shape, d["obs_full"].shape)
+    assert np.array_equal(obs, d["obs_full"].astype(np.float32))
+    env.close()
+
+
+@pytest.mark.parametrize("n_envs,n_steps,seed,n_senders,history_len", [(8193, 40, 21, 1, 10), (600, 60, 22, 2, 1), (8193, 30, 23, 2, 4)])
+def test_philox_batches_with_odd_shapes_match_oracle(n_envs, n_steps, seed, n_senders, history_len):
+    """Partitions with a one-env tail (8 193 envs = 8 partitions of 1 088 envs, the last one holding 577), two senders with a
+    history of one interval, two senders over ragged partitions: device-drawn parameters against the oracle, every column and
+    the whole observation."""
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, n_senders=n_senders, history_len=history_len,
+                                       record_steps=True, auto_reset=False)
+    obs0 = env.reset().cpu().numpy()
+    rs = np.random.RandomState(seed)
+    acts = rs.uniform(-1, 1.5, (n_envs, n_steps, n_senders) if n_senders > 1 else (n_envs, n_steps))
+    steps, obs, done = run_gpu(env, acts, n_steps)
+    ref = oracle.run_batch(acts, n_senders=n_senders, history_len=history_len, rng_mode=oracle.RNG_PHILOX, seed=seed)
+    assert np.array_equal(obs0, ref["obs0"].astype(np.float32))
+    bad = np.argwhere((steps[..., :3] != ref["steps"][..., :3]).any(axis=tuple(range(1, steps.ndim))))
+    assert bad.size == 0, "envs with count mismatches: %s" % bad[:10].ravel()
+    assert np.array_equal(steps, ref["steps"])
+    assert np.array_equal(obs, ref["obs"].astype(np.float32))
+    env.check_flags()
+    env.close()
+
+
 @pytest.mark.parametrize("n_envs,n_steps,seed", [(4096, 60, 11), (777, 400, 5)])
 def test_philox_batches_match_oracle(n_envs, n_steps, seed):
     """Randomized parameters drawn on the device vs the oracle drawing them on the host from the

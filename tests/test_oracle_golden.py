@@ -180,6 +180,28 @@ def test_two_sender_engine_bit_exact():
         env.close()
 
 
+def test_two_sender_engine_with_another_observation_shape_bit_exact():
+    """tests/golden/two_sender_allfeat_h3.npz: two senders, all 12 features, three intervals of history -- every step's whole
+    observation of both senders (the history / observation writer with S = 2, F != 3, H != 10)."""
+    d = load("two_sender_allfeat_h3")
+    feats, H = [str(f) for f in d["features"]], int(d["history_len"])
+    assert len(feats) == 12 and H == 3
+    for i in range(d["seed"].shape[0]):
+        bw, lat, queue, loss, r0, r1, run_dur0 = d["params"][i]
+        env = oracle.OracleEnv(2, H, feats)
+        env.rng_mt(int(d["seed"][i]), skip=6)
+        env.set_params(bw, lat, queue, loss, [r0, r1])
+        env.reset()
+        assert env.cur_time == d["warm"][i][0] and env.heap_len == int(d["warm"][i][1])
+        for t in range(d["actions"].shape[1]):
+            obs, rew, done, _ = env.step(d["actions"][i, t])
+            for s in range(2):
+                assert np.array_equal(env.last_row[s], d["steps"][i, s, t]), (i, s, t)
+                assert np.array_equal(obs[s], d["obs_full"][i, s, t]), (i, s, t)
+        assert env.rng_draws == int(d["rng"][i][1])
+        env.close()
+
+
 def test_survey_kats_seed0():
     """The numbers SURVEY.md section 8(c) quotes for seed 0."""
     d = load("default_pm1")

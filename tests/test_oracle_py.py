@@ -59,6 +59,22 @@ def test_two_senders():
                 assert np.array_equal(obs[s][-3:], d["obs_tail"][i, s, t])
 
 
+def test_two_senders_with_another_observation_shape():
+    d = load("two_sender_allfeat_h3")
+    feats, H = tuple(str(f) for f in d["features"]), int(d["history_len"])
+    for i in (0, 3):
+        bw, lat, queue, loss, r0, r1, _ = d["params"][i]
+        env = PyOracleEnv(seed=int(d["seed"][i]), n_senders=2, fixed=(bw, lat, queue, loss, r0, r1), ctor_draws=6,
+                          history_len=H, features=feats)
+        env.reset()
+        assert env.now == d["warm"][i][0]
+        for t in range(d["actions"].shape[1]):
+            obs, rew, done, _ = env.step(d["actions"][i, t])
+            for s in range(2):
+                assert np.array_equal(np.array(env.last_rows[s], dtype=np.float64), d["steps"][i, s, t]), (i, s, t)
+                assert np.array_equal(np.asarray(obs[s], dtype=np.float64), d["obs_full"][i, s, t]), (i, s, t)
+
+
 def test_use_cwnd_option():
     d = load("cwnd_pm1")
     for i in (0, 3):

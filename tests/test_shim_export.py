@@ -4,6 +4,8 @@ monitor-interval history against vectors generated from the unmodified reference
 import ast
 import os
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -124,3 +126,25 @@ def test_top_level_plugin_file_loads_like_the_reference_one():
     assert mod.get_rate(7) == shim.apply_rate_delta(6.0, 0.5) * 1e6
     mod.reset(7)
     assert mod.get_rate(7) == shim.apply_rate_delta(6.0, 0.5) * 1e6
+
+
+@pytest.mark.gpu
+def test_deployment_side_fixtures_on_the_gpu_box(tmp_path):
+    """The driver runs only `-m gpu` on the GPU box: the deployment side is checked there too --
+    the same fixture comparisons as above (they need no reference, only tests/golden/*.npz), and the export taken from a policy
+    that lives on the GPU, as a training run leaves it."""
+    test_wire_lines_equal_the_reference_plugins()
+    test_decode_takes_the_last_complete_line()
+    test_history_observations_equal_the_reference()
+    test_udt_plugin_module_equals_the_reference_loaded_client()
+    test_top_level_plugin_file_loads_like_the_reference_one()
+    torch.manual_seed(0)
+    pol = MlpPolicy(30, 1).to("cuda:0")
+    path = export.export_policy(pol, str(tmp_path), history_len=10, features="sent latency inflation,latency ratio,send ratio")
+    assert next(pol.parameters()).device.type == "cuda"          # the training policy stays where it is
+    loaded = torch.jit.load(path)
+    ob = torch.randn(5, 30)
+    act, stoch = loaded(ob)
+    with torch.no_grad():
+        mean = pol.pi(ob.to("cuda:0")).cpu()
+    assert torch.allclose(act, mean, atol=1e-6) and stoch.shape == act.shape == (5, 1)
