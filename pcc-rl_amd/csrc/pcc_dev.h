@@ -107,7 +107,7 @@ struct alignas(128) EnvBlk {
     uint32_t mi_draws;  //  96  send half: link-entry draws of the MI (a SEND the window blocks still draws)
     uint32_t ep_draws;  //      ... of the episode: the position in a replayed loss trace
     uint32_t flags;
-    uint32_t pad_h;
+    uint32_t params_gen;  // (a shadow block) the generation of the caller's parameters -- link arrays, ranges, seed -- its episode was drawn from
 };
 struct alignas(128) SndBlk {
     double rate, rate0;          //  0  send half (rate)
@@ -152,6 +152,9 @@ struct Dev {
     // XCD-affine partitions (see "partitions" below): the envs in `parts` contiguous id ranges of part_envs envs each
     uint32_t parts, parts_shift, part_envs;   // (parts = 1 << parts_shift)
     uint32_t key0, key1, gid_base;
+    uint32_t params_gen;   // generation of what a reset draws from (p_bw.., lo / hi, key0 / key1): every setter moves it, and a shadow
+                           // prepared under another generation is not swapped in (the env then restarts through the restart list,
+                           // which samples at reset time like the reference, ns:455-477)
     double delta_scale;
     uint32_t max_steps;
     uint32_t *cls_count;  // [3][parts][kClsStride] work lists of the send half (three buffers in rotation -- read / filed / cleared for the step after -- a set per partition): envs per class
@@ -355,6 +358,21 @@ struct RingRef {
 // in flight into the sender's own storage (load_env), after which the shadow can be refilled
 constexpr uint32_t kTierBorrowed = 0xFEu;
 constexpr uint32_t kShadowTier = 1u;  // a shadow's private rings have the size of tier 1
+
+// A shadow's state word -- the aligned 32 bits that hold EnvBlk::done (always 0 in a shadow) and EnvBlk::resetting (0 = ready,
+// 1 = being refilled, 2 = listed for a refill, 3 = unusable) -- is moved with atomics wherever two launches can meet:
+//   shadow_list: "to be refilled", and whether the caller has to append it to a refill row (it was not listed already: a
+//                swap and a masked reset of the same step, or two restarts, would otherwise list it twice -- two wavefronts
+//                refilling one shadow at once, and a row of N ids overflowing);
+//   shadow_claim (refill_kernel): listed -> being refilled, for exactly one wavefront.
+static_assert(offsetof(EnvBlk, resetting) == offsetof(EnvBlk, done) + 1 && offsetof(EnvBlk, done) % 4 == 0, "the shadow's state word");
+__device__ __forceinline__ bool shadow_list(EnvBlk *sh) {
+    const uint32_t old = atomicExch(reinterpret_cast<uint32_t *>(&sh->done), 2u << 8);
+    return ((old >> 8) & 0xFFu) != 2u;
+}
+__device__ __forceinline__ bool shadow_claim(EnvBlk *sh) {
+    return atomicCAS(reinterpret_cast<uint32_t *>(&sh->done), 2u << 8, 1u << 8) == (2u << 8);
+}
 
 __device__ __forceinline__ int64_t sidx(const Dev &D, int s, int64_t i) { return (int64_t)s * D.stride + i; }
 __device__ __forceinline__ int64_t env_of(const Dev &D, int64_t i) { return i >= D.n ? i - D.n : i; }  // block index -> env id

@@ -1396,7 +1396,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             // (a shadow is trusted three steps after the launch that prepared it was queued: the caller's stream has waited
             // for that launch by then -- pcc_sim.hip -- so every line of it is what the refill wrote)
             const bool ok = (restart & 2) != 0 && D.env[sh].resetting == 0 && D.env[sh].episode == D.env[i].episode + 1u &&
-                            D.step_seq - D.env[sh].fill_seq >= 3u;
+                            D.step_seq - D.env[sh].fill_seq >= 3u && D.env[sh].params_gen == D.params_gen;
             if (ok) {
                 D.env[i].bw = D.env[sh].bw; D.env[i].dl = D.env[sh].dl; D.env[i].lr = D.env[sh].lr; D.env[i].maxq = D.env[sh].maxq;
                 D.env[i].ebw = D.env[sh].ebw; D.env[i].episode = D.env[sh].episode;
@@ -1420,10 +1420,11 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
                     rates += D.snd[ks].rate;
                 }
                 filed = (float)(D.env[sh].run_dur * rates);   // (the class of the new episode's first interval)
-                D.env[sh].resetting = 2;                       // consumed: the refill kernel prepares the episode after this one
-                const uint32_t row = D.step_seq & 3u;
-                const uint32_t at = atomicAdd(&D.refill_count[row * kCntStride], 1u);
-                D.refill_list[(size_t)row * (size_t)D.n + at] = (uint32_t)i;
+                if (shadow_list(&D.env[sh])) {                 // consumed: the refill kernel prepares the episode after this one
+                    const uint32_t row = D.step_seq & 3u;
+                    const uint32_t at = atomicAdd(&D.refill_count[row * kCntStride], 1u);
+                    D.refill_list[(size_t)row * (size_t)D.n + at] = (uint32_t)i;
+                }
                 atomicAdd(&D.restart_stats[0], 1ull);
             } else {
                 D.env[i].resetting = 2;

@@ -35,8 +35,7 @@ __global__ __launch_bounds__(4 * kWave, PCC_RESTART_OCC) void send_restart_kerne
         const int64_t i = has ? (int64_t)cls_list_of(D, list_view(D, read_buf, part), (uint32_t)kRestart)[t] : 0;
         // new links and fresh state (ns:469-477) unless a flush already did all of it (pcc_get_state, a masked reset)
         if (has && D.env[i].resetting == 2) reset_env<NS>(D, i, nullptr);
-        if (has && D.shadows) {   // its shadow (if any) was not usable: have it prepared for the episode after this one
-            D.env[D.n + i].resetting = 2;
+        if (has && D.shadows && shadow_list(&D.env[D.n + i])) {   // its shadow (if any) was not usable: have it prepared for the episode after this one
             const uint32_t row = D.step_seq & 3u;
             D.refill_list[(size_t)row * (size_t)D.n + atomicAdd(&D.refill_count[row * kCntStride], 1u)] = (uint32_t)i;
         }
@@ -77,10 +76,10 @@ __global__ __launch_bounds__(4 * kWave, PCC_RESTART_OCC) void refill_kernel(Dev 
         const int64_t ie = (int64_t)D.refill_list[(size_t)row * (size_t)D.n + t];
         const int64_t i = D.n + ie;   // the shadow's block
         bool go = false;
-        if (has && D.env[i].resetting == 2) {
+        if (has && shadow_claim(&D.env[i])) {   // (listed -> being refilled: one wavefront, whoever else lists or holds the id)
             D.env[i].episode = D.env[ie].episode;   // the episode after the one the env is running
             D.env[i].fill_seq = fill_seq;
-            D.env[i].resetting = 1;
+            D.env[i].params_gen = D.params_gen;     // (what its links are drawn from: the swap asks for the same generation)
             D.env[i].total_sent = 0;
             D.env[i].flags = 0;
 #pragma unroll

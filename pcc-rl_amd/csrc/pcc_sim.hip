@@ -504,6 +504,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     const double lo[5] = {100, 0.05, 0, 0.0, 0.3}, hi[5] = {500, 0.5, 8, 0.05, 1.5};  // ns:355-358,466
     memcpy(d.lo, lo, sizeof lo); memcpy(d.hi, hi, sizeof hi);
     d.rng_mode = PCC_RNG_PHILOX;
+    d.params_gen = 1u;
     sim->device = device;
     sim->state_bytes = carve_state(d, nullptr);
     if (hipMalloc(&sim->state_blob, sim->state_bytes) != hipSuccess) {
@@ -662,11 +663,26 @@ int64_t pcc_device_bytes(const pcc_sim_t *sim) {
     return sim ? (int64_t)(sim->state_bytes + sim->ring_bytes + sim->list_bytes + sim->noise_bytes + sim->shadow_bytes) : 0;
 }
 
+namespace {
+// What the next reset of an env draws from -- the caller's link arrays, the ranges, the seed, the uniforms -- has changed.
+// Shadows (next episodes prepared ahead of time, pcc_send_restart.hip) were drawn from the OLD generation: none of them may be
+// swapped in any more (retire_env compares generations; the env restarts through the restart list, which samples at reset
+// time like the reference, ns:455-477, and its shadow is prepared again from there).  And no refill launch that is still queued
+// on the side stream may read the caller's old arrays after this call returns: wait for them.
+void params_changed(pcc_sim_t *sim) {
+    if (++sim->d.params_gen == 0u) sim->d.params_gen = 1u;
+    DeviceGuard guard(sim->device);
+    for (int k = 0; k < 4; k++)
+        if (sim->refill_recorded[k]) (void)hipEventSynchronize(sim->ev_refill[k]);
+}
+}  // namespace
+
 int pcc_set_link_params(pcc_sim_t *sim, const double *bw, const double *dl, const double *queue, const double *loss,
                         const double *rate0) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     const int given = (bw != nullptr) + (dl != nullptr) + (queue != nullptr) + (loss != nullptr) + (rate0 != nullptr);
     if (given != 0 && given != 5) return fail(PCC_EINVAL, "pass all five parameter arrays or none");
+    params_changed(sim);
     sim->d.p_bw = bw; sim->d.p_dl = dl; sim->d.p_queue = queue; sim->d.p_loss = loss; sim->d.p_rate0 = rate0;
     return PCC_OK;
 }
@@ -682,12 +698,14 @@ int pcc_set_param_ranges(pcc_sim_t *sim, const double *lo, const double *hi) {
     if (!(lo[2] >= 0.0) || !(hi[2] <= 20.0)) return fail(PCC_EINVAL, "queue exponent range must lie in [0, 20] (queue = 1 + floor(e^x))");
     if (!(lo[3] >= 0.0) || !(hi[3] <= 1.0)) return fail(PCC_EINVAL, "loss range must lie in [0, 1]");
     if (!(lo[4] > 0.0)) return fail(PCC_EINVAL, "the starting-rate factor must be positive");
+    params_changed(sim);
     for (int k = 0; k < 5; k++) { sim->d.lo[k] = lo[k]; sim->d.hi[k] = hi[k]; }
     return PCC_OK;
 }
 
 int pcc_set_rng(pcc_sim_t *sim, int mode, const double *trace, int64_t trace_stride) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    params_changed(sim);   // (a replayed trace and Philox draws do not mix inside an episode prepared ahead of time)
     if (mode == PCC_RNG_PHILOX) {
         sim->d.rng_mode = mode; sim->d.trace = nullptr; sim->d.trace_stride = 0;
         return PCC_OK;
@@ -702,6 +720,7 @@ int pcc_set_rng(pcc_sim_t *sim, int mode, const double *trace, int64_t trace_str
 
 int pcc_set_seed(pcc_sim_t *sim, uint64_t seed) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    params_changed(sim);
     sim->d.key0 = (uint32_t)seed;
     sim->d.key1 = (uint32_t)(seed >> 32);
     return PCC_OK;
@@ -896,6 +915,9 @@ int pcc_set_max_steps(pcc_sim_t *sim, int max_steps) {
 
 int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
+    // (a masked reset pushes the ring slots its envs hold back onto the pools' stacks: before the first full reset -- or
+    // after the pools were rebuilt, which asks for one -- the senders' slot ids mean nothing)
+    if (mask && !sim->ever_reset) return fail(PCC_ESTATE, "a masked pcc_reset needs a full pcc_reset (mask = NULL) before it");
     DeviceGuard guard(sim->device);
     sim->last_stream = static_cast<hipStream_t>(stream);
     if (!mask) {

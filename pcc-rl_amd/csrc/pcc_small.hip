@@ -91,10 +91,9 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
     // use_done 1: the envs that finished their episode; 2: the envs a retire launch marked for a restart
     const bool sel = use_done == 2 ? D.env[i].resetting == 2 : (!mask || mask[i]) && (!use_done || D.env[i].done);
     D.env[i].resetting = sel ? 1 : 0;
-    if (sel && D.shadows && !all_envs) {
+    if (sel && D.shadows && !all_envs && shadow_list(&D.env[D.n + i])) {
         // a reset that is not the env's own episode end overtakes its shadow (prepared for the episode index this reset now
-        // takes): have the shadow prepared again, for the episode after this one
-        D.env[D.n + i].resetting = 2;
+        // takes): have the shadow prepared again, for the episode after this one (listed once, whoever else lists it in this step)
         const uint32_t row = D.step_seq & 3u;
         D.refill_list[(size_t)row * (size_t)D.n + atomicAdd(&D.refill_count[row * kCntStride], 1u)] = (uint32_t)i;
     }
@@ -106,12 +105,14 @@ __global__ __launch_bounds__(kWave) void reset_init_kernel(Dev D, const uint8_t 
 
 // pcc_set_ring_pools: every sender back in its own tier-0 rings, holding no pool slot (the pools are being replaced)
 __global__ void forget_ring_slots_kernel(Dev D) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= D.n * D.ns) return;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.n * D.ns) return;
+    const int64_t s = j / D.n, i = j % D.n;
+    const int64_t k = sidx(D, (int)s, i);   // (sender blocks are [S][2 N]: every env's block is followed, N blocks on, by its shadow's)
     for (int c = 0; c < kMaxTiers; c++) D.snd[k].ring_held[c] = 0;
     D.snd[k].ring_tier = 0;
-    const int64_t s = k / D.n, i = k % D.n;
     D.snd[k].ring_base = D.tier_base[0] + (size_t)(i * D.ns + s) * tier_slot_bytes(D, 0);
+    // (the shadow's blocks hold no pool slot -- a refill never touches a pool -- and keep their private rings)
 }
 
 }  // namespace

@@ -31,6 +31,17 @@ def mlp(inp, hidden, out):
     return nn.Sequential(*layers)
 
 
+_warned = set()
+
+
+def _warn_once(msg):
+    """A fallback off the HIP kernels of this caller is never silent (once per message and process)."""
+    if msg not in _warned:
+        _warned.add(msg)
+        import warnings
+        warnings.warn("pcc_rl_amd.ppo: " + msg, RuntimeWarning, stacklevel=3)
+
+
 class MlpPolicy(nn.Module):
     """pi and vf networks of src/gym/stable_solve.py:39-45 (net_arch = [dict(pi=arch, vf=arch)])
     with a state-independent log-std, as stable-baselines' diagonal Gaussian head."""
@@ -89,6 +100,7 @@ class MlpPolicy(nn.Module):
 
         from .native import lib
         if not self.fused_ok(obs):
+            _warn_once("the policy forward runs on the framework path (no pcc_policy_act for this policy / observation batch)")
             return self.act(obs, stochastic)
         linears = [m for m in self.pi if isinstance(m, nn.Linear)]
         n, D = obs.shape
@@ -106,6 +118,8 @@ class MlpPolicy(nn.Module):
                                   ptr(noise if stochastic else None), None, ptr(a), ptr(logp), ptr(v),
                                   ctypes.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
         if rc != 0:   # e.g. an observation length without a kernel instantiation
+            _warn_once("pcc_policy_act has no kernel for %d observations x hidden %d-%d: the policy forward runs on the framework "
+                       "path (several times slower)" % (D, linears[0].out_features, linears[1].out_features))
             a2, logp2, v2 = self.act(obs, stochastic)
             if out is not None:
                 a.copy_(a2.reshape(-1)); logp.copy_(logp2); v.copy_(v2)
@@ -172,10 +186,16 @@ class PPO(object):
         if hasattr(env, "groups"):   # GroupedNetworkEnv: the surface of a BatchedNetworkEnv, from its groups
             env.obs_dim, env.n_senders = env.groups[0].obs_dim, env.groups[0].n_senders
         self.policy = MlpPolicy(env.obs_dim, 1, arch).to(env.device)
+        if hasattr(env, "groups") and not (len(arch) == 2 and env.n_senders == 1 and torch.device(env.device).type == "cuda"):
+            # (a GroupedNetworkEnv is stepped group by group on its streams by the fused rollout only: it has no step() of its own)
+            raise ValueError("PPO over a GroupedNetworkEnv needs the fused rollout (a two-hidden-layer policy, one sender, on the GPU)")
         self.lr, self.adam_eps = lr, 1e-5
         # the fused optimiser step (pcc_ppo_minibatch_step: gradient + Adam in two launches) when the library has a kernel
         # for this shape; the framework path (autograd + torch.optim.Adam, the same arithmetic) otherwise
         self.fused_update = bool(fused_update) and self._fused_update_ok()
+        if fused_update and not self.fused_update:
+            _warn_once("PPO.update runs autograd + torch.optim.Adam (no pcc_ppo_minibatch_step for observation length %d, hidden %s, "
+                       "%d sender(s) on %s): about 20x slower than the fused step" % (env.obs_dim, list(arch), env.n_senders, env.device))
         if self.fused_update:
             from .native import lib
             self.flat = self.policy.share_flat()

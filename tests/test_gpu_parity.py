@@ -568,6 +568,58 @@ def test_envs_out_of_lockstep_match_oracle():
     env.close()
 
 
+def test_new_link_params_out_of_lockstep_apply_at_every_envs_next_reset():
+    """set_link_params while the envs are out of lockstep: like the reference (ns:455-477 samples at reset time) every env takes
+    the new links at ITS next reset -- also the envs whose next episode had already been prepared ahead of time in a shadow
+    (csrc/pcc_send_restart.hip) from the old parameters: such a shadow is of another generation and must not be swapped in.
+    Every env against its own oracle object, all columns and observations, across the change and two more episodes."""
+    n, seed, max_steps, T, t_change = 96, 17, 20, 90, 33
+    env = pcc_rl_amd.BatchedNetworkEnv(n, device=DEV, seed=seed, record_steps=True, auto_reset=True, max_steps=max_steps)
+    oenvs = []
+    for i in range(n):
+        o = oracle.OracleEnv()
+        o.rng_philox(seed, i)
+        oenvs.append(o)
+    obs = env.reset().cpu().numpy()
+    assert np.array_equal(obs, np.stack([o.reset() for o in oenvs]).astype(np.float32))
+    osteps = np.zeros(n, dtype=int)
+    rs = np.random.RandomState(6)
+    idx = np.arange(n)
+    new = dict(bw=150.0 + idx, dl=0.04 + 0.001 * idx, queue=5.0 + (idx % 40), loss=0.002 * (idx % 10), rate0=90.0 + 2.0 * idx)
+    for t in range(T):
+        if t < 20 and t % 5 == 2:      # stagger the episode phases (masked resets), so that shadows come into use
+            mask = (idx % 4) == ((t // 5) % 4)
+            got = env.reset(torch.as_tensor(mask)).cpu().numpy()
+            for i in idx[mask]:
+                want = oenvs[i].reset()
+                osteps[i] = 0
+                assert np.array_equal(got[i], want.astype(np.float32)), (t, i)
+        if t == t_change:
+            env.set_link_params(new["bw"], new["dl"], new["queue"], new["loss"], new["rate0"])
+            for i in range(n):
+                oenvs[i].set_params(new["bw"][i], new["dl"][i], new["queue"][i], new["loss"][i], [new["rate0"][i]])
+        a = rs.uniform(-1, 1.2, n)
+        o_gpu, r_gpu, d_gpu, info = env.step(torch.as_tensor(a, device=DEV))
+        rows = info["steps"].cpu().numpy()
+        o_gpu, d_gpu = o_gpu.cpu().numpy(), d_gpu.cpu().numpy()
+        for i in range(n):
+            o_ref, r_ref, _, _ = oenvs[i].step(a[i])
+            osteps[i] += 1
+            done = osteps[i] >= max_steps
+            assert np.array_equal(rows[i], oenvs[i].last_row[0]), (t, i)
+            assert bool(d_gpu[i]) == done, (t, i)
+            if done:
+                o_ref = oenvs[i].reset()
+                osteps[i] = 0
+            assert np.array_equal(o_gpu[i], o_ref.astype(np.float32)), (t, i)
+    # every env has restarted since the change: its link is the new one
+    assert np.array_equal(env.state("bw").cpu().numpy(), new["bw"])
+    stats = env.restart_stats()
+    assert stats["shadow_swaps"] > 0, stats          # (the shadows were in use: the test saw what it is about)
+    env.check_flags()
+    env.close()
+
+
 def test_two_senders_out_of_lockstep_match_oracle():
     """The same schedule with two senders on the link (restart items run the two-sender wave path and both senders'
     warm-up retires): masked resets, then auto-resets at each env's own episode end, every env against its oracle."""
