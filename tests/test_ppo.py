@@ -64,17 +64,21 @@ def test_policy_shapes():
 
 
 @pytest.mark.gpu
-def test_short_training_run_improves_reward():
-    """Whole-episode iterations (horizon = 400 steps) so every iteration averages the same mix of
-    episode phases; a handful of PPO iterations must raise the mean reward."""
+def test_short_training_run_beats_the_random_policy_by_a_margin():
+    """Whole-episode iterations (horizon = 400 steps) so every iteration averages the same mix of episode phases.  The first
+    iterations ARE the random policy (N(0, 1) actions around a zero-initialised mean: ~300 per episode); ten iterations at
+    1 024 envs (4.1e6 env-steps, the reference's whole budget) must lift the episode return by half of that at least
+    (measured: ~295 -> ~615; profiles/r05_learning_curve.json has the long run: 289 -> 814 in 2e8 env-steps, and the trained
+    controller against baselines on held-out envs)."""
     import pcc_rl_amd
     from pcc_rl_amd.ppo import PPO
     env = pcc_rl_amd.BatchedNetworkEnv(1024, device="cuda:0", seed=3)
     agent = PPO(env, horizon=400, seed=0)
-    rewards = [agent.iterate()["mean_step_reward"] for _ in range(6)]
+    returns = [agent.iterate()["mean_step_reward"] * env.max_steps for _ in range(10)]
     env.check_flags()
-    assert all(np.isfinite(r) for r in rewards)
-    assert max(rewards[3:]) > rewards[0], rewards
+    assert all(np.isfinite(r) for r in returns)
+    random_policy = sum(returns[:2]) / 2
+    assert sum(returns[-3:]) / 3 > 1.5 * random_policy, returns
 
 
 @pytest.mark.gpu
