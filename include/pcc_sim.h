@@ -127,8 +127,11 @@ const char *pcc_last_error(void);
  *                   default) and is moved -- at the start of a monitor interval whose packets
  *                   could overflow them -- into rings 4x, 16x, ... as large taken from shared
  *                   pools.  Pool rings are held until the env is reset, so a pool with a slot for
- *                   every sender can never run dry; by default the pools get what a third of the
- *                   device memory that is free at creation pays for (65 536 senders on an idle
+ *                   every sender can never run dry; by default the pools are allocated at the handle's
+ *                   FIRST pcc_reset (not here: a caller that names their sizes with pcc_set_ring_pools allocates
+ *                   them once, and handles created side by side do not all size themselves from the same free
+ *                   figure) and get what a third of the
+ *                   device memory that is free then pays for (65 536 senders on an idle
  *                   288 GB MI355X: a slot for every sender in tiers 1 and 2 and for every second one
  *                   in tier 3, 83 GB), never less than slots for 1/2, 1/8, 1/32 of the senders
  *                   (6.4 GB at 65 536: what U(-1, 1) policies need; pcc_set_ring_pools sets the

@@ -54,6 +54,7 @@ struct pcc_sim {
     void *noise_blob;   // heap + RTT samples of the latency-noise option (allocated when it is switched on)
     size_t noise_bytes;
     uint32_t ring_capacity;
+    bool pools_pending;     // the pools of tiers >= 1 are not allocated yet (they are sized at the first reset, or by pcc_set_ring_pools)
     bool restarts_pending;  // a retire launch may have left envs in the restart list (their warm-up intervals are due)
     bool read_has_restarts; // the list buffer read_buf was filed by a retire launch that resets finished envs (restart list)
     uint32_t list_min_envs; // batches below this size are stepped without work lists (index order)
@@ -513,36 +514,16 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         return fail(PCC_ENOMEM, "hipMalloc(%zu) for env state failed", want);
     }
     carve_state(d, static_cast<char *>(sim->state_blob));
-    // Pool sizes.  A sender keeps the slots it was promoted into until its env is reset, so the pools of tiers 1, 2, 3 can
-    // never run dry when each has a slot for every sender (divisor 1) -- and a policy that climbs towards the rate limit on
-    // every link (what PPO learns on generous links) does need most of that.  An MI355X has 288 GB: the pools get what a
-    // third of the memory that is free right now pays for, the largest tier halved first (round 3 sized them for U(-1, 1)
-    // policies -- divisors 2, 8, 32, measured need ~25 %, ~2 %, ~0.02 % of the senders -- and a saturating policy ended a
-    // training run with PCC_FLAG_POOL_EXHAUSTED); those divisors are the floor.  pcc_set_ring_pools overrides.
-    unsigned div[kMaxTiers] = {1, 1, 1, 1};
-    {
-        const unsigned floor_div[kMaxTiers] = {1, 2, 8, 32};
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        const double budget = 0.33 * (double)free_b;
-        const double senders = (double)n_envs * n_senders;
-        auto tier_bytes = [&](int c) { return senders / div[c] * 3.0 * (double)((size_t)d.cap0 << (2 * c)) * sizeof(double2); };
-        for (;;) {
-            double total = 0.0;
-            int big = -1;
-            for (int c = 1; c < d.n_tiers; c++) {
-                total += tier_bytes(c);
-                if (div[c] < floor_div[c] && (big < 0 || tier_bytes(c) > tier_bytes(big))) big = c;
-            }
-            if (total <= budget || big < 0) break;
-            div[big] *= 2;
-        }
-    }
+    // Tier 0 (a slot per sender) now; the pools of tiers 1, 2, 3 when the handle is first reset (ensure_pools: sized from the
+    // device memory that is free THEN) or when pcc_set_ring_pools names their sizes -- so a caller that sets them allocates
+    // them once, and handles that are created side by side do not each claim a third of the same free memory before any of
+    // them has allocated (round 4 allocated and zeroed the default pools, 85 GB for 65 536 envs, inside pcc_create).
     sim->ring_bytes = 0;
-    for (int c = 0; c < d.n_tiers; c++) {
-        const int rc = alloc_tier(sim, c, div[c]);
+    {
+        const int rc = alloc_tier(sim, 0, 1);
         if (rc != PCC_OK) { pcc_destroy(sim); return rc; }
     }
+    sim->pools_pending = d.n_tiers > 1;
     // partitions: batches that run with work lists (every XCD then keeps to its own eighth of the rings); smaller ones and
     // whatever runs without lists gain nothing from them
     set_parts(sim, n_envs >= 8192 ? kParts : 1u);
@@ -550,7 +531,6 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
         pcc_destroy(sim);
         return fail(PCC_EHIP, "initialising the env state failed");
     }
-    if (init_pool_stacks(sim) != PCC_OK) { pcc_destroy(sim); return PCC_EHIP; }
     if (kProfile && getenv("PCC_DEBUG_TIMELINE") && atoi(getenv("PCC_DEBUG_TIMELINE"))) {  // profile build only
         sim->timeline_bytes = (size_t)n_envs * 4 * 8 * sizeof(uint64_t);
         if (hipMalloc(&sim->timeline_blob, sim->timeline_bytes) != hipSuccess ||
@@ -783,7 +763,7 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             DeviceGuard guard(sim->device);
             if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "hipDeviceSynchronize failed");
             set_parts(sim, (uint32_t)value);
-            const int rc = init_pool_stacks(sim);
+            const int rc = sim->pools_pending ? PCC_OK : init_pool_stacks(sim);   // (pools that do not exist yet get their stacks with them)
             if (rc != PCC_OK) return rc;
             launch_forget_ring_slots(sim->d, nullptr);
             if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "forget_ring_slots_kernel failed");
@@ -835,6 +815,48 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
     }
 }
 
+namespace {
+// The pools of tiers 1, 2, 3 with a slot for one sender in div[c] (tier 0 is a slot per sender), their free stacks full.
+int alloc_pools(pcc_sim_t *sim, const unsigned (&div)[kMaxTiers]) {
+    Dev &d = sim->d;
+    for (int c = 1; c < d.n_tiers; c++) {
+        const int rc = alloc_tier(sim, c, div[c]);
+        if (rc != PCC_OK) return rc;
+    }
+    sim->pools_pending = false;
+    return init_pool_stacks(sim);
+}
+
+// Default pool sizes, at the handle's first reset.  A sender keeps the slots it was promoted into until its env is reset, so
+// the pools of tiers 1, 2, 3 can never run dry when each has a slot for every sender (divisor 1) -- and a policy that climbs
+// towards the rate limit on every link (what PPO learns on generous links) does need most of that.  An MI355X has 288 GB: the
+// pools get what a third of the memory that is free right now pays for, the largest tier halved first (round 3 sized them
+// for U(-1, 1) policies -- divisors 2, 8, 32, measured need ~25 %, ~2 %, ~0.02 % of the senders -- and a saturating policy
+// ended a training run with PCC_FLAG_POOL_EXHAUSTED); those divisors are the floor.  pcc_set_ring_pools overrides.
+int ensure_pools(pcc_sim_t *sim) {
+    if (!sim->pools_pending) return PCC_OK;
+    Dev &d = sim->d;
+    unsigned div[kMaxTiers] = {1, 1, 1, 1};
+    const unsigned floor_div[kMaxTiers] = {1, 2, 8, 32};
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const double budget = 0.33 * (double)free_b;
+    const double senders = (double)d.n * d.ns;
+    auto tier_bytes = [&](int c) { return senders / div[c] * 3.0 * (double)((size_t)d.cap0 << (2 * c)) * sizeof(double2); };
+    for (;;) {
+        double total = 0.0;
+        int big = -1;
+        for (int c = 1; c < d.n_tiers; c++) {
+            total += tier_bytes(c);
+            if (div[c] < floor_div[c] && (big < 0 || tier_bytes(c) > tier_bytes(big))) big = c;
+        }
+        if (total <= budget || big < 0) break;
+        div[big] *= 2;
+    }
+    return alloc_pools(sim, div);
+}
+}  // namespace
+
 int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t div3) {
     if (!sim) return fail(PCC_EINVAL, "sim is NULL");
     if (sim->send_pending) return fail(PCC_ESTATE, "pcc_set_ring_pools between pcc_step_send and pcc_step_retire");
@@ -844,11 +866,7 @@ int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t di
     DeviceGuard guard(sim->device);
     if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "hipDeviceSynchronize failed");
     Dev &d = sim->d;
-    for (int c = 1; c < d.n_tiers; c++) {
-        const int rc = alloc_tier(sim, c, div[c]);
-        if (rc != PCC_OK) return rc;
-    }
-    { const int rc = init_pool_stacks(sim); if (rc != PCC_OK) return rc; }
+    { const int rc = alloc_pools(sim, div); if (rc != PCC_OK) return rc; }
     launch_forget_ring_slots(d, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) return fail(PCC_EHIP, "forget_ring_slots_kernel failed");
     sim->ever_reset = false;  // whatever was in flight lived in the old pools: a reset must follow
@@ -919,6 +937,7 @@ int pcc_reset(pcc_sim_t *sim, const uint8_t *mask, float *obs_out, void *stream)
     // after the pools were rebuilt, which asks for one -- the senders' slot ids mean nothing)
     if (mask && !sim->ever_reset) return fail(PCC_ESTATE, "a masked pcc_reset needs a full pcc_reset (mask = NULL) before it");
     DeviceGuard guard(sim->device);
+    { const int rc = ensure_pools(sim); if (rc != PCC_OK) return rc; }
     sim->last_stream = static_cast<hipStream_t>(stream);
     if (!mask) {
         sim->restarts_pending = false;  // everything starts over
