@@ -130,6 +130,10 @@ def test_hot_kernels_do_not_spill():
         if name != "send_kernel<1, true>":   # (the trace build reserves 20 bytes it never touches: no scratch instruction in its code)
             assert r["scratch"] == 0, (name, r)
     assert res["send_kernel<1, false>"]["occupancy"] == 4 and res["retire_kernel<1, false>"]["occupancy"] == 4
+    # the one-launch step (experimental, off by default): the register budget and the occupancy of the two launches; what it spills
+    # (a dozen registers around its retire loop, none in a hot loop: pcc-rl_amd/csrc/pcc_fused.hip) stays small
+    f = res["step_fused_kernel<1, false>"]
+    assert f["vgprs"] <= 128 and f["occupancy"] == 4 and f["scratch"] <= 64 and f["vgpr_spills"] <= 16, f
 
 
 def test_no_built_binary_is_tracked():
