@@ -243,6 +243,11 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value);
  * what the tests and the bench check to know which path they measured.  No reference counterpart. */
 int pcc_fused_steps(pcc_sim_t *sim, uint64_t *out);
 
+/* Diagnostics: the device addresses of the handle's allocations -- state blob, ring tiers 0..3, work lists, shadow rings, history
+ * (0 = not allocated).  Where the rings land in the address space moves the retire launch by ~10 % from one handle to the next
+ * (profiles/r05_placement.json).  No reference counterpart. */
+int pcc_debug_addresses(pcc_sim_t *sim, uint64_t *out8);
+
 /* Sizes of the shared ring pools (see pcc_create): tiers 1, 2, 3 get a slot for one sender in div1, div2, div3 (defaults
  * 2, 8, 32, measured on U(-1, 1) policies; 1 = a slot for every sender -- what a policy that drives every env to its
  * rate limit can need: ~100 GB for 65 536 envs at the default ring_capacity).  Reallocates the pools and synchronizes the

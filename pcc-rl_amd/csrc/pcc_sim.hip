@@ -1119,6 +1119,16 @@ int pcc_step_many(pcc_sim_t *sim, const void *actions, int actions_f64, int n_st
     return PCC_OK;
 }
 
+int pcc_debug_addresses(pcc_sim_t *sim, uint64_t *out8) {
+    if (!sim || !out8) return fail(PCC_EINVAL, "NULL argument");
+    out8[0] = reinterpret_cast<uint64_t>(sim->state_blob);
+    for (int c = 0; c < kMaxTiers; c++) out8[1 + c] = reinterpret_cast<uint64_t>(sim->tier_blob[c]);
+    out8[5] = reinterpret_cast<uint64_t>(sim->list_blob);
+    out8[6] = reinterpret_cast<uint64_t>(sim->shadow_blob);
+    out8[7] = reinterpret_cast<uint64_t>(sim->d.hist);
+    return PCC_OK;
+}
+
 int pcc_fused_steps(pcc_sim_t *sim, uint64_t *out) {
     if (!sim || !out) return fail(PCC_EINVAL, "NULL argument");
     *out = sim->fused_steps;

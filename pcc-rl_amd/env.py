@@ -324,6 +324,12 @@ class BatchedNetworkEnv(object):
         check(self._L.pcc_restart_stats(self._h, out, self._stream()))
         return {"shadow_swaps": int(out[0]), "restart_list": int(out[1])}
 
+    def debug_addresses(self):
+        """Device addresses of the handle's allocations (pcc_debug_addresses): state, ring tiers 0..3, lists, shadow rings, history."""
+        out = (ctypes.c_uint64 * 8)()
+        check(self._L.pcc_debug_addresses(self._h, out))
+        return dict(zip(("state", "tier0", "tier1", "tier2", "tier3", "lists", "shadow_rings", "hist"), [int(v) for v in out]))
+
     def fused_steps(self):
         """Steps of this handle that ran as ONE launch so far (pcc_fused_steps; set_tuning(fused=0) switches that off)."""
         out = ctypes.c_uint64(0)

@@ -32,7 +32,7 @@ FIELDS = {
 SYMBOLS = ["pcc_last_error", "pcc_create", "pcc_destroy", "pcc_set_link_params", "pcc_set_param_ranges",
            "pcc_set_rng", "pcc_set_seed", "pcc_set_tuning", "pcc_set_ring_pools", "pcc_set_cwnd_mode", "pcc_set_latency_noise", "pcc_set_delta_scale", "pcc_set_max_steps", "pcc_reset", "pcc_step", "pcc_step_many", "pcc_step_send",
            "pcc_step_retire",
-           "pcc_get_state", "pcc_restart_stats", "pcc_fused_steps", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline", "pcc_debug_pass_stats",
+           "pcc_get_state", "pcc_restart_stats", "pcc_fused_steps", "pcc_debug_addresses", "pcc_metric_info", "pcc_device_bytes", "pcc_debug_timeline", "pcc_debug_pass_stats",
            "pcc_policy_act", "pcc_ppo_scratch_floats", "pcc_ppo_minibatch_step", "pcc_gae"]
 
 
@@ -93,6 +93,8 @@ def lib():
     L.pcc_restart_stats.argtypes = [vp, vp, vp]
     L.pcc_fused_steps.restype = i32
     L.pcc_fused_steps.argtypes = [vp, vp]
+    L.pcc_debug_addresses.restype = i32
+    L.pcc_debug_addresses.argtypes = [vp, vp]
     L.pcc_metric_info.argtypes = [i32, ctypes.POINTER(dbl), ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     L.pcc_device_bytes.restype = i64
     L.pcc_device_bytes.argtypes = [vp]
