@@ -178,7 +178,7 @@ __device__ __forceinline__ bool fused_retire_unit(const Dev &D, const uint32_t l
     if (prof_on(D) && lane == 0 && D.n >= 1024) {   // profile build: when the unit was claimed / ready / done (tools/fused_timeline.py)
         uint64_t *cnt = D.timeline + (int64_t)19 * D.n;   // (a running counter: the region holds the last few launches' units)
         const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long *>(cnt), 1ull) % (unsigned long long)(D.n / 2);
-        uint64_t *w = cnt + 8 + at * 4;
+        uint64_t *w = cnt + 32 + at * 4;   // (words 16..31 of the region: the XCDs of the two launches' first blocks, pcc_send.hip / pcc_retire.hip)
         w[0] = ((uint64_t)D.step_seq << 32) | (q << 31) | n_unit;
         w[1] = t_claim; w[2] = t_ready; w[3] = wall_clock64();
     }

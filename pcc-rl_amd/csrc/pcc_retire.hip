@@ -33,6 +33,8 @@ __global__ __launch_bounds__(kRetireBlock, NS == 2 ? PCC_RETIRE_OCC2 : PCC_RETIR
         for (int64_t slot = (int64_t)blockIdx.x * kRetireBlock + tid; slot < 2 * D.n; slot += (int64_t)gridDim.x * kRetireBlock)
             D.timeline[slot * 8] = 0;
     }
+    if (prof_on(D) && !warm && blockIdx.x < 8u && tid == 0 && D.n >= 1024)   // profile build: which XCD the first blocks of this launch run on
+        D.timeline[(int64_t)19 * D.n + 24 + blockIdx.x] = ((uint64_t)D.step_seq << 8) | xcc_id();
     const uint32_t lane = tid & (kWave - 1);
     if (tid == 0) s_arrived = 0u;
     if (tid < (uint32_t)kRetireMaxPerBlock) s_env[tid] = 0xFFFFFFFFu;

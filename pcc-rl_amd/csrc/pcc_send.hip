@@ -43,6 +43,8 @@ __global__ __launch_bounds__(4 * kWave, NS == 2 ? PCC_SEND_OCC2 : PCC_SEND_OCC) 
         for (uint32_t w = threadIdx.x; w < kXcds * kFctlWords; w += blockDim.x)   // (a fused step may read this buffer: pcc_fused.hip)
             *fq_word(D, zero_buf, w / kFctlWords, w % kFctlWords) = 0u;
     }
+    if (prof_on(D) && blockIdx.x < 8u && threadIdx.x == 0 && D.n >= 1024)   // profile build: which XCD the first blocks of this launch run on
+        D.timeline[(int64_t)19 * D.n + 16 + blockIdx.x] = ((uint64_t)D.step_seq << 8) | xcc_id();
     __shared__ SendLds<NS> lds;
     const uint32_t b = blockIdx.x;
     if (read_buf < 0) {   // (no lists: light workgroups only, the envs in index order)

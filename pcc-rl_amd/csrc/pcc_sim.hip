@@ -590,7 +590,7 @@ int64_t pcc_debug_timeline(pcc_sim_t *sim, uint64_t *out, int64_t n_words) {
     const int64_t rblocks = (sim->d.n + 7) / 8 + 1;  // (the largest retire grid)
     // ... and the retire units of the fused step (pcc_fused.hip: a running counter at word 19 n, then 4 words per unit --
     // sequence number << 32 | queue << 31 | envs, claimed, ready, done -- the last n / 2 units)
-    const int64_t units = sim->d.n >= 1024 ? 8 + 2 * sim->d.n : 0;
+    const int64_t units = sim->d.n >= 1024 ? 32 + 2 * sim->d.n : 0;
     const int64_t total = (int64_t)items * 8 + rblocks * 16 + units;
     if (!out || n_words <= 0) return total;
     if (n_words < total) return fail(PCC_EINVAL, "pcc_debug_timeline needs room for %lld words", (long long)total);

@@ -37,7 +37,7 @@ for t in range(max(sample) + 1):
     items = raw[:2 * N]
     rblocks = (N + 7) // 8 + 1
     head = raw[2 * N + 2 * rblocks]                          # (the first row of the region: running counter, launch start, sequence number)
-    units = raw[2 * N + 2 * rblocks + 1:].reshape(-1, 4)
+    units = raw[2 * N + 2 * rblocks + 4:].reshape(-1, 4)    # (rows 2, 3 of the region: the XCDs of the two launches' first blocks)
     tag = units[:, 0] >> 32
     cur = units[tag == int(head[2])]
     q = (cur[:, 0] >> 31) & 1
