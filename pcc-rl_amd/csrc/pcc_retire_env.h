@@ -530,23 +530,33 @@ __device__ __noinline__ LeafPair leaf_sum2(const double2 *ring, uint32_t mask, u
 // takes its sum.  8192-sample chunks left to right; inside a chunk DOUBLE_pairwise_sum's
 // recursion (split n -> n/2 rounded down to a multiple of 8 | rest, until <= 128) walked left to
 // right with an explicit stack (depth <= 6).
+// The stack lives in LDS, a row per 8-lane subgroup (the lanes of a subgroup walk the same list: they write the same sizes;
+// the sums are lane 0's -- the leaf code returns them there -- and only that lane writes them).  In registers every access was
+// a chain of selects over the 7 levels (a dynamically indexed array goes to scratch memory): ~300 of the ~650 instructions
+// between two leaves of a long list, and the retire launch is bound by what its wavefronts ISSUE -- its longest workgroups
+// are 16 such leaves one after the other (profiles/r05_latency_ring.json, r05_rtt_prefetch.json).
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+constexpr int kWalkDepth = 7;          // 8192 -> 4096 -> ... -> 128
+constexpr int kWalkRowWords = 24;      // words 0..6: the right parts' sizes; words 8..21: the left parts' sums
+constexpr int kWalkMaxBlock = 4 * kWave;
 struct NpSumWalk {
-    // the stack lives in registers: every access is a select over the (at most 7) levels, a
-    // dynamically indexed array would go to scratch memory
-    static constexpr int kDepth = 7;  // 8192 -> 4096 -> ... -> 128
-    uint32_t right_n[kDepth];
-    double left_sum[kDepth];
+    lds_u32 *right_n;
+    lds_f64 *left_sum;
     uint32_t have_left;
     int sp;
     uint32_t cur, pos, left_in_job;
     double tot;
-    bool done;
+    bool done, writer;
 
+    __device__ __forceinline__ void bind(lds_u32 *row, bool lane0) {
+        right_n = row;
+        left_sum = (lds_f64 *)(row + 8);
+        writer = lane0;
+    }
     __device__ __forceinline__ void start(uint32_t beg, uint32_t n) {
         pos = beg; left_in_job = n; tot = 0.; sp = 0; have_left = 0; done = n == 0;
         cur = n < kNpBufsize ? n : kNpBufsize;
-#pragma unroll
-        for (int k = 0; k < kDepth; k++) { right_n[k] = 0; left_sum[k] = 0.; }
     }
     __device__ __forceinline__ bool single_leaf() const { return sp == 0 && cur == left_in_job && cur <= 128; }
     // the next leaf: [leaf_beg, leaf_beg + leaf_len)
@@ -554,9 +564,7 @@ struct NpSumWalk {
         while (cur > 128) {
             uint32_t n2 = cur / 2;
             n2 -= n2 % 8;
-#pragma unroll
-            for (int k = 0; k < kDepth; k++)
-                if (k == sp) right_n[k] = cur - n2;
+            right_n[sp] = cur - n2;
             have_left &= ~(1u << sp);
             sp++;
             cur = n2;
@@ -570,17 +578,12 @@ struct NpSumWalk {
         while (sp > 0) {
             const int top = sp - 1;
             if (!(have_left & (1u << top))) {
-#pragma unroll
-                for (int k = 0; k < kDepth; k++)
-                    if (k == top) { left_sum[k] = val; cur = right_n[k]; }
+                if (writer) left_sum[top] = val;
+                cur = right_n[top];
                 have_left |= 1u << top;
                 return;  // descend into the right part
             }
-            double l = 0.;
-#pragma unroll
-            for (int k = 0; k < kDepth; k++)
-                if (k == top) l = left_sum[k];
-            val = l + val;
+            val = left_sum[top] + val;
             sp--;
         }
         tot += val;  // one chunk finished (0.0 + x == x for the first)
@@ -619,7 +622,9 @@ __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, u
     constexpr int kPairJob = G == 16 ? 0 : 1;
     const uint32_t pair_beg = kPairJob == 0 ? jb1 : jb2, pair_n = kPairJob == 0 ? jn1 : jn2;
     double res0 = 0.0, res1 = 0.0, res2 = 0.0;
+    __shared__ uint32_t s_walk[kWalkMaxBlock / 8 * kWalkRowWords];
     NpSumWalk w;
+    w.bind((lds_u32 *)s_walk + (threadIdx.x >> 3) * kWalkRowWords, sl == 0);
     int job = 0;
     // the first job at or after `j` that has samples (kJobs: none); starts the walk over it
     auto start_from = [&](int j) {
