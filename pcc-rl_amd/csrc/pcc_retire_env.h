@@ -711,7 +711,7 @@ __device__ __forceinline__ double select_metric(const double (&m)[PCC_N_METRICS]
 // USE_LATENCY_NOISE (ns:51-52, 150-151, 171-172): every link latency is multiplied by
 // random.uniform(1.0, MAX_LATENCY_NOISE), one more draw of the stream per hop.  Packets overtake each
 // other on both hops, so the two monotone rings cannot hold the in-flight set: with this option an
-// env keeps the reference's own structure, a binary heap of its events, in global memory, and ONE
+// env keeps the reference's own structure, a heap of its events, in global memory, and ONE
 // lane runs the reference's event loop (ns:127-178) over it -- exactness, not speed, is the point of
 // a dormant option.  Only acknowledgement events live in the heap (hop 1: arrives at the return link,
 // hop 2: arrives at the sender); the sender's one pending SEND is next_send as everywhere else.  The
@@ -728,34 +728,46 @@ __device__ __forceinline__ bool heap_less(const double2 a, const double2 b) {
     if (la != lb) return la < lb;
     return !sign_of(a.y) && sign_of(b.y);  // dropped: False < True
 }
+// The heap is 8-ary: node p's children are nodes 8p + 1 .. 8p + 8, and node p lives in slot p + 7 of the sender's array, so
+// the eight children of a node are one aligned 128-byte line -- a level of the sift-down is one trip to memory for the lane,
+// and 4 096 events in flight are 4 levels, not 12 (the lane's trips, one after the other, are what an interval of this
+// build lasts).  kHeapPad more slots per array than events.
+constexpr uint32_t kHeapPad = 8;
+__device__ __forceinline__ double2 *heap_node(double2 *H, uint32_t p) { return H + 7u + p; }
 __device__ __forceinline__ void heap_push(double2 *H, uint32_t &n, const double2 v) {
     uint32_t pos = n++;
     while (pos > 0) {
-        const uint32_t parent = (pos - 1u) >> 1;
-        const double2 pv = ld_rec(H + parent);
+        const uint32_t parent = (pos - 1u) >> 3;
+        const double2 pv = ld_rec(heap_node(H, parent));
         if (!heap_less(v, pv)) break;
-        st_rec(H + pos, pv);
+        st_rec(heap_node(H, pos), pv);
         pos = parent;
     }
-    st_rec(H + pos, v);
+    st_rec(heap_node(H, pos), v);
 }
 __device__ __forceinline__ double2 heap_pop(double2 *H, uint32_t &n) {
-    const double2 top = ld_rec(H);
-    const double2 last = ld_rec(H + (--n));
+    const double2 top = ld_rec(heap_node(H, 0));
+    const double2 last = ld_rec(heap_node(H, --n));
     uint32_t pos = 0;
     for (;;) {
-        uint32_t c = 2u * pos + 1u;
-        if (c >= n) break;
-        double2 cv = ld_rec(H + c);
-        if (c + 1u < n) {
-            const double2 rv = ld_rec(H + c + 1u);
-            if (heap_less(rv, cv)) { cv = rv; c++; }
+        const uint32_t c0 = 8u * pos + 1u;
+        if (c0 >= n) break;
+        double2 cv[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) {   // (one line: the loads leave together)
+            cv[j].x = INFINITY; cv[j].y = INFINITY;
+            if (c0 + j < n) cv[j] = ld_rec(heap_node(H, c0 + j));
         }
-        if (!heap_less(cv, last)) break;
-        st_rec(H + pos, cv);
+        double2 best = cv[0];
+        uint32_t c = c0;
+#pragma unroll
+        for (uint32_t j = 1; j < 8u; j++)
+            if (c0 + j < n && heap_less(cv[j], best)) { best = cv[j]; c = c0 + j; }
+        if (!heap_less(best, last)) break;
+        st_rec(heap_node(H, pos), best);
         pos = c;
     }
-    if (n) st_rec(H + pos, last);
+    if (n) st_rec(heap_node(H, pos), last);
     return top;
 }
 
@@ -788,7 +800,7 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;   // (the event heaps are [S][N]; the sender blocks [S][2N]: sidx)
         hn[s] = D.snd[sidx(D, s, i)].heap_n;
-        H[s] = D.noise_heap + (size_t)k * D.noise_cap;
+        H[s] = D.noise_heap + (size_t)k * (D.noise_cap + kHeapPad);
         R[s] = D.noise_rtt + (size_t)k * D.noise_cap;
         nsend[s] = nsend0[s];
         o.sent[s] = o.acked[s] = o.lost[s] = 0;
@@ -814,7 +826,7 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             if (hn[s] > 0) {
-                const double t = fabs(ld_rec(H[s]).x);
+                const double t = fabs(ld_rec(heap_node(H[s], 0)).x);
                 if (t < bt) { bt = t; bs = s; from_heap = true; }
             }
             if (nsend[s] < bt) { bt = nsend[s]; bs = s; from_heap = false; }

@@ -877,18 +877,20 @@ int pcc_set_ring_pools(pcc_sim_t *sim, uint32_t div1, uint32_t div2, uint32_t di
 
 // The event-loop build (event_engine) runs the interval when packets can overtake each other (latency noise) and when
 // windows couple two senders' SEND streams to their notifications; it needs a heap and an RTT list per sender.
+constexpr size_t kHeapSlack = 8;   // pcc_retire_env.h: kHeapPad (the heaps' nodes sit 7 slots into their arrays: a node's children are one line)
 int update_engine(pcc_sim_t *sim) {
     const int engine = (sim->d.use_noise || (sim->d.use_cwnd && sim->d.ns > 1)) ? 1 : 0;
     if (engine && !sim->noise_blob) {
         DeviceGuard guard(sim->device);
-        const size_t per = (size_t)sim->d.n * sim->d.ns * sim->ring_capacity * sizeof(double2);
+        const size_t senders = (size_t)sim->d.n * sim->d.ns;
+        const size_t heaps = senders * (sim->ring_capacity + kHeapSlack) * sizeof(double2), lists = senders * sim->ring_capacity * sizeof(double2);
         void *p = nullptr;
-        if (hipMalloc(&p, 2 * per) != hipSuccess)
-            return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the event heaps failed", 2 * per);
+        if (hipMalloc(&p, heaps + lists) != hipSuccess)
+            return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the event heaps failed", heaps + lists);
         sim->noise_blob = p;
-        sim->noise_bytes = 2 * per;
+        sim->noise_bytes = heaps + lists;
         sim->d.noise_heap = static_cast<double2 *>(p);
-        sim->d.noise_rtt = sim->d.noise_heap + (size_t)sim->d.n * sim->d.ns * sim->ring_capacity;
+        sim->d.noise_rtt = sim->d.noise_heap + senders * (sim->ring_capacity + kHeapSlack);
         sim->d.noise_cap = sim->ring_capacity;
     }
     sim->d.engine = engine;
