@@ -806,17 +806,30 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
         o.sent[s] = o.acked[s] = o.lost[s] = 0;
     }
     double now = start;
+    // What the loop reads of D, once: D is a reference here (this function is not inlined), and after every store to a heap
+    // the compiler has to load a field of it again -- a dozen trips to memory per event, one after the other, in a loop
+    // that is nothing but one lane's trips.
+    const bool from_trace = D.rng_mode == PCC_RNG_TRACE, use_noise = D.use_noise != 0;
+    const double noise_span = D.noise_span;
+    const double *const trace_row = from_trace ? D.trace + i * D.trace_stride : nullptr;
+    const int64_t trace_stride = D.trace_stride;
+    const uint32_t key0 = D.key0, key1 = D.key1, gid = D.gid_base + (uint32_t)env_of(D, i), noise_cap = D.noise_cap;
+    // (draws j, j+1, j+2, j+3 of an interval are the four words of one Philox block: computed once)
+    uint32_t blk_of = 0xFFFFFFFFu, blk_w[4] = {0u, 0u, 0u, 0u};
     auto draw = [&]() -> double {
-        if (D.rng_mode == PCC_RNG_TRACE) {
+        if (from_trace) {
             const uint32_t pos = ep_draws++;
-            if ((int64_t)pos >= D.trace_stride) { o.flags |= PCC_FLAG_TRACE_OVERRUN; return 1.0; }
-            return D.trace[i * D.trace_stride + pos];
+            if ((int64_t)pos >= trace_stride) { o.flags |= PCC_FLAG_TRACE_OVERRUN; return 1.0; }
+            return trace_row[pos];
         }
         ep_draws++;
-        return philox_packet_uniform(D, D.gid_base + (uint32_t)env_of(D, i), episode, mi, mi_draws++);
+        const uint32_t j = mi_draws++;
+        if ((j >> 2) != blk_of) { blk_of = j >> 2; philox4x32_10(blk_of, mi, episode, gid, key0, key1, blk_w); }
+        const uint32_t x = j & 3u;
+        return u32_to_unit(x == 0 ? blk_w[0] : x == 1 ? blk_w[1] : x == 2 ? blk_w[2] : blk_w[3]);   // = philox_packet_uniform
     };
     auto noisy = [&](double ll) -> double {  // ns:150-151, 171-172
-        if (D.use_noise) ll *= 1.0 + D.noise_span * draw();
+        if (use_noise) ll *= 1.0 + noise_span * draw();
         return ll;
     };
     while (now < end) {  // ns:128
@@ -841,7 +854,7 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
                 if (sign_of(ev.x)) {  // hop 2 == len(path): the sender hears of it (ns:139-146)
                     if (sign_of(ev.y)) o.lost[s]++;
                     else {
-                        if (o.acked[s] < D.noise_cap) { double2 r; r.x = 0.0; r.y = lat; st_rec(R[s] + o.acked[s], r); }
+                        if (o.acked[s] < noise_cap) { double2 r; r.x = 0.0; r.y = lat; st_rec(R[s] + o.acked[s], r); }
                         else o.flags |= PCC_FLAG_RING_OVERFLOW;
                         o.acked[s]++;
                     }
@@ -850,7 +863,7 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
                     double2 nv;
                     nv.x = -(now + ll);
                     nv.y = sign_of(ev.y) ? -(lat + ll) : lat + ll;
-                    if (hn[s] < D.noise_cap) heap_push(H[s], hn[s], nv);
+                    if (hn[s] < noise_cap) heap_push(H[s], hn[s], nv);
                     else o.flags |= PCC_FLAG_RING_OVERFLOW;
                 }
             } else {  // SEND (ns:155-175)
@@ -875,7 +888,7 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
                 nv.x = now + ll;
                 nv.y = dropped ? -lat : lat;
                 if (can_send) {
-                    if (hn[s] < D.noise_cap) heap_push(H[s], hn[s], nv);
+                    if (hn[s] < noise_cap) heap_push(H[s], hn[s], nv);
                     else o.flags |= PCC_FLAG_RING_OVERFLOW;
                 }
             }
