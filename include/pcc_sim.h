@@ -234,6 +234,10 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     16) takes them anyway once it has waited this many naps; default 2 */,
        PCC_TUNE_FUSED_LIGHT_FRONT = 32 /* fused step: so many of the light-first workgroups per partition are dispatched in FRONT of the
                                     wave-path workgroups (a compute unit's memory pipeline serves its oldest wavefronts first); default 0 */,
+       PCC_TUNE_NOISE_SORTED = 33 /* USE_LATENCY_NOISE alone on one sender: 1 (default) = an interval is run by a wavefront per env as counts, two
+                                    sorts and a scan (pcc-rl_amd/csrc/pcc_noise_sorted.hip) and the event loop takes only the envs whose events in
+                                    flight do not fit its arrays; 2 = only its 256-event instance (the event loop takes the rest: what the
+                                    tests use to cross the two); 0 = the event loop for every env.  Results do not depend on it. */,
        PCC_TUNE_FUSED_DEBUG = 31 /* fused step, experiments: bit 0 (1) = an agent-scope release (buffer_wbl2) in front of every publication,
                                     bit 2 (4) = no retire work before every env is sent (the halves one after the other inside the launch);
                                     default 0 */ };

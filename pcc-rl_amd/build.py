@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 # one translation unit per kernel family (each kernel is register-allocated on its own) + the C ABI + the PPO caller's kernels
-UNITS = ["pcc_sim.hip", "pcc_send.hip", "pcc_send_restart.hip", "pcc_retire.hip", "pcc_small.hip", "pcc_fused.hip",
+UNITS = ["pcc_sim.hip", "pcc_send.hip", "pcc_send_restart.hip", "pcc_retire.hip", "pcc_small.hip", "pcc_fused.hip", "pcc_noise_sorted.hip",
          "pcc_policy.hip", "pcc_ppo.hip"]
 SRCS = [os.path.join(CSRC, u) for u in UNITS]
 HEADERS = [os.path.join(CSRC, h) for h in ("pcc_dev.h", "pcc_kernels.h", "pcc_wave_pass.h", "pcc_send_item.h", "pcc_send_bodies.h", "pcc_retire_env.h")]

@@ -131,6 +131,14 @@ struct alignas(128) SndBlk {
 static_assert(sizeof(EnvBlk) == 128 && sizeof(SndBlk) == 128, "one line per block");
 
 // Everything a kernel needs, passed by value.
+// What pcc_noise_sorted.hip leaves for the retire launch of the same interval: event_engine's result.
+struct NoiseOut {
+    double now, q, tu, nsend;
+    uint32_t sent, acked, lost, flags;
+    uint32_t seq, pad[3];
+};
+static_assert(sizeof(NoiseOut) == 64, "one 64-byte record per env");
+
 struct Dev {
     int64_t n;
     int ns, H, F, HF;
@@ -221,6 +229,8 @@ struct Dev {
     uint32_t noise_cap;    // events / RTT samples per sender (a power of two)
     double2 *noise_heap;   // [S][N][noise_cap] (+-t, +-latency): sign of t = hop 2, sign of latency = dropped
     double2 *noise_rtt;    // [S][N][noise_cap] (-, rtt) of the packets acknowledged in the current MI, in ack order
+    NoiseOut *noise_out;  // [N]: an interval run ahead of the retire launch by pcc_noise_sorted.hip (nullptr: never)
+    uint32_t noise_seq;    // ... counts the intervals launched: NoiseOut::seq == noise_seq says "this one has been run"
     float *hist;    // [N][S][HF]
     double2 *ring;  // [N][S][2][cap]: accepted ring, dropped ring
 };

@@ -20,6 +20,8 @@ void launch_retire(const Dev &d, bool noise, unsigned grid, hipStream_t st, int 
                    const void *actions, int actions_f64);
 // pcc_fused.hip: both halves of a full-size step in one launch (an env's retire half follows its own send half); grid =
 // wave_wgs workgroups that start with the wave-path work + the rest, both multiples of Dev::parts
+void launch_noise_sorted(const Dev &d, hipStream_t st, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64,
+                         int only_small);
 void launch_step_fused(const Dev &d, bool trace, unsigned grid, unsigned wave_wgs, unsigned light_front, hipStream_t st, int read_buf, int fill_buf, int zero_buf,
                        int retire_on, const void *actions, int actions_f64, float *obs_out, float *reward_out, uint8_t *done_out, double *steps_out);
 void launch_clear_list_buffer(const Dev &d, hipStream_t st, int buf);

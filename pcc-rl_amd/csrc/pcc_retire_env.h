@@ -771,6 +771,34 @@ __device__ __forceinline__ double2 heap_pop(double2 *H, uint32_t &n) {
     return top;
 }
 
+// pcc_noise_sorted.hip writes the events in flight back in no particular order and says so in bit 31 of SndBlk::heap_n:
+// Floyd's bottom-up construction makes a heap of them (once; the event loop clears the bit).
+__device__ __forceinline__ void heap_sift_down(double2 *H, uint32_t n, uint32_t pos, const double2 v) {
+    for (;;) {
+        const uint32_t c0 = 8u * pos + 1u;
+        if (c0 >= n) break;
+        double2 best = ld_rec(heap_node(H, c0));
+        uint32_t c = c0;
+        for (uint32_t j = 1; j < 8u && c0 + j < n; j++) {
+            const double2 cv = ld_rec(heap_node(H, c0 + j));
+            if (heap_less(cv, best)) { best = cv; c = c0 + j; }
+        }
+        if (!heap_less(best, v)) break;
+        st_rec(heap_node(H, pos), best);
+        pos = c;
+    }
+    st_rec(heap_node(H, pos), v);
+}
+__device__ __forceinline__ uint32_t heapify_if_loose(double2 *H, uint32_t raw_n) {
+    const uint32_t n = raw_n & 0x7FFFFFFFu;
+    if ((raw_n >> 31) && n > 1u)
+        for (uint32_t p = (n - 2u) >> 3;; p--) {
+            heap_sift_down(H, n, p, ld_rec(heap_node(H, p)));
+            if (p == 0u) break;
+        }
+    return n;
+}
+
 template <int NS>
 struct EngineOut {
     double now, q, tu;
@@ -799,8 +827,8 @@ __device__ __noinline__ EngineOut<NS> event_engine(const Dev &D, int64_t i, doub
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = (int64_t)s * D.n + i;   // (the event heaps are [S][N]; the sender blocks [S][2N]: sidx)
-        hn[s] = D.snd[sidx(D, s, i)].heap_n;
         H[s] = D.noise_heap + (size_t)k * (D.noise_cap + kHeapPad);
+        hn[s] = heapify_if_loose(H[s], D.snd[sidx(D, s, i)].heap_n);
         R[s] = D.noise_rtt + (size_t)k * D.noise_cap;
         nsend[s] = nsend0[s];
         o.sent[s] = o.acked[s] = o.lost[s] = 0;
@@ -1081,7 +1109,14 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
 #pragma unroll
         for (int s = 0; s < NS; s++) { o.nsend[s] = nsend[s]; o.sent[s] = o.acked[s] = o.lost[s] = 0; }
         if (lead) {
-            o = event_engine<NS>(D, i, start, end, rate, nsend, warm ? warm_mi : steps + 2, cw);
+            bool ran = false;
+            if (NS == 1 && D.noise_out != nullptr && D.noise_out[i].seq == D.noise_seq) {   // pcc_noise_sorted.hip has run this interval
+                const NoiseOut r = D.noise_out[i];
+                o.now = r.now; o.q = r.q; o.tu = r.tu; o.nsend[0] = r.nsend;
+                o.sent[0] = r.sent; o.acked[0] = r.acked; o.lost[0] = r.lost; o.flags = r.flags;
+                ran = true;
+            }
+            if (!ran) o = event_engine<NS>(D, i, start, end, rate, nsend, warm ? warm_mi : steps + 2, cw);
 #pragma unroll
             for (int s = 0; s < NS; s++) D.snd[sidx(D, s, i)].rate = rate[s];
             D.env[i].q = o.q; D.env[i].tu = o.tu;

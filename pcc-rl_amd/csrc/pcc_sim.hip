@@ -52,6 +52,8 @@ struct pcc_sim {
     void *list_blob;    // the class lists (Dev::cls_list)
     size_t list_bytes;
     void *noise_blob;   // heap + RTT samples of the latency-noise option (allocated when it is switched on)
+    void *noise_out_blob;  // ... and the per-env results of the heap-free interval (pcc_noise_sorted.hip)
+    int noise_sorted;   // PCC_TUNE_NOISE_SORTED: 1 = latency noise alone on one sender runs its intervals by sorting, 2 = only the small instance, 0 = the event loop
     size_t noise_bytes;
     uint32_t ring_capacity;
     bool pools_pending;     // the pools of tiers >= 1 are not allocated yet (they are sized at the first reset, or by pcc_set_ring_pools)
@@ -302,7 +304,14 @@ int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gat
     if (sim->d.engine) {
         // the event-loop build (latency noise; the congestion window with two senders): the whole interval is one launch of
         // the retire kernel's NOISE build (no send half, no work lists)
-        const Dev &d = sim->d;
+        // Latency noise alone on one sender: the interval itself is run ahead of that launch, a wavefront per env, without
+        // the event loop (pcc_noise_sorted.hip); the retire launch picks the results up env by env (NoiseOut::seq) and
+        // runs the event loop for the envs that were left alone.
+        sim->d.noise_seq++;
+        Dev d = sim->d;
+        const bool sorted = sim->noise_sorted && d.use_noise && !d.use_cwnd && d.ns == 1 && d.noise_out != nullptr;
+        if (!sorted) d.noise_out = nullptr;
+        else launch_noise_sorted(d, st, warm, warm_mi, gate, actions, actions_f64, sim->noise_sorted == 2);
         const unsigned grid = (unsigned)((d.n + kRetireEnvsPerBlockNarrow - 1) / kRetireEnvsPerBlockNarrow);
         launch_retire(d, true, grid, st, -1, -1, warm, warm_mi, last_warm, gate, 0, obs_out, reward_out, done_out, steps_out,
                       actions, actions_f64);
@@ -553,6 +562,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     sim->read_buf = -1;
     sim->fill_buf = 0;
     sim->clean_buf = -1;
+    sim->noise_sorted = 1;
     sim->fused = 0;   // (measured slower than the two launches at full size: profiles/r05_fused_experiments.json)
     sim->fused_light_wgs = 32;   // light-first workgroups per partition (4 wavefronts each: a partition of 8 192 envs has ~105 light items)
     d.fused_acquire = 0u;
@@ -631,6 +641,7 @@ void pcc_destroy(pcc_sim_t *sim) {
     if (sim->timeline_blob) (void)hipFree(sim->timeline_blob);
     if (sim->list_blob) (void)hipFree(sim->list_blob);
     if (sim->noise_blob) (void)hipFree(sim->noise_blob);
+    if (sim->noise_out_blob) (void)hipFree(sim->noise_out_blob);
 
     if (sim->state_blob) (void)hipFree(sim->state_blob);
     for (int c = 0; c < kMaxTiers; c++) {
@@ -777,6 +788,10 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             if (!(value >= 0.0)) return fail(PCC_EINVAL, "retire_wide_predict out of range");
             sim->d.retire_wide_predict = value >= 1e9 ? 1e9f : (float)value;
             return PCC_OK;
+        case PCC_TUNE_NOISE_SORTED:
+            if (value != 0.0 && value != 1.0 && value != 2.0) return fail(PCC_EINVAL, "noise_sorted must be 0, 1 or 2");
+            sim->noise_sorted = (int)value;
+            return PCC_OK;
         case PCC_TUNE_HEAVY_ITEM_PACKETS:
             if (!(value >= 0.0 && value <= 1e9)) return fail(PCC_EINVAL, "heavy_item_packets out of range");
             sim->d.heavy_item_packets = (float)value;
@@ -891,6 +906,13 @@ int update_engine(pcc_sim_t *sim) {
         sim->noise_bytes = heaps + lists;
         sim->d.noise_heap = static_cast<double2 *>(p);
         sim->d.noise_rtt = sim->d.noise_heap + senders * (sim->ring_capacity + kHeapSlack);
+        void *po = nullptr;
+        if (hipMalloc(&po, (size_t)sim->d.n * sizeof(NoiseOut)) != hipSuccess || hipMemset(po, 0, (size_t)sim->d.n * sizeof(NoiseOut)) != hipSuccess)
+            return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the intervals' results failed", (size_t)sim->d.n * sizeof(NoiseOut));
+        sim->noise_out_blob = po;
+        sim->noise_bytes += (size_t)sim->d.n * sizeof(NoiseOut);
+        sim->d.noise_out = static_cast<NoiseOut *>(po);
+        sim->d.noise_seq = 0;
         sim->d.noise_cap = sim->ring_capacity;
     }
     sim->d.engine = engine;

@@ -59,6 +59,7 @@ class BatchedNetworkEnv(object):
     # PCC_TEST_FUSED / PCC_TEST_FUSED_ACQUIRE so that the parity suite can run through either path)
     DEFAULT_FUSED = None
     DEFAULT_FUSED_ACQUIRE = None
+    DEFAULT_NOISE_SORTED = None   # tests: PCC_TUNE_NOISE_SORTED for every handle (0 = the event loop, 2 = the two crossed)
 
     def __init__(self, n_envs, device="cuda", history_len=None, features=None, seed=0, n_senders=1,
                  link_params=None, env_gid_base=0, ring_capacity=0, auto_reset=True, delta_scale=None,
@@ -103,6 +104,8 @@ class BatchedNetworkEnv(object):
             check(L.pcc_set_tuning(self._h, 26, float(self.DEFAULT_FUSED)))
         if self.DEFAULT_FUSED_ACQUIRE is not None:
             check(L.pcc_set_tuning(self._h, 27, float(self.DEFAULT_FUSED_ACQUIRE)))
+        if self.DEFAULT_NOISE_SORTED is not None:
+            check(L.pcc_set_tuning(self._h, 33, float(self.DEFAULT_NOISE_SORTED)))
         check(L.pcc_set_delta_scale(self._h, float(DELTA_SCALE if delta_scale is None else delta_scale)))
         check(L.pcc_set_max_steps(self._h, self.max_steps))
         # the reference's dormant USE_CWND engine option (ns:54): window-limited sending, actions
@@ -191,14 +194,16 @@ class BatchedNetworkEnv(object):
                    send_waves=None, team_predict=None, heavy_item_packets=None, retire_wide_predict=None, list_min_envs=None,
                    retire_sorted=None, light_snake=None, wave_oldest_first=None, prio_level=None, prio_light_items=None,
                    prio_wave_items=None, prio_team=None, retire_grid_frac=None, restart_fork=None, parts=None, light_half_predict=None,
-                   fused=None, fused_acquire=None, fused_light_wgs=None, fused_max_naps=None, fused_partial_naps=None, fused_debug=None, fused_light_front=None):
+                   fused=None, fused_acquire=None, fused_light_wgs=None, fused_max_naps=None, fused_partial_naps=None, fused_debug=None, fused_light_front=None,
+                   noise_sorted=None):
         """Performance knobs (results do not depend on them); see pcc_set_tuning in include/pcc_sim.h.  `parts` (the
         partitioning of the batch) must be followed by reset()."""
         for key, value in ((2, round_packets), (3, takeover_lanes), (4, send_envs_per_wave), (5, heavy_predict),
                            (8, send_waves), (9, team_predict), (10, heavy_item_packets), (11, retire_wide_predict), (12, list_min_envs),
                            (13, retire_sorted), (14, light_snake), (15, wave_oldest_first), (16, prio_level), (17, prio_light_items),
                            (18, prio_wave_items), (19, prio_team), (22, retire_grid_frac), (23, restart_fork), (24, parts), (25, light_half_predict),
-                           (26, fused), (27, fused_acquire), (28, fused_light_wgs), (29, fused_max_naps), (30, fused_partial_naps), (31, fused_debug), (32, fused_light_front)):
+                           (26, fused), (27, fused_acquire), (28, fused_light_wgs), (29, fused_max_naps), (30, fused_partial_naps), (31, fused_debug), (32, fused_light_front),
+                           (33, noise_sorted)):
             if value is not None:
                 check(self._L.pcc_set_tuning(self._h, key, float(value)))
 

@@ -48,5 +48,8 @@ def work_lists_for_small_batches():
         pcc_rl_amd.BatchedNetworkEnv.DEFAULT_FUSED = int(os.environ["PCC_TEST_FUSED"])
     if os.environ.get("PCC_TEST_FUSED_ACQUIRE") is not None:
         pcc_rl_amd.BatchedNetworkEnv.DEFAULT_FUSED_ACQUIRE = int(os.environ["PCC_TEST_FUSED_ACQUIRE"])
+    # latency noise: intervals by sorting (default), by the event loop (0), or the two crossed (2: the small instance + the event loop)
+    if os.environ.get("PCC_TEST_NOISE_SORTED") is not None:
+        pcc_rl_amd.BatchedNetworkEnv.DEFAULT_NOISE_SORTED = int(os.environ["PCC_TEST_NOISE_SORTED"])
     yield
     pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = old

@@ -69,3 +69,17 @@ def test_one_launch_step_reproduces_every_number():
         tail = r.stdout[-3000:]
         assert r.returncode == 0, "one-launch step, %s:\n%s" % (what, tail)
         assert " passed" in tail and "no tests ran" not in tail, tail
+
+
+def test_latency_noise_by_sorting_by_the_event_loop_and_crossed():
+    """USE_LATENCY_NOISE on one sender runs its intervals without the event loop by default (pcc_noise_sorted.hip); the same
+    parity tests with the event loop for every env (0) and with the two crossed from env to env and from interval to interval
+    (2: only the small instance -- the event loop takes the envs it leaves, out of an array in no particular order)."""
+    for mode in ("0", "2"):
+        envv = dict(os.environ, PCC_TEST_NOISE_SORTED=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", "noise", "-m", "gpu", "-x",
+                            "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=envv, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           universal_newlines=True, timeout=600)
+        tail = r.stdout[-3000:]
+        assert r.returncode == 0, "PCC_TEST_NOISE_SORTED=%s:\n%s" % (mode, tail)
+        assert " passed" in tail and "no tests ran" not in tail, tail
