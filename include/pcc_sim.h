@@ -276,11 +276,12 @@ int pcc_set_cwnd_mode(pcc_sim_t *sim, int enable);
  * 1.1 in the reference): every link latency -- forward hop at the SEND (ns:171-172), return hop at the
  * first ACK event (ns:150-151) -- is multiplied by random.uniform(1.0, max_noise), one more draw of the
  * env's stream per hop (at a SEND it precedes the loss draw).  Packets overtake each other, so with the
- * option on an env keeps the reference's own structure -- a binary heap of each sender's events, ring_capacity
+ * option on an env keeps the reference's own structure -- a heap of each sender's events, ring_capacity
  * events per sender, allocated by this call (2 x 16 bytes x ring_capacity per sender) -- and one lane runs the
- * reference's event loop over it ("event-loop build"); the whole interval is one kernel launch (pcc_step; there is no
- * pcc_step_send / pcc_step_retire split).  Exact like the other paths (golden sets noise_*, two_sender_noise), and slow:
- * it exists for parity with the reference's flag, not for throughput.  Uniforms: PCC_RNG_TRACE replays
+ * reference's event loop over it ("event-loop build"); there is no pcc_step_send / pcc_step_retire split.  With ONE sender and
+ * no window the interval itself runs ahead of that launch without the event loop (PCC_TUNE_NOISE_SORTED,
+ * pcc-rl_amd/csrc/pcc_noise_sorted.hip: counts, two sorts and a scan by a workgroup per env; ~10x the event loop's speed).
+ * Exact like the other paths either way (golden sets noise_*, two_sender_noise).  Uniforms: PCC_RNG_TRACE replays
  * the trace in draw order (three draws per packet); PCC_RNG_PHILOX numbers ALL draws of an interval
  * 0, 1, 2, ... in event order (word index of the interval's Philox stream).  One or two senders per env (events of
  * equal time: lower sender id first, ns:42-43).  Together with pcc_set_cwnd_mode (the reference's two flags are module
