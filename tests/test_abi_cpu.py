@@ -134,6 +134,12 @@ def test_hot_kernels_do_not_spill():
     # (one or two dozen registers around its retire loop, none in a hot loop: pcc-rl_amd/csrc/pcc_fused.hip) stays small
     f = res["step_fused_kernel<1, false>"]
     assert f["vgprs"] <= 128 and f["occupancy"] == 4 and f["scratch"] <= 96 and f["vgpr_spills"] <= 32, f
+    # latency noise without the event loop: nothing in scratch; the arrays of the first instance leave room for a dozen workgroups
+    # per compute unit, those of the second for three (160 KB of LDS per compute unit)
+    small, large = res["noise_sorted_kernel<256, 128, 128, false, 64>"], res["noise_sorted_kernel<1024, 512, 256, true, 256>"]
+    for r in (small, large):
+        assert r["scratch"] == 0 and r["vgpr_spills"] == 0, r
+    assert small["lds"] <= 13 * 1024 and large["lds"] <= 48 * 1024, (small, large)
 
 
 def test_no_built_binary_is_tracked():
