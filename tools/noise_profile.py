@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """USE_LATENCY_NOISE at 16 384 envs, a few steps: run under `rocprofv3 --kernel-trace --stats` to see which kernel the time is in
-(the three instances of noise_sorted_kernel, retire_kernel<1, true>); prints how many envs each path ran.  (GPU box.)"""
+(the two instances of noise_sorted_kernel, retire_kernel<1, true>).  (GPU box.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pcc_rl_amd
