@@ -120,7 +120,8 @@ struct alignas(128) SndBlk {
     uint32_t mi_sent;            // 80
     uint32_t ring_held[kMaxTiers];  // pool slot + 1 the sender holds in tier c (0 = none) until reset
     uint32_t cwnd;     // the reference's dormant USE_CWND option (ns:54): the sender's window in packets (ns:227: 25 at reset)
-    uint32_t heap_n;   // event-loop build (event_engine): the sender's events in its heap = its packets in flight
+    uint32_t heap_n;   // event-loop build (event_engine): the sender's events in its heap = its packets in flight; bit 31: the array is
+                       // in no particular order (pcc_noise_sorted.hip wrote it; the event loop makes a heap of it first)
     uint32_t pad1;
     // 112  retire half: where the last interval's four ring boundaries fell, as predictions of the next ones (speed only:
     // search_many verifies them) -- acknowledgements and loss reports per second of simulated time, and the packets that were
