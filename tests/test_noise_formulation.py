@@ -37,3 +37,40 @@ def test_rates_pushed_up_and_down_match_and_the_blocks_are_wide():
 
 def test_lossy_shallow_queue_matches():
     run_pair(3, 100, fixed=(150.0, 0.08, 2, 0.04, 200.0))
+
+
+# ---- one or two senders on the link (tests/proto_noise_sorting2.py)
+from tests.proto_noise_sorting2 import SortedNoiseEnvS
+
+
+def run_pair_s(seed, n_steps, n_senders, scale=1.0, fixed=None):
+    a = PyOracleEnv(seed=seed, latency_noise=1.1, fixed=fixed, n_senders=n_senders)
+    b = SortedNoiseEnvS(seed=seed, latency_noise=1.1, fixed=fixed, n_senders=n_senders)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    acts = np.random.RandomState(seed).uniform(-1, 1, (n_steps, n_senders)) * scale
+    for t in range(n_steps):
+        act = acts[t] if n_senders > 1 else acts[t, 0]
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert (a.sent, a.acked, a.lost) == (b.sent, b.acked, b.lost), (seed, t)
+        assert a.now == b.now and a.q == b.q and a.tq == b.tq, (seed, t)
+        assert a.rtts == b.rtts, (seed, t)
+        assert np.array_equal(oa, ob) and ra == rb and da == db, (seed, t)
+        assert a.draws == b.draws, (seed, t)
+    return b
+
+
+@pytest.mark.parametrize("seed", [0, 1, 4])
+def test_two_senders_match_the_event_loop(seed):
+    run_pair_s(seed, 100, 2)
+
+
+def test_two_senders_large_actions_and_a_fast_pair_on_a_long_link():
+    run_pair_s(9, 120, 2, scale=8.0)
+    b = run_pair_s(6, 80, 2, fixed=(450.0, 0.3, 3000, 0.01, 700.0, 300.0))
+    assert max(b.block_sizes) >= 100
+
+
+def test_the_general_restatement_with_one_sender():
+    run_pair_s(2, 100, 1)
