@@ -60,6 +60,19 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def code_stamp():
+    """Which code this run measures: the commit the library was built from ("+" = csrc/ or include/ differed from it) and the hash
+    of its sources (pcc-rl_amd/build.py leaves the stamp next to the library: the GPU box has the .so but no .git)."""
+    try:
+        from pcc_rl_amd import build as pbuild
+        bi = pbuild.build_info(os.environ.get("PCC_SIM_LIBRARY"))
+    except Exception:
+        bi = {}
+    if not bi:
+        return "unknown"
+    return "%s%s sources %s" % (bi.get("commit") or "no-git", "+" if bi.get("dirty") else "", bi.get("sources_sha16"))
+
+
 def pmc_traffic():
     """HBM bytes per launch from the newest committed PMC summary (profiles/*_pmc_hbm.json): the fallback when the
     counter passes of this run (pmc_passes) are switched off or fail; labelled with its source and window."""
@@ -90,13 +103,14 @@ def pmc_passes(config, timeout_s=150):
         return None, "tools/pmc_aggregate.py: %s" % e
     tmp = tempfile.mkdtemp(prefix="pcc_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
+    env.setdefault("PCC_COMMIT", code_stamp())   # tools/pmc_aggregate.py stamps its summary with it
     dirs, line = [], None
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter.lower())
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--config", str(config), "--steps", "400", "--warmup", "20", "--repeats", "1",
-                   "--no-cpu-baseline", "--no-pmc", "--no-policy"]
+                   "--no-cpu-baseline", "--no-pmc", "--no-policy", "--no-scaling"]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s)
             except subprocess.TimeoutExpired:
@@ -238,20 +252,118 @@ def policy_in_loop(pcc_rl_amd, torch, N, dev, horizon=64):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
+    recorded = []
+
     def rollout():
         box["b"] = agent.collect()
+        recorded.append(box["b"][1])     # the actions the policy chose: [horizon, N, 1]
 
     t_roll = timed(rollout, 3)
     t_upd = timed(lambda: agent.update(*box["b"][:5]), 2)
     env.check_flags()
-    env.close()
-    return {"rollout": {"value": N * horizon / t_roll, "unit": "env steps/s", "ms_per_step": 1e3 * t_roll / horizon},
+    # ---- where a rollout step's time goes (round 6): (a) the env alone under the SAME actions from the same state -- a second
+    # handle of the same seed replays the four recorded rollouts (the first untimed, like above), its two launches timed apart on
+    # every 7th step; (b) the policy kernel alone on the last rollout's observation rows; (c) the rest = launch gaps / the
+    # rollout's own bookkeeping (noise, GAE, the value of the last observation)
+    split = None
+    try:
+        obs_rows = box["b"][0]
+        env.close()
+        env = None
+        env2 = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
+        env2.reset()
+        for t in range(horizon):
+            env2.step(recorded[0][t])
+        n_rep = (len(recorded) - 1) * horizon
+        ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, n_rep, 7)}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_rep):
+            a = recorded[1 + k // horizon][k % horizon]
+            e = ev.get(k)
+            if e: e[0].record()
+            env2.step_send(a)
+            if e: e[1].record()
+            env2.step_retire()
+            if e: e[2].record()
+        torch.cuda.synchronize()
+        t_env = (time.perf_counter() - t0) / n_rep
+        env2.check_flags()
+        env2.close()
+        params = agent.policy.flat_params()
+        noise = torch.randn((horizon, N), device=dev)
+        a_o, l_o, v_o = torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
+        for t in range(4):
+            agent.policy.act_fused(obs_rows[t], True, params, noise[t], (a_o, l_o, v_o))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(horizon):
+            agent.policy.act_fused(obs_rows[t], True, params, noise[t], (a_o, l_o, v_o))
+        torch.cuda.synchronize()
+        t_pol = (time.perf_counter() - t0) / horizon
+        split = {"env_alone_under_the_policys_actions_ms": 1e3 * t_env,
+                 "env_send_ms": sum(e[0].elapsed_time(e[1]) for e in ev.values()) / len(ev),
+                 "env_retire_ms": sum(e[1].elapsed_time(e[2]) for e in ev.values()) / len(ev),
+                 "policy_kernel_ms": 1e3 * t_pol,
+                 "rest_ms": 1e3 * (t_roll / horizon - t_env - t_pol),
+                 "note": "a second handle (same seed) replays the recorded actions of the timed rollouts from the same state: what the env's "
+                         "two launches cost under N(0,1)-sampled actions (they spread the sending rates further than the line's U(-1,1) "
+                         "does: more packets in the largest envs); policy_kernel_ms = pcc_policy_act back to back on the rollout's "
+                         "observation rows; rest = launch gaps, the rollout's noise / GAE / last-value launches"}
+    except Exception as e:
+        split = {"error": "%s: %s" % (type(e).__name__, e)}
+    if env is not None:
+        env.close()
+    return {"rollout": {"value": N * horizon / t_roll, "unit": "env steps/s", "ms_per_step": 1e3 * t_roll / horizon, "split": split},
             "rollout_plus_update": {"value": N * horizon / (t_roll + t_upd), "unit": "env steps/s", "update_s": t_upd,
                                     "fused_update": bool(agent.fused_update)},
             "envs": N, "horizon": horizon,
             "note": "PPO.collect() over %d envs x %d steps (fused policy kernel + step_into, N(0,1)-sampled actions of the untrained "
                     "32-16 policy), then GAE + 4 epochs x 4 minibatches of the fused gradient step; 3 / 2 repetitions after one "
                     "untimed; supplementary -- `value` is the env with pre-generated U(-1,1) actions (SURVEY.md section 8d)" % (N, horizon)}
+
+
+def scaling_in_n(pcc_rl_amd, torch, dev, sizes=(131072, 262144), max_steps=400):
+    """Supplementary: the same workload (config 3's links and action law) at LARGER batches per GPU -- the step's two launches each
+    wait for their own longest work item, so a larger batch fills the wavefront slots the headline size leaves idle.  One whole
+    episode per size after 40 warm-up steps, HIP events around the two launches on every 7th step."""
+    out = []
+    for n in sizes:
+        env = None
+        try:
+            env = pcc_rl_amd.BatchedNetworkEnv(n, device=dev, seed=0, auto_reset=True, max_steps=max_steps)
+            gen = torch.Generator(device=dev).manual_seed(1234)
+            acts = torch.rand((max_steps, n, 1), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
+            env.reset()
+            for t in range(40):
+                env.step(acts[t])
+            ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, max_steps, 7)}
+            sent0 = env.state("total_sent").sum()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(max_steps):
+                e = ev.get(k)
+                if e: e[0].record()
+                env.step_send(acts[(40 + k) % max_steps])
+                if e: e[1].record()
+                env.step_retire()
+                if e: e[2].record()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            env.check_flags()
+            ks = [k for k in ev if (40 + k + 1) % max_steps != 0]
+            out.append({"envs": n, "value": n * max_steps / el, "unit": "env steps/s", "ms_per_step": 1e3 * el / max_steps,
+                        "send_ms": sum(ev[k][0].elapsed_time(ev[k][1]) for k in ks) / len(ks),
+                        "retire_ms": sum(ev[k][1].elapsed_time(ev[k][2]) for k in ks) / len(ks),
+                        "packets_per_env_step": float((env.state("total_sent").sum() - sent0).item()) / (n * max_steps),
+                        "device_bytes": env.device_bytes() if hasattr(env, "device_bytes") else None})
+        except Exception as e:   # (supplementary: never in the way of the line)
+            out.append({"envs": n, "error": "%s: %s" % (type(e).__name__, e)})
+        finally:
+            if env is not None:
+                env.close()
+            torch.cuda.empty_cache()
+    return out
 
 
 def async_groups(pcc_rl_amd, torch, N, dev, K, W, n_groups=4):
@@ -299,6 +411,8 @@ def main():
     ap.add_argument("--ring-capacity", type=int, default=0, help="records per accepted ring (0 = library default)")
     ap.add_argument("--no-policy", action="store_true",
                     help="skip the supplementary policy_in_loop figures (PPO rollout and rollout + update at the bench size)")
+    ap.add_argument("--no-scaling", action="store_true",
+                    help="skip the supplementary scaling_in_n figures (one episode each at 131 072 and 262 144 envs per GPU)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 counter passes that measure roofline.traffic (HBM bytes per launch)")
     ap.add_argument("--groups", type=int, default=0,
@@ -349,7 +463,9 @@ def main():
     K, W, R = args.steps, args.warmup, max(1, args.repeats)
     env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, env_gid_base=pdist.env_gid_base(rank, N), n_senders=S,
                                        link_params=(200.0, 0.03, 5.0, 0.0, 60.0) if cfg == 2 else None,   # ns:459-464
-                                       auto_reset=True, ring_capacity=args.ring_capacity, max_steps=args.max_steps)
+                                       auto_reset=True, ring_capacity=args.ring_capacity, max_steps=args.max_steps,
+                                       # experiments: "d1,d2,d3" = pool divisors for pcc_set_ring_pools (tools/r06/pmc_attrib.sh)
+                                       ring_pools=[int(v) for v in os.environ["PCC_BENCH_RING_POOLS"].split(",")] if os.environ.get("PCC_BENCH_RING_POOLS") else None)
     if os.environ.get("PCC_BENCH_TUNING"):   # experiments: {"knob": value, ...} for env.set_tuning (speed only, never results)
         env.set_tuning(**json.loads(os.environ["PCC_BENCH_TUNING"]))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -413,6 +529,8 @@ def main():
         n_all = kWhole * max_steps
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(n_all // SEG + 1)]
         ev_h = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, n_all, HALVES)}
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
         c0 = time.perf_counter()
         for k in range(n_all):
@@ -422,7 +540,9 @@ def main():
             t_global += 1
         ev_b[n_all // SEG].record()
         torch.cuda.synchronize()
-        el = time.perf_counter() - c0
+        if world > 1:
+            dist.barrier()
+        el = pdist.max_over_ranks(time.perf_counter() - c0, device=dev)   # MAX over ranks, like the timed runs below
         seg_t = [ev_b[j].elapsed_time(ev_b[j + 1]) / SEG for j in range(n_all // SEG)]       # ms per step, by segment
         per_ep = max_steps // SEG
         # mean over the episodes, by step of the episode (a step takes its segment's mean)
@@ -524,14 +644,19 @@ def main():
         value = world * N * K / med["elapsed"]
         ms_per_step = 1e3 * med["elapsed"] / K
         window_fields = None
+        # `value` / `ms_per_step` / `timed_steps` / `repeats` / `runs_ms_per_step` describe ONE measurement: value = envs x timed_steps /
+        # (ms_per_step x timed_steps).  `steps` stays the K the caller asked for (the bench contract echoes its arguments).
+        timed_steps, timed_repeats, timed_runs = K, R, [1e3 * r["elapsed"] / K for r in runs]
         if whole is not None:
             # fewer timed steps than an episode: the K-step window has no episode boundary inside, and SURVEY.md section 8d's
             # metric includes the auto-resets -- so `value` is the whole episodes' figure (three 400-step episodes with their
             # boundary resets, timed by this run just before the window), and the window is reported next to it
-            window_fields = {"value": value, "ms_per_step": ms_per_step, "steps": K,
+            window_fields = {"value": value, "ms_per_step": ms_per_step, "steps": K, "repeats": R,
+                             "runs_ms_per_step": [1e3 * r["elapsed"] / K for r in runs],
                              "note": "the %d timed steps after the warm-up (the bench contract's K), placed where an episode has its mean "
                                      "step time; no episode boundary inside" % K}
             value, ms_per_step = whole["value"], whole["ms_per_step"]
+            timed_steps, timed_repeats, timed_runs = whole["episodes"] * max_steps, 1, [whole["ms_per_step"]]
         pk_per_step = med["packets"] / (N * K)
         send_ms, retire_ms = med["send_ms"], med["retire_ms"]
         roof_src = "the timed steps"
@@ -557,15 +682,16 @@ def main():
         out = {
             "metric": "env steps/sec (whole node) at 64k parallel envs",
             "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "timed_steps": timed_steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "repeats": R, "runs_ms_per_step": [1e3 * r["elapsed"] / K for r in runs],
+            "repeats": timed_repeats, "runs_ms_per_step": timed_runs,
             "median_run_kernel_ms": {"send": med["send_ms"], "retire": med["retire_ms"], "first_steps": med["first_steps_ms"],
                                      "steps_with_events": med["event_steps"], "event_stride": ES,
                                      "note": "HIP events around the two kernels on every event_stride-th timed step (an event record "
                                              "costs the stream ~4.5 us; three on every step are 7 % of a step of config 3)"},
             "spread": (max(r["elapsed"] for r in runs) - min(r["elapsed"] for r in runs)) / med["elapsed"],
             "window": window,
+            "code": code_stamp(),
             "config": {"workload": ("BASELINE config %d: %d envs/GPU, %s, U(-1,1) actions, 400-step episodes, auto-reset%s"
                                     % (cfg, N, {2: "1 sender, fixed link (bw 200 pkt/s, 0.03 s, queue 5, no loss, rate0 60)",
                                                 3: "1 sender, per-env randomized bw/latency/queue/loss (ICML'19 ranges)",
@@ -581,8 +707,9 @@ def main():
                               "launcher": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else "plain"}
         if window_fields is not None:
             out["timed_window"] = window_fields
-            out["value_source"] = ("whole_episode: %d whole %d-step episodes with their boundary resets, run and timed before the %d-step "
-                                   "window (--steps < one episode); the window itself is `timed_window`" % (whole["episodes"], max_steps, K))
+            out["value_source"] = ("whole_episode: %d whole %d-step episodes with their boundary resets (timed_steps = %d, one pass, MAX over "
+                                   "ranks), run and timed before the %d-step window (--steps < one episode); the K-step window with its own "
+                                   "repeats is `timed_window`" % (whole["episodes"], max_steps, whole["episodes"] * max_steps, K))
         if whole is not None:
             out["whole_episode"] = dict(whole, unit="env steps/s", steps=whole["episodes"] * max_steps,
                                         note="%d whole %d-step episodes run before the timed steps (a boundary event every 5 steps, the "
@@ -648,6 +775,14 @@ def main():
                 out["policy_in_loop"] = policy_in_loop(pcc_rl_amd, torch, N, dev)
             except Exception as e:   # (supplementary: never in the way of the line)
                 out["policy_in_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and cfg == 3 and not args.stagger and not args.no_scaling and N == 65536 and not fused:
+            pts = scaling_in_n(pcc_rl_amd, torch, dev, max_steps=max_steps)
+            head = {"envs": N, "value": value, "unit": "env steps/s", "ms_per_step": ms_per_step, "send_ms": send_ms, "retire_ms": retire_ms,
+                    "packets_per_env_step": pk_roof, "note": "the line's own figures"}
+            out["scaling_in_n"] = {"points": [head] + pts,
+                                   "note": "envs per GPU beyond BASELINE's 65 536 (same links, same action law, one whole episode each after 40 "
+                                           "warm-up steps; supplementary): the two launches of a step are as long as their longest work "
+                                           "items, so a larger batch costs less than proportionally -- what a trainer should run per GPU"}
         if world == 1 and args.groups > 1:
             out["async_groups"] = async_groups(pcc_rl_amd, torch, N, dev, K, W, args.groups)
         if not args.no_cpu_baseline and world == 1:

@@ -222,7 +222,8 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     serve; pcc-rl_amd/csrc/pcc_fused.hip): 0 (default) = the send launch and the retire launch -- the
                                     one-launch step is exact (the parity suite runs through it) and measured SLOWER at full size
                                     (0.33 ms per step against 0.18: profiles/r05_fused_experiments.json); 1 = on; 2 = experiment: its
-                                    send part as the send launch, then the retire launch */,
+                                    send part as the send launch, then the retire launch.  EXPERIMENTAL: refused (PCC_EINVAL) unless the
+                                    device reports 8 XCDs in one partition, the configuration its in-launch hand-off was validated on */,
        PCC_TUNE_FUSED_ACQUIRE = 27 /* fused step, debug: 2 = an agent-scope acquire (buffer_inv sc1) between the poll that finds an env
                                     ready and the first load of its state; 0 (default) = none: the ready queues are per physical XCD, so
                                     producer and consumer share an L2 (pcc-rl_amd/csrc/pcc_dev.h "ready queues") */,

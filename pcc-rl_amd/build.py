@@ -113,7 +113,41 @@ def build_library(force=False, verbose=False, profile=False, extra_flags=(), out
         pass
     with open(lib + ".resources.json", "w") as f:
         json.dump(resources, f, indent=1, sort_keys=True)
+    with open(lib + ".build_info.json", "w") as f:
+        json.dump(_source_stamp(extra_flags, profile), f, indent=1, sort_keys=True)
     return lib
+
+
+def _source_stamp(extra_flags=(), profile=False):
+    """What a built library was compiled from: the commit of the tree (and whether csrc/ or include/ differed from it) -- the GPU
+    box gets the built .so but no .git, and every measurement file names the code it measured -- plus a hash of the sources."""
+    import hashlib
+    import time
+    h = hashlib.sha256()
+    for p in sorted(SRCS + HEADERS + [os.path.join(INCLUDE, "pcc_sim.h"), os.path.join(INCLUDE, "pcc_policy.h")]):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    stamp = {"sources_sha16": h.hexdigest()[:16], "flags": HIPCC_FLAGS + (["-DPCC_PROFILE=1"] if profile else []) + list(extra_flags),
+             "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "commit": None, "dirty": None}
+    try:
+        stamp["commit"] = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                         universal_newlines=True, timeout=10).stdout.strip() or None
+        if stamp["commit"]:
+            stamp["dirty"] = bool(subprocess.run(["git", "status", "--porcelain", "--", "pcc-rl_amd/csrc", "include"], cwd=ROOT,
+                                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True, timeout=10).stdout.strip())
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return stamp
+
+
+def build_info(lib=None):
+    """The stamp build_library() left next to `lib` (default: the product library); {} if there is none."""
+    import json
+    try:
+        with open((lib or LIB) + ".build_info.json") as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 def build_variants(force=False, verbose=False):

@@ -199,6 +199,10 @@ __global__ __launch_bounds__(T) void noise_sorted_kernel(Dev D, int warm, uint32
     const double dl = D.env[i].dl, lr = D.env[i].lr, maxq = D.env[i].maxq, ebw = D.env[i].ebw, span = D.noise_span;
     const double start = D.env[i].now, end = start + D.env[i].run_dur;
     const double gap = 1.0 / rate;
+    // A latency below the clock's resolution (t + dl == t: pcc_set_param_ranges only asks for dl > 0) would let a packet's arrival
+    // at the return link tie with its own SEND, which the event loop runs first -- and the count of "SENDs strictly before the
+    // arrival" below would miss it (two draws).  Such an env is the event loop's (nothing is written yet).
+    if (!(end + 0.5 * dl > end)) return;
     const double nsend0 = D.snd[k0s].next_send;
     const uint32_t n_old = D.snd[k0s].heap_n & 0x7FFFFFFFu, noise_cap = D.noise_cap;
     double2 *const H = D.noise_heap + (size_t)i * (noise_cap + kHeapPad);

@@ -622,7 +622,9 @@ __device__ __forceinline__ void rtt_means(const Group &g, const double2 *ring, u
     constexpr int kPairJob = G == 16 ? 0 : 1;
     const uint32_t pair_beg = kPairJob == 0 ? jb1 : jb2, pair_n = kPairJob == 0 ? jn1 : jn2;
     double res0 = 0.0, res1 = 0.0, res2 = 0.0;
-    __shared__ uint32_t s_walk[kWalkMaxBlock / 8 * kWalkRowWords];
+    // (rows are read and written as 8-byte words from word 8 on: the array is aligned for that by declaration, not by luck)
+    static_assert(kWalkRowWords % 2 == 0, "a row's sums start on an 8-byte boundary");
+    __shared__ __attribute__((aligned(16))) uint32_t s_walk[kWalkMaxBlock / 8 * kWalkRowWords];
     NpSumWalk w;
     w.bind((lds_u32 *)s_walk + (threadIdx.x >> 3) * kWalkRowWords, sl == 0);
     int job = 0;

@@ -18,7 +18,12 @@ struct SendLds {
     EnvSlot<NS> slots[4][kSlots];      // send_wave_item's parked envs, per wavefront
     uint32_t tab[4][6][kClasses];      // wave_body's class table, per wavefront
     TeamX team;                        // what the wavefronts of a team pass tell each other
+    double2 stage[4][4 * kWave];       // heavy_mi<.., STAGE>: the records of a closed-form pass on their way out, per wavefront
 };
+#ifndef PCC_STAGE_RECORDS
+#define PCC_STAGE_RECORDS 1
+#endif
+constexpr bool kStageRecords = PCC_STAGE_RECORDS != 0;
 
 // The light items of one workgroup (b of Q light workgroups): one item per wavefront and round, dealt statically -- the grid
 // covers the worst case (every env light), a wavefront without an item leaves at once.  With work lists (view >= 0: the list set of the workgroup's
@@ -82,8 +87,8 @@ __device__ __forceinline__ void light_body(const Dev &D, SendLds<NS> &lds, const
             // the item's last lanes (see send_light_item) go on by the wave path, from the state the item just stored: what
             // one lane wrote is read by others of this wavefront -- a workgroup-scope fence orders that (same L1)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            (void)send_wave_item<NS, TRACE, 1>(D, lane, i, ((left >> lane) & 1ull) != 0ull, false, 0xFFFFFFFFu, warm, warm_mi,
-                                               actions, actions_f64, lds.slots[wv]);
+            (void)send_wave_item<NS, TRACE, 1, kStageRecords && NS == 1>(D, lane, i, ((left >> lane) & 1ull) != 0ull, false, 0xFFFFFFFFu, warm, warm_mi,
+                                                                         actions, actions_f64, lds.slots[wv], 0u, nullptr, false, nullptr, lds.stage[wv]);
         }
         if (prio) set_prio(0u);
     }
@@ -161,8 +166,8 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
                     const uint32_t off = tt - (uni_u32(tab[4][L]) - uni_u32(tab[5][L]));
                     const uint32_t *list = cls_list_of(D, view, kClasses - 1u - L);
                     const int64_t i = lane == 0 ? (int64_t)list[off] : 0;
-                    (void)send_wave_item<NS, TRACE, kTeams ? kTeamMax : 1>(D, lane, i, lane == 0, true, tl_base + n_items + tt < tl_end ? tl_base + n_items + tt : 0xFFFFFFFFu, 0, 0, actions,
-                                                                           actions_f64, lds.slots[wv], wv, &lds.team);
+                    (void)send_wave_item<NS, TRACE, kTeams ? kTeamMax : 1, kStageRecords && NS == 1>(D, lane, i, lane == 0, true, tl_base + n_items + tt < tl_end ? tl_base + n_items + tt : 0xFFFFFFFFu, 0, 0, actions,
+                                                                           actions_f64, lds.slots[wv], wv, &lds.team, false, nullptr, lds.stage[wv]);
                     if constexpr (FUSED) {   // all four wavefronts stored records: each drains, then wavefront 0 publishes
                         fused_drain();
                         __syncthreads();
@@ -229,7 +234,8 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
             const int64_t i = has ? (int64_t)list[idx] : 0;
             const bool prio = t < D.prio_wave_items;
             if (prio) set_prio(D.prio_level);
-            (void)send_wave_item<NS, TRACE, 1>(D, lane, i, has, true, tl_base + t < tl_end ? tl_base + t : 0xFFFFFFFFu, 0, 0, actions, actions_f64, lds.slots[wv]);
+            (void)send_wave_item<NS, TRACE, 1, kStageRecords && NS == 1>(D, lane, i, has, true, tl_base + t < tl_end ? tl_base + t : 0xFFFFFFFFu, 0, 0, actions, actions_f64, lds.slots[wv],
+                                                                         0u, nullptr, false, nullptr, lds.stage[wv]);
             if constexpr (FUSED) {
                 fused_drain();
                 fused_push(D, read_buf, xcc, 1u, __ballot(has), lane, i);

@@ -58,8 +58,14 @@ __device__ __forceinline__ LaneEnv<NS> load_env(const Dev &D, const uint32_t lan
         double rate = D.snd[k].rate;
         const bool act = fresh && !warm && E.live;
         if (act) {
-            const int64_t a = D.use_cwnd ? ii * 2 : ii * NS + s;  // USE_CWND: [rate action, cwnd action] per env
-            double delta = actions_f64 ? ((const double *)actions)[a] : (double)((const float *)actions)[a];
+            // (the action's address is computed HERE, from the env index behind a barrier the optimizer cannot see through: hoisted
+            // out of the wave path's loop over an item's envs, the index times 2 or NS or the address itself stayed live across
+            // heavy_mi and was the one value the send kernel spilled to scratch)
+            uint32_t i_here = (uint32_t)ii;
+            asm volatile("" : "+v"(i_here));
+            const int64_t a = D.use_cwnd ? (int64_t)i_here * 2 : (int64_t)i_here * NS + s;  // USE_CWND: [rate action, cwnd action] per env
+            const char *ap = (const char *)actions + (a << (actions_f64 ? 3 : 2));
+            double delta = actions_f64 ? *(const double *)ap : (double)*(const float *)ap;
             if (delta != delta) { delta = 0.0; E.flags |= PCC_FLAG_BAD_ACTION; }  // NaN: never silent, never in the clock
             delta *= D.delta_scale;
             rate = delta >= 0.0 ? rate * (1.0 + delta) : rate / (1.0 - delta);
@@ -154,6 +160,50 @@ __device__ __forceinline__ void timeline_record(const Dev &D, const uint32_t lan
         w[0] = tl0; w[1] = tl1; w[2] = wall_clock64(); w[3] = heavy_envs | (last_env << 16); w[4] = sum; w[5] = mx; w[6] = hp;
         w[7] = live_n | (closed << 8) | (other << 24);
     }
+}
+
+// ---- the lane rounds' packet, branch-free (round 6).  The same operations of ns:66-84 in the reference's order as
+// link_send (pcc_dev.h), other selects -- one basic block, no exec-mask regions, a shorter chain from q to q':
+//   qcur    = max(0, q - (t - tu))                            ns:66-67
+//   grown   = qcur + 1/bw   (= 1/bw + qcur: the operands of ns:79 and ns:82 commute, the sums are the same double)
+//   dropped = lost at random || grown > maxq                  ns:73, 79 as ONE compare, against (lost ? a negative number : maxq)
+//   q'      = dropped ? (lost ? q : qcur) : grown             ns:74, 80-82: the inner select does not wait for the compare
+//   tu'     = lost ? tu : t                                   ns:76
+// a4 / d4 are the ring indices times 16 (byte offsets before masking; they wrap like the indices do).
+struct LightState {
+    double q, tu, t;
+    uint32_t a4, d4;
+};
+__device__ __forceinline__ void light_packet(LightState &S, const bool lost, const double dl, const double maxq, const double ebw,
+                                             const double gap, char *base, const uint32_t mask_b, const uint32_t dmask_b,
+                                             const uint32_t cap_b, const bool store) {
+    const double t = S.t;
+    const double qcur = max0(S.q - (t - S.tu));
+    const double grown = qcur + ebw;
+    const double lat0 = dl + qcur;            // ns:170
+    // (maxq > 0 and grown >= 1/bw > 0: any negative limit makes the compare true)
+    const double lim = __hiloint2double(lost ? (int)0xBFF00000u : __double2hiint(maxq), __double2loint(maxq));
+    const bool dropped = grown > lim;
+    const double keep = lost ? S.q : qcur;
+    S.q = dropped ? keep : grown;
+    S.tu = lost ? S.tu : t;
+    double2 rec;
+    rec.x = t + lat0;                         // ns:174
+    rec.y = lat0;                             // ns:173
+    const uint32_t off_a = S.a4 & mask_b, off_d = cap_b + (S.d4 & dmask_b);
+    if (store) st_rec(reinterpret_cast<double2 *>(base + (dropped ? off_d : off_a)), rec);
+    const uint32_t inc = dropped ? 16u : 0u;
+    S.d4 += inc;
+    S.a4 += 16u - inc;
+    S.t = t + gap;                            // ns:161
+}
+#ifndef PCC_LIGHT_BLOCKS
+#define PCC_LIGHT_BLOCKS 1
+#endif
+constexpr int kLightBlocks = PCC_LIGHT_BLOCKS;   // Philox blocks (4 packets each) per loop body of the lane rounds
+__device__ __forceinline__ void light_philox(const Dev &D, uint32_t blk, uint32_t mi, uint32_t episode, uint32_t gid, uint32_t (&w)[4]) {
+    if (prof_skip(D, 8)) { w[0] = blk * 2654435761u; w[1] = w[0] ^ gid; w[2] = w[1] * 40503u; w[3] = w[2] ^ mi; }
+    else philox4x32_10_sched(blk, mi, episode, gid, D.key0, D.key1, w);
 }
 
 // A LIGHT item: lane l sends for env i (or for none).  Lane-serial rounds of round_packets packets per env; after a
@@ -252,48 +302,61 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
             double t = E.nsend[0];
             uint32_t a = E.ta[0], d = E.td[0];
             active = E.run;
-            uint32_t blk = 0;  // Philox block = packets sent in this MI / 4
-            for (;;) {
-                if (active) {
-                    if (!TRACE) {
-                        // four packets per Philox block, no loads, no data-dependent branches.  The first
-                        // `safe` packets are certainly before `end` (t advances by gap up to rounding; two
-                        // packets of margin), so whole blocks run without the fp64 exit test.
-                        const double ahead = (end - t) / gap - 2.0;
+            if constexpr (!TRACE) {
+                // Philox uniforms: the loop body is ONE basic block per kLightBlocks Philox blocks (4 packets each) -- the
+                // branch-free packet (light_packet) and the Philox rounds of the NEXT blocks, which depend on nothing the packets
+                // compute: the compiler interleaves the two instruction streams, so the multiplies fill the latency of the
+                // recurrence's dependent fp64 operations instead of running in front of them (round 6: 250 -> see
+                // profiles/r06_lane_round_microbench.txt ns per iteration; the longest light item is the launch's critical path).
+                // The first `safe` packets are certainly before `end` (t advances by gap up to rounding; two packets of margin),
+                // so whole blocks run without the fp64 exit test.
+                LightState S;
+                S.q = q; S.tu = tu; S.t = t; S.a4 = a << 4; S.d4 = d << 4;
+                const uint32_t a4_0 = S.a4, d4_0 = S.d4;
+                uint32_t blk = 0;  // Philox block = packets sent in this MI / 4
+                for (;;) {
+                    if (active) {
+                        const double ahead = (end - S.t) / gap - 2.0;
                         uint32_t safe4 = ahead >= 4.0 ? (uint32_t)fmin(ahead, (double)D.round_packets) >> 2 : 0u;
                         uint32_t budget4 = D.round_packets / 4 - safe4;
-                        for (; safe4; safe4--) {
-                            uint32_t w[4];
-                            if (prof_skip(D, 8)) { w[0] = blk * 2654435761u; w[1] = w[0] ^ gid; w[2] = w[1] * 40503u; w[3] = w[2] ^ mi; } else philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
-                            blk++;
+                        uint32_t w[kLightBlocks][4];
+#pragma unroll
+                        for (int b = 0; b < kLightBlocks; b++) light_philox(D, blk + b, mi, episode, gid, w[b]);
+                        for (; safe4 >= (uint32_t)kLightBlocks; safe4 -= kLightBlocks) {
+                            uint32_t wn[kLightBlocks][4];
+#pragma unroll
+                            for (int b = 0; b < kLightBlocks; b++) light_philox(D, blk + kLightBlocks + b, mi, episode, gid, wn[b]);
+#pragma unroll
+                            for (int b = 0; b < kLightBlocks; b++)
+#pragma unroll
+                                for (int k = 0; k < 4; k++)
+                                    light_packet(S, always || w[b][k] < thr, dl, maxq, ebw, gap, base, mask_b, dmask_b, cap_b, !prof_skip(D, 4));
+                            blk += kLightBlocks;
+#pragma unroll
+                            for (int b = 0; b < kLightBlocks; b++)
+#pragma unroll
+                                for (int k = 0; k < 4; k++) w[b][k] = wn[b][k];
+                        }
+                        budget4 += safe4;   // (a block left over when two go to a body)
+                        for (; budget4 && S.t < end; budget4--) {
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
-                                bool dropped;
-                                const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
-                                const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                                if (!prof_skip(D, 4)) st_rec(reinterpret_cast<double2 *>(base + off), rec);
-                                a += dropped ? 0u : 1u;
-                                d += dropped ? 1u : 0u;
-                                t += gap;  // ns:161
+                                if (k > 0 && !(S.t < end)) break;
+                                light_packet(S, always || w[0][k] < thr, dl, maxq, ebw, gap, base, mask_b, dmask_b, cap_b, !prof_skip(D, 4));
                             }
-                        }
-                        for (; budget4 && t < end; budget4--) {
-                            uint32_t w[4];
-                            if (prof_skip(D, 8)) { w[0] = blk * 2654435761u; w[1] = w[0] ^ gid; w[2] = w[1] * 40503u; w[3] = w[2] ^ mi; } else philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
                             blk++;
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                if (k > 0 && !(t < end)) break;
-                                bool dropped;
-                                const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
-                                const uint32_t off = dropped ? cap_b + ((d << 4) & dmask_b) : ((a << 4) & mask_b);
-                                if (!prof_skip(D, 4)) st_rec(reinterpret_cast<double2 *>(base + off), rec);
-                                a += dropped ? 0u : 1u;
-                                d += dropped ? 1u : 0u;
-                                t += gap;  // ns:161
-                            }
+                            light_philox(D, blk, mi, episode, gid, w[0]);
                         }
-                    } else {
+                        active = S.t < end;
+                    }
+                    const uint64_t am = __ballot(active);
+                    if (!am || (uint32_t)__popcll(am) <= D.takeover_lanes) break;
+                }
+                q = S.q; tu = S.tu; t = S.t;
+                a += (S.a4 - a4_0) >> 4; d += (S.d4 - d4_0) >> 4;   // (the packets of one interval: far fewer than 2^28)
+            } else {
+                for (;;) {
+                    if (active) {
                         for (uint32_t budget = D.round_packets; budget && t < end; budget--) {
                             const uint64_t pos = (uint64_t)a + d;
                             double u = 1.0;
@@ -307,11 +370,11 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
                             d += dropped ? 1u : 0u;
                             t += gap;
                         }
+                        active = t < end;
                     }
-                    active = t < end;
+                    const uint64_t am = __ballot(active);
+                    if (!am || (uint32_t)__popcll(am) <= D.takeover_lanes) break;
                 }
-                const uint64_t am = __ballot(active);
-                if (!am || (uint32_t)__popcll(am) <= D.takeover_lanes) break;
             }
             E.nsend[0] = t;
             E.sent[0] = (a - E.ta[0]) + (d - E.td[0]);
@@ -443,12 +506,13 @@ __device__ __forceinline__ uint64_t uni_u64(uint64_t v) { return ((uint64_t)uni_
 // W > 1: a TEAM item -- one env (lane 0 of every wavefront names it) sent by the W wavefronts of the workgroup together
 // (heavy_mi<.., W>); every wavefront loads the env's state and computes everything alike, wavefront 0 writes.
 // Returns the packets the item sent (wave-uniform; the launch statistics of pcc_get_send_split).
-template <int NS, bool TRACE, int W>
+// STAGE / stage: the closed-form passes' records leave through 256 LDS slots of this wavefront (heavy_mi; one sender).
+template <int NS, bool TRACE, int W, bool STAGE = false>
 __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t lane, const int64_t i, const bool in_range,
                                                    const bool fresh, const uint32_t tl_slot, const int warm, const uint32_t warm_mi,
                                                    const void *actions, const int actions_f64, EnvSlot<NS> *slots,
                                                    const uint32_t wv = 0, TeamX *X = nullptr, const bool no_promote = false,
-                                                   bool *refused = nullptr) {
+                                                   bool *refused = nullptr, double2 *stage = nullptr) {
     static_assert(W == 1 || NS == 1, "team items are built for one sender");
     const bool writer = W == 1 || wv == 0u;
     const uint64_t tl0 = prof_on(D) ? wall_clock64() : 0;
@@ -507,10 +571,10 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
                     st.a = ta_new[0]; st.d = td_new[0]; st.flags = 0;
                     st.prof_closed = 0; st.prof_other = 0;
                     st.sent = sent_new[0];  // packets of this MI the lane rounds already sent
-                    heavy_mi<TRACE, W>(D, lane, wv, X, uni_f64(S.dl), uni_f64(S.lr), uni_u32(S.thr), (bits & 1u) != 0u, uni_f64(S.maxq),
-                                       uni_f64(S.ebw), uni_f64(S.gap[0]), uni_f64(S.end), uni_u32(S.episode), uni_u32(S.mi), uni_u32(S.gid),
-                                       reinterpret_cast<const double *>(uni_u64(reinterpret_cast<uint64_t>(S.trace))),
-                                       reinterpret_cast<char *>(uni_u64(reinterpret_cast<uint64_t>(S.base[0]))), uni_u32(S.cap[0]), st);
+                    heavy_mi<TRACE, W, STAGE>(D, lane, wv, X, uni_f64(S.dl), uni_f64(S.lr), uni_u32(S.thr), (bits & 1u) != 0u, uni_f64(S.maxq),
+                                              uni_f64(S.ebw), uni_f64(S.gap[0]), uni_f64(S.end), uni_u32(S.episode), uni_u32(S.mi), uni_u32(S.gid),
+                                              reinterpret_cast<const double *>(uni_u64(reinterpret_cast<uint64_t>(S.trace))),
+                                              reinterpret_cast<char *>(uni_u64(reinterpret_cast<uint64_t>(S.base[0]))), uni_u32(S.cap[0]), st, stage);
                     sent_new[0] += (st.a - ta_new[0]) + (st.d - td_new[0]);
                     q_new = st.q; tu_new = st.tu; nsend_new[0] = st.t; ta_new[0] = st.a; td_new[0] = st.d; flags |= st.flags;
                     if (kProfile) { tl_closed += st.prof_closed; tl_other += st.prof_other; tl_env = (uint64_t)ie; }

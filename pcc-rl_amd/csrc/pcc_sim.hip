@@ -75,6 +75,7 @@ struct pcc_sim {
     // the fused step (pcc_fused.hip): on / off (tuning), the list buffer known to be clean (-1: none), workgroups of the
     // kernel a compute unit holds at once (per rng mode; 0 = not asked yet, -1 = unknown), light-first workgroups per partition
     int fused;
+    int xcc_count;      // XCDs of the device (hipDeviceAttributeNumberOfXccs): the fused step's per-XCD queues are built for 8
     int clean_buf;
     int fused_blocks[2];
     uint32_t fused_light_wgs;
@@ -564,6 +565,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     sim->clean_buf = -1;
     sim->noise_sorted = 1;
     sim->fused = 0;   // (measured slower than the two launches at full size: profiles/r05_fused_experiments.json)
+    { int x = 0; sim->xcc_count = hipDeviceGetAttribute(&x, hipDeviceAttributeNumberOfXccs, device) == hipSuccess ? x : 0; }
     sim->fused_light_wgs = 32;   // light-first workgroups per partition (4 wavefronts each: a partition of 8 192 envs has ~105 light items)
     d.fused_acquire = 0u;
     d.fused_spin_ticks = 100000000u;   // 1 s of the 100 MHz clock
@@ -804,7 +806,14 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
             if (value < 0 || value > 64) return fail(PCC_EINVAL, "takeover_lanes out of range");
             sim->d.takeover_lanes = (uint32_t)value;
             return PCC_OK;
-        case PCC_TUNE_FUSED: sim->fused = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0); return PCC_OK;
+        case PCC_TUNE_FUSED:
+            // experimental: its hand-off inside a launch counts on what was validated on one configuration
+            // only -- a gfx950 with 8 XCDs in one partition (XCC_ID & 7 names the L2 a wavefront shares with its consumers)
+            // (0 = the runtime does not say: not refused)
+            if (value != 0.0 && sim->xcc_count > 0 && sim->xcc_count != (int)kXcds)
+                return fail(PCC_EINVAL, "the one-launch step is validated for a device of %u XCDs in one partition; this one reports %d", kXcds, sim->xcc_count);
+            sim->fused = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
+            return PCC_OK;
         case PCC_TUNE_FUSED_ACQUIRE:
             if (value != 0.0 && value != 2.0) return fail(PCC_EINVAL, "fused_acquire must be 0 or 2");
             sim->d.fused_acquire = (uint32_t)value;
@@ -899,18 +908,25 @@ int update_engine(pcc_sim_t *sim) {
         DeviceGuard guard(sim->device);
         const size_t senders = (size_t)sim->d.n * sim->d.ns;
         const size_t heaps = senders * (sim->ring_capacity + kHeapSlack) * sizeof(double2), lists = senders * sim->ring_capacity * sizeof(double2);
-        void *p = nullptr;
+        // both blobs are allocated before either is published: a failure leaves the handle as it was (a retry starts over)
+        void *p = nullptr, *po = nullptr;
+        const size_t outs = (size_t)sim->d.n * sizeof(NoiseOut);
         if (hipMalloc(&p, heaps + lists) != hipSuccess)
             return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the event heaps failed", heaps + lists);
+        if (hipMalloc(&po, outs) != hipSuccess) {
+            (void)hipFree(p);
+            return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the intervals' results failed", outs);
+        }
+        if (hipMemset(po, 0, outs) != hipSuccess) {
+            (void)hipFree(po);
+            (void)hipFree(p);
+            return fail(PCC_EHIP, "hipMemset of the intervals' results failed");
+        }
         sim->noise_blob = p;
-        sim->noise_bytes = heaps + lists;
+        sim->noise_out_blob = po;
+        sim->noise_bytes = heaps + lists + outs;
         sim->d.noise_heap = static_cast<double2 *>(p);
         sim->d.noise_rtt = sim->d.noise_heap + senders * (sim->ring_capacity + kHeapSlack);
-        void *po = nullptr;
-        if (hipMalloc(&po, (size_t)sim->d.n * sizeof(NoiseOut)) != hipSuccess || hipMemset(po, 0, (size_t)sim->d.n * sizeof(NoiseOut)) != hipSuccess)
-            return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the intervals' results failed", (size_t)sim->d.n * sizeof(NoiseOut));
-        sim->noise_out_blob = po;
-        sim->noise_bytes += (size_t)sim->d.n * sizeof(NoiseOut);
         sim->d.noise_out = static_cast<NoiseOut *>(po);
         sim->d.noise_seq = 0;
         sim->d.noise_cap = sim->ring_capacity;

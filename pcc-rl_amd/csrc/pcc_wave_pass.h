@@ -110,11 +110,19 @@ __device__ __forceinline__ double pow2_f64(int e_unbiased) {  // 2^e for a norma
 #define PCC_TRY_REGIME_C (maxq - 64.0 * ebw < B)
 #endif
 
-template <bool TRACE, int W>
+// STAGE (round 6; the send kernel's wavefronts): the records of a closed-form pass leave through `stage`, 256 slots of LDS per
+// wavefront.  A lane owns four CONSECUTIVE positions, so the store instruction of position i had neighbouring lanes ~4 ring
+// slots (64 bytes) apart: every lane a request of its own to the compute unit's address path -- one per record, 9.85 M write
+// requests per send launch (TCP_TCC_WRITE_REQ, profiles/r06_pmc_attribution.json), next to the lane rounds' scattered stores
+// that wait behind them (a lane-round iteration costs 85-115 ns of arithmetic alone and 240-260 next to the wave path:
+// profiles/r06_lane_round_microbench.txt, r06_send_timeline_*.json).  Staged, the accepted records of the pass sit in LDS in
+// ring order from slot 0 up, the dropped ones from slot 255 down, and lane l stores slot 64 k + l: 1 KB of consecutive ring
+// bytes per instruction, a quarter of the requests.  Same records, same ring slots.
+template <bool TRACE, int W, bool STAGE = false>
 __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint32_t wv, TeamX *X, double dl, double lr,
                                          uint32_t thr, bool always, double maxq, double ebw, double gap, double end,
                                          uint32_t episode, uint32_t mi, uint32_t gid, const double *trace, char *base,
-                                         uint32_t cap, SendState &st) {
+                                         uint32_t cap, SendState &st, double2 *stage = nullptr) {
     static_assert(W >= 1 && W <= kTeamMax, "team size");
     const uint32_t mask_b = (cap - 1u) << 4, dmask_b = (2u * cap - 1u) << 4, cap_b = cap << 4;
     constexpr uint32_t kPass = 4u * kWave * W;
@@ -481,12 +489,24 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 double x = x_base;
                 int64_t xt = xi_base + c_before;  // regime C: the true queue in units of v
                 uint32_t j = (uint32_t)j_base;
+                // STAGE: what this wavefront's first committed position has in front of it in the pass: accepted, dropped
+                uint32_t acc0 = 0, drp0 = 0, n_acc_w = 0, n_com_w = 0;
+                if constexpr (STAGE) {
+                    acc0 = rl_u32((uint32_t)j_base, 0);
+                    const uint32_t p0 = W > 1 ? wv * 4u * kWave : 0u, pv = p0 > skip ? p0 : skip;   // (this wavefront's first position)
+                    drp0 = (pv - skip) - acc0;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const uint32_t p = 4u * glane + (uint32_t)i;
                     const bool a = (acc4 >> i) & 1u;
                     const int cpr = (int)((cp4 >> (2 * i)) & 3u) - 1;  // regime C: this packet's correction c' (0 elsewhere)
                     if (regime == 3) x = (double)xt * u;  // exact: even from B up
+                    if constexpr (STAGE) {
+                        const bool com = p >= skip && p < p_stop;
+                        n_com_w += (uint32_t)__popcll(__ballot(com));
+                        n_acc_w += (uint32_t)__popcll(__ballot(com && a));
+                    }
                     if (p >= skip && p < p_stop) {
                         const uint32_t kk = p - skip;             // packets of the pass before this one
                         const double tki = t0 + (double)kk * G;   // exact
@@ -494,8 +514,12 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                         double2 rec;
                         rec.y = dl + qc;                          // ns:170
                         rec.x = tki + rec.y;                      // ns:174
-                        const uint32_t off = a ? (((st.a + j) << 4) & mask_b) : cap_b + (((st.d + (kk - j)) << 4) & dmask_b);
-                        st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                        if constexpr (STAGE) {
+                            stage[a ? j - acc0 : 255u - ((kk - j) - drp0)] = rec;
+                        } else {
+                            const uint32_t off = a ? (((st.a + j) << 4) & mask_b) : cap_b + (((st.d + (kk - j)) << 4) & dmask_b);
+                            st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                        }
                         if ((m4 >> i) & 1u) {
                             have_last = true;
                             last_t = tki;
@@ -508,6 +532,21 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                         xt = (a ? xt + Ri + cpr : xt) - Gi;
                         j += a ? 1u : 0u;
                     }
+                }
+                if constexpr (STAGE) {
+                    // (what the lanes staged is read by other lanes of this wavefront: LDS accesses of one wavefront execute in
+                    // order; the barriers keep the compiler from moving them across)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const uint32_t a0 = st.a + acc0, d0 = st.d + drp0, n_drp_w = n_com_w - n_acc_w;
+                    for (uint32_t sl = lane; sl < n_acc_w; sl += kWave)
+                        st_rec(reinterpret_cast<double2 *>(base + (((a0 + sl) << 4) & mask_b)), stage[sl]);
+                    for (uint32_t sl = lane; sl < n_drp_w; sl += kWave)
+                        st_rec(reinterpret_cast<double2 *>(base + cap_b + (((d0 + sl) << 4) & dmask_b)), stage[255u - sl]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();   // (the next pass stages into the same slots)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
                 const uint64_t lm = __ballot(have_last);
                 if constexpr (W == 1) {

@@ -40,16 +40,17 @@ def work_lists_for_small_batches():
     workgroups, restart items -- so they switch the lists on for every batch size; the tests of the small-batch path
     itself set BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS back to None."""
     import pcc_rl_amd
-    old = pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS
-    pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = 0
-    # the step as one launch (the default) or as two (PCC_TEST_FUSED=0), and the fused step's acquire mode: tests/test_variants.py
-    # runs slices of the parity suite through each
+    B = pcc_rl_amd.BatchedNetworkEnv
+    old = (B.DEFAULT_LIST_MIN_ENVS, B.DEFAULT_FUSED, B.DEFAULT_FUSED_ACQUIRE, B.DEFAULT_NOISE_SORTED)
+    B.DEFAULT_LIST_MIN_ENVS = 0
+    # the step as two launches (the library's default) or as one (PCC_TEST_FUSED=1), and the fused step's acquire mode:
+    # tests/test_variants.py runs slices of the parity suite through each
     if os.environ.get("PCC_TEST_FUSED") is not None:
-        pcc_rl_amd.BatchedNetworkEnv.DEFAULT_FUSED = int(os.environ["PCC_TEST_FUSED"])
+        B.DEFAULT_FUSED = int(os.environ["PCC_TEST_FUSED"])
     if os.environ.get("PCC_TEST_FUSED_ACQUIRE") is not None:
-        pcc_rl_amd.BatchedNetworkEnv.DEFAULT_FUSED_ACQUIRE = int(os.environ["PCC_TEST_FUSED_ACQUIRE"])
+        B.DEFAULT_FUSED_ACQUIRE = int(os.environ["PCC_TEST_FUSED_ACQUIRE"])
     # latency noise: intervals by sorting (default), by the event loop (0), or the two crossed (2: the small instance + the event loop)
     if os.environ.get("PCC_TEST_NOISE_SORTED") is not None:
-        pcc_rl_amd.BatchedNetworkEnv.DEFAULT_NOISE_SORTED = int(os.environ["PCC_TEST_NOISE_SORTED"])
+        B.DEFAULT_NOISE_SORTED = int(os.environ["PCC_TEST_NOISE_SORTED"])
     yield
-    pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = old
+    B.DEFAULT_LIST_MIN_ENVS, B.DEFAULT_FUSED, B.DEFAULT_FUSED_ACQUIRE, B.DEFAULT_NOISE_SORTED = old

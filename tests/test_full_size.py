@@ -102,6 +102,15 @@ def _size(default_envs, default_steps=400):
     return int(os.environ.get("PCC_FULL_SIZE_ENVS", default_envs)), int(os.environ.get("PCC_FULL_SIZE_STEPS", default_steps))
 
 
+def _not_silently_reduced(n, steps, full_envs, full_steps=400):
+    """PCC_FULL_SIZE_ENVS / PCC_FULL_SIZE_STEPS shrink these tests (tests/test_variants.py runs a reduced config 3 through the
+    one-launch step).  A reduced run must not read as a full-size pass: after its comparison HAS passed it reports itself as
+    skipped, with the size it ran at, in the summary."""
+    if n < full_envs or steps < full_steps:
+        pytest.skip("REDUCED run: %d envs x %d steps matched the oracle (full size is %d x %d: not a full-size result)"
+                    % (n, steps, full_envs, full_steps))
+
+
 def test_config3_every_env_every_step_matches_the_oracle():
     """BASELINE.json configs[2] as bench.py runs it: 65 536 envs, randomized links, one sender, 400-step episode, then
     the auto-reset and 20 steps of the second episode."""
@@ -111,6 +120,7 @@ def test_config3_every_env_every_step_matches_the_oracle():
         # the point of the size: the largest envs of a whole episode are in the comparison
         assert info["max_packets_in_a_step"] >= 4096, info   # (the team items' threshold: the largest envs went that way)
     print("config 3 whole batch:", info)
+    _not_silently_reduced(n, steps, 65536)
 
 
 def test_config5_every_env_every_step_matches_the_oracle():
@@ -119,6 +129,7 @@ def test_config5_every_env_every_step_matches_the_oracle():
     n = min(n, 32768)
     info = _run_and_compare(n, 2, seed=4, n_steps=steps, extra_steps=10)
     print("config 5 whole batch:", info)
+    _not_silently_reduced(n, steps, 32768)
 
 
 @pytest.mark.parametrize("n_senders", [1, 2])

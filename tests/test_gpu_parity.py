@@ -917,6 +917,35 @@ def test_use_latency_noise_philox_batch_matches_oracle():
     env.close()
 
 
+def test_latency_noise_with_a_latency_below_the_clock_resolution_matches_oracle():
+    """A link latency so small that t + latency == t in double (allowed: the ranges only ask for latency > 0): a packet's arrival
+    at the return link then ties with its own SEND.  The heap-free noise path leaves such envs to the event loop (it would
+    count two draws fewer); every column equal to the oracle's event loop, next to envs with ordinary latencies."""
+    n_envs, n_steps, seed = 96, 24, 17
+    rs = np.random.RandomState(seed)
+    bw = rs.uniform(100, 500, n_envs)
+    # (these envs' clocks stay near 0.01-0.05 s -- an interval is half a round trip -- where an ulp is 2e-18 .. 7e-18)
+    dl = np.where(np.arange(n_envs) % 3 == 0, 1e-20, np.where(np.arange(n_envs) % 3 == 1, 4e-19, rs.uniform(0.05, 0.5, n_envs)))
+    queue = 1.0 + np.floor(np.exp(rs.uniform(0, 4, n_envs)))
+    loss = rs.uniform(0, 0.05, n_envs)
+    rate0 = rs.uniform(0.3, 1.5, n_envs) * bw
+    params = np.stack([bw, dl, queue, loss, rate0], 1)
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, record_steps=True, auto_reset=False, latency_noise=1.1,
+                                       link_params=[torch.tensor(c, dtype=torch.float64, device=DEV) for c in (bw, dl, queue, loss, rate0)])
+    env.reset()
+    acts = rs.uniform(-1, 1, (n_envs, n_steps))
+    rows = []
+    for t in range(n_steps):
+        o, r, dn, info = env.step(acts[:, t])
+        rows.append(info["steps"].clone())
+    env.check_flags()
+    steps = torch.stack(rows, 1).cpu().numpy()
+    ref = oracle.run_batch(acts, rng_mode=oracle.RNG_PHILOX, seed=seed, latency_noise=1.1, params=params)
+    assert np.array_equal(steps[..., :3], ref["steps"][..., :3])
+    assert np.array_equal(steps, ref["steps"])
+    env.close()
+
+
 @pytest.mark.parametrize("option", ["noise", "cwnd"])
 def test_engine_options_out_of_lockstep_match_oracle(option):
     """With the dormant engine options the auto-reset of envs that are out of lockstep stays the gated reset

@@ -13,8 +13,9 @@ Each variant library runs a slice of tests/test_gpu_parity.py in a subprocess (P
 Round 5 adds a variant of the LAUNCH STRUCTURE instead of the build: the one-launch step (PCC_TUNE_FUSED, csrc/pcc_fused.hip:
 an env's retire half runs as soon as its own send half is done, inside one launch, through per-XCD ready queues).  It is exact
 and measured slower at full size (profiles/r05_fused_experiments.json), so it is off by default -- and kept under test here:
-the whole parity file and the full-size whole-episode comparison of config 3 run with it switched on (tests/conftest.py reads
-PCC_TEST_FUSED), and the test asserts that the steps really went through the one launch."""
+a slice of the parity file and a reduced config-3 comparison run with it switched on (tests/conftest.py reads PCC_TEST_FUSED; the
+whole file and the whole episode did in round 5 -- the path is frozen since), and the test asserts that the steps really went
+through the one launch."""
 import os
 import subprocess
 import sys
@@ -61,14 +62,20 @@ def test_one_launch_step_reproduces_every_number():
         env.step(torch.zeros(8192, device="cuda:0"))
     assert env.fused_steps() == 4, env.fused_steps()   # (the step after the reset has no lists yet)
     env.close()
-    envv = dict(os.environ, PCC_TEST_FUSED="1")
-    for what in ([os.path.join(ROOT, "tests", "test_gpu_parity.py")],
+    # Frozen (round 6: measured slower, no new design): a SLICE of the parity file -- the reference's golden traces, Philox batches
+    # with ragged partitions, the auto-reset, two senders, the tuning knobs that force every send path -- and the config-3
+    # comparison at a quarter of the batch over the first 120 steps + the auto-reset's 20 (the whole file and the whole episode
+    # ran through the one launch in round 5: profiles/r05_gpu_tests_final.log; together they took 9 of the GPU suite's 20 minutes)
+    envv = dict(os.environ, PCC_TEST_FUSED="1", PCC_FULL_SIZE_ENVS="16384", PCC_FULL_SIZE_STEPS="120")
+    for what in ([os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
+                  "golden_vectors_bit_exact or philox_batches or auto_reset_and_second or two_sender_golden_bit_exact or send_paths_are_exact"],
                  [os.path.join(ROOT, "tests", "test_full_size.py"), "-k", "config3"]):
-        r = subprocess.run([sys.executable, "-m", "pytest"] + what + ["-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=envv,
+        r = subprocess.run([sys.executable, "-m", "pytest"] + what + ["-m", "gpu", "-x", "-q", "-rs", "-p", "no:cacheprovider"], cwd=ROOT, env=envv,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
         tail = r.stdout[-3000:]
         assert r.returncode == 0, "one-launch step, %s:\n%s" % (what, tail)
-        assert " passed" in tail and "no tests ran" not in tail, tail
+        # (the reduced full-size run reports itself as skipped-with-reason AFTER its comparison passed: tests/test_full_size.py)
+        assert (" passed" in tail or "matched the oracle" in tail) and "no tests ran" not in tail and " failed" not in tail, tail
 
 
 def test_latency_noise_by_sorting_by_the_event_loop_and_crossed():
