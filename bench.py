@@ -356,7 +356,7 @@ def scaling_in_n(pcc_rl_amd, torch, dev, sizes=(131072, 262144), max_steps=400):
                         "send_ms": sum(ev[k][0].elapsed_time(ev[k][1]) for k in ks) / len(ks),
                         "retire_ms": sum(ev[k][1].elapsed_time(ev[k][2]) for k in ks) / len(ks),
                         "packets_per_env_step": float((env.state("total_sent").sum() - sent0).item()) / (n * max_steps),
-                        "device_bytes": env.device_bytes() if hasattr(env, "device_bytes") else None})
+                        "device_bytes": int(env.device_bytes) if hasattr(env, "device_bytes") else None})
         except Exception as e:   # (supplementary: never in the way of the line)
             out.append({"envs": n, "error": "%s: %s" % (type(e).__name__, e)})
         finally:

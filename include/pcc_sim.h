@@ -180,8 +180,8 @@ int pcc_set_seed(pcc_sim_t *sim, uint64_t seed);
 enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
        PCC_TUNE_SEND_ENVS_PER_WAVE = 4 /* envs per light work item, 1..64 */,
        PCC_TUNE_HEAVY_PREDICT = 5 /* predicted packets per interval above which an env is a work item of
-                                    its own (wave path); default 512 (two senders: 1024), 0 = every env, >= 1e9 = none */,
-       PCC_TUNE_SEND_WAVES = 8 /* persistent wavefronts of the wave kernel per compute unit, 1..32 (default 12) */,
+                                    its own (wave path); default 480 (two senders: 640), 0 = every env, >= 1e9 = none */,
+       PCC_TUNE_SEND_WAVES = 8 /* persistent wavefronts of the wave kernel per compute unit, 1..32 (default 13) */,
        PCC_TUNE_TEAM_PREDICT = 9 /* predicted packets per interval above which an env is sent by a whole workgroup (four
                                     wavefronts, 1 024 packets per pass); default 4096, >= 1e9 = never (one sender only) */,
        PCC_TUNE_HEAVY_ITEM_PACKETS = 10 /* a wave-path work item holds as many envs of one class (1..8) as make up about this
@@ -239,6 +239,10 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     sorts and a scan (pcc-rl_amd/csrc/pcc_noise_sorted.hip) and the event loop takes only the envs whose events in
                                     flight do not fit its arrays; 2 = only its 256-event instance (the event loop takes the rest: what the
                                     tests use to cross the two); 0 = the event loop for every env.  Results do not depend on it. */,
+       PCC_TUNE_LIGHT_WGS = 34 /* send launch: light workgroups (4 wavefronts, an item each per round) per partition; their wavefronts take
+                                    further items when there are more items than wavefronts.  0 (default) = the worst case, an item per
+                                    wavefront.  32 = what stays resident next to 12 wave-path wavefronts per compute unit: measured no
+                                    faster (profiles/r06_knob_sweeps.json) */,
        PCC_TUNE_FUSED_DEBUG = 31 /* fused step, experiments: bit 0 (1) = an agent-scope release (buffer_wbl2) in front of every publication,
                                     bit 2 (4) = no retire work before every env is sent (the halves one after the other inside the launch);
                                     default 0 */ };

@@ -122,7 +122,10 @@ struct alignas(128) SndBlk {
     uint32_t cwnd;     // the reference's dormant USE_CWND option (ns:54): the sender's window in packets (ns:227: 25 at reset)
     uint32_t heap_n;   // event-loop build (event_engine): the sender's events in its heap = its packets in flight; bit 31: the array is
                        // in no particular order (pcc_noise_sorted.hip wrote it; the event loop makes a heap of it first)
-    uint32_t pad1;
+    uint32_t send_cost;   // what the wave path spent on this env's last interval: 100 MHz ticks (low 24 bits) | interval index << 24 -- written by the send
+                          // half (sender 0's block), read by the retire half when it files the env for the next send: an env whose packets
+                          // cost several times the usual (accept-chain passes: 90-150 ns per packet against ~25) is filed as if it had that many
+                          // times the packets, so that the send launch starts it early instead of late (speed only; round 6)
     // 112  retire half: where the last interval's four ring boundaries fell, as predictions of the next ones (speed only:
     // search_many verifies them) -- acknowledgements and loss reports per second of simulated time, and the packets that were
     // on the return hop at the interval's end (accepted / dropped ring)

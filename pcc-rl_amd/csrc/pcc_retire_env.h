@@ -1317,6 +1317,9 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
     }
     const double dur = now - start;  // ns:311-314
     double new_run_dur = run_dur, rate_sum = 0.0;
+    uint32_t cost_word = 0, sent_all = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) sent_all += sent[s];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         const int64_t k = sidx(D, s, i);
@@ -1341,6 +1344,7 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
             }
         }
         double min_lat = D.snd[k].min_lat;
+        if (s == 0) cost_word = D.snd[k].send_cost;
         const double ep_before = D.snd[k].ep_return;
         const double rate_now = NOISE ? noise_rate[s] : D.snd[k].rate;
         rate_sum += rate_now;
@@ -1505,7 +1509,20 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
 #undef PCC_TL_STAMP
     // prediction for the next MI's send half: packets ~ MI length x current rate (the next action
     // moves the rate by at most a few percent)
-    return (float)(new_run_dur * rate_sum);
+    float pred = (float)(new_run_dur * rate_sum);
+    // ... and for an env of the wave-path classes, what those packets COST the last time (SndBlk::send_cost): the send launch
+    // hands its items out largest class first, and an env whose passes stop every few packets (the accept chain: 90-150 ns per
+    // packet against ~25) is an item of 100-200 us -- filed by its packet count it starts 40-60 us into the launch and is the
+    // last thing running (config 5, profiles/r06_config5_timeline.json).  Filed as if it had as many times the packets as
+    // its cost per packet exceeds the usual, it starts first.  Speed only: every path is exact whatever the class.
+    if (!NOISE && pred >= (float)D.heavy_predict && sent_all != 0u && (cost_word >> 24) == ((steps + 2u) & 0xFFu)) {
+        const float ns_per_packet = (float)(cost_word & 0xFFFFFFu) * 10.0f / (float)sent_all;
+        const float factor = fminf(fmaxf(ns_per_packet * (1.0f / 32.0f), 1.0f), 8.0f);
+        // (one sender: not across the team threshold -- four wavefronts per env are for envs that ARE that large)
+        const float cap = (NS == 1 && D.team_predict < 1e9) ? fmaxf(pred, 0.98f * (float)D.team_predict) : 3.0e38f;
+        pred = fminf(pred * factor, cap);
+    }
+    return pred;
 }
 
 }  // namespace

@@ -61,7 +61,10 @@ __device__ __forceinline__ void light_body(const Dev &D, SendLds<NS> &lds, const
     const uint32_t n_items = listed ? rl_u32(incl, kClasses - 1) : (uint32_t)((D.n + E - 1) / E);
     for (uint32_t r0 = 0; r0 < n_items; r0 += n_waves) {
         const uint32_t b = (D.light_snake && (wv & 1u)) ? Q - 1u - b_wg : b_wg;
-        const uint32_t t = r0 + wv * Q + b;
+        // (more items than wavefronts -- the grid holds the workgroups that stay resident, pcc_sim.hip: the second round's items,
+        // the shortest classes, go out in the opposite order: the wavefront that had the longest item gets the shortest)
+        const uint32_t w_rank = wv * Q + b;
+        const uint32_t t = r0 + (((r0 / n_waves) & 1u) ? n_waves - 1u - w_rank : w_rank);
         if (t >= n_items) continue;
         int64_t i;
         bool has;

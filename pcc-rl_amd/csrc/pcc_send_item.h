@@ -146,7 +146,7 @@ __device__ __forceinline__ void store_env(const Dev &D, const int64_t i, LaneEnv
 template <int NS>
 __device__ __forceinline__ void timeline_record(const Dev &D, const uint32_t lane, const uint32_t tl_slot, const LaneEnv<NS> &E,
                                                 uint64_t tl0, uint64_t tl1, uint64_t heavy_envs, uint64_t heavy_pk,
-                                                uint64_t closed, uint64_t other, uint64_t last_env) {
+                                                uint64_t closed, uint64_t other, uint64_t last_env, uint64_t cycles = 0) {
     uint64_t sum = E.live ? E.sent[0] : 0, mx = sum, hp = heavy_pk;
     for (int o = 32; o; o >>= 1) {
         sum += __shfl_xor(sum, o);
@@ -158,7 +158,7 @@ __device__ __forceinline__ void timeline_record(const Dev &D, const uint32_t lan
     if (lane == 0 && tl_slot != 0xFFFFFFFFu) {
         uint64_t *w = D.timeline + (int64_t)tl_slot * 8;
         w[0] = tl0; w[1] = tl1; w[2] = wall_clock64(); w[3] = heavy_envs | (last_env << 16); w[4] = sum; w[5] = mx; w[6] = hp;
-        w[7] = live_n | (closed << 8) | (other << 24);
+        w[7] = live_n | (closed << 8) | (other << 24) | (cycles << 32);   // (cycles: light items only, whose pass counts are 0)
     }
 }
 
@@ -197,6 +197,40 @@ __device__ __forceinline__ void light_packet(LightState &S, const bool lost, con
     S.a4 += 16u - inc;
     S.t = t + gap;                            // ns:161
 }
+// ... and for two senders on the shared link: the packet of the (time, sender id) merge, the sender a select (equal times: sender
+// 0 first, the heap's order; ns:42-43).  Ring indices times 16, per sender.
+struct Light2State {
+    double q, tu, nsend[2];
+    uint32_t a4[2], d4[2], sent[2];
+};
+__device__ __forceinline__ void light_packet2(Light2State &S, const bool lost, const double dl, const double maxq, const double ebw,
+                                              const double gap0, const double gap1, char *base0, char *base1, const uint32_t mask_b0,
+                                              const uint32_t mask_b1, const uint32_t dmask_b0, const uint32_t dmask_b1, const uint32_t cap_b0,
+                                              const uint32_t cap_b1) {
+    const bool s1 = S.nsend[1] < S.nsend[0];
+    const double t = s1 ? S.nsend[1] : S.nsend[0];
+    const double qcur = max0(S.q - (t - S.tu));
+    const double grown = qcur + ebw;
+    const double lat0 = dl + qcur;            // ns:170
+    const double lim = __hiloint2double(lost ? (int)0xBFF00000u : __double2hiint(maxq), __double2loint(maxq));
+    const bool dropped = grown > lim;
+    const double keep = lost ? S.q : qcur;
+    S.q = dropped ? keep : grown;
+    S.tu = lost ? S.tu : t;
+    double2 rec;
+    rec.x = t + lat0;                         // ns:174
+    rec.y = lat0;                             // ns:173
+    const uint32_t a4 = s1 ? S.a4[1] : S.a4[0], d4 = s1 ? S.d4[1] : S.d4[0];
+    const uint32_t off_a = a4 & (s1 ? mask_b1 : mask_b0), off_d = (s1 ? cap_b1 : cap_b0) + (d4 & (s1 ? dmask_b1 : dmask_b0));
+    st_rec(reinterpret_cast<double2 *>((s1 ? base1 : base0) + (dropped ? off_d : off_a)), rec);
+    const uint32_t inc_d = dropped ? 16u : 0u, inc_a = 16u - inc_d;
+    S.a4[0] += s1 ? 0u : inc_a; S.a4[1] += s1 ? inc_a : 0u;
+    S.d4[0] += s1 ? 0u : inc_d; S.d4[1] += s1 ? inc_d : 0u;
+    S.sent[0] += s1 ? 0u : 1u; S.sent[1] += s1 ? 1u : 0u;            // ns:260-262
+    const double next = t + (s1 ? gap1 : gap0);                     // ns:161
+    S.nsend[0] = s1 ? S.nsend[0] : next;
+    S.nsend[1] = s1 ? next : S.nsend[1];
+}
 #ifndef PCC_LIGHT_BLOCKS
 #define PCC_LIGHT_BLOCKS 1
 #endif
@@ -221,8 +255,11 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
     LaneEnv<NS> E = load_env<NS, TRACE, 1>(D, lane, i, in_range, true, warm, warm_mi, actions, actions_f64, 0u);
     if (!__ballot(E.live)) return 0ull;
     const uint64_t tl0 = prof_on(D) ? wall_clock64() : 0;
+    const uint64_t cy0 = prof_on(D) ? __builtin_readcyclecounter() : 0;   // (shader clock: the item's cycles go into the record's last word)
     const int64_t ii = E.live ? i : D.n;   // (see load_env)
     bool active = false;
+    uint64_t tl_r1 = 0;
+    uint32_t tl_trip = 0;   // (profile build: trips of the unchecked-block loop so far, all rounds)
     if (NS == 1) {
         const double dl = E.dl, lr = E.lr, maxq = E.maxq, ebw = E.ebw, end = E.end;
         const uint32_t thr = E.thr, episode = E.episode, mi = E.mi, gid = E.gid;
@@ -323,6 +360,12 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
 #pragma unroll
                         for (int b = 0; b < kLightBlocks; b++) light_philox(D, blk + b, mi, episode, gid, w[b]);
                         for (; safe4 >= (uint32_t)kLightBlocks; safe4 -= kLightBlocks) {
+                            if (prof_on(D)) {   // profile build: a stamp every 8 trips (32 packets) of this wavefront, 16 per item (tools/send_timeline.py)
+                                if ((tl_trip & 7u) == 0u && (tl_trip >> 3) < 16u && tl_slot < 4096u && D.n >= 32768 &&
+                                    lane == (uint32_t)__ffsll((unsigned long long)__ballot(true)) - 1u)
+                                    D.timeline[((int64_t)8192 + 2 * (int64_t)tl_slot) * 8 + (tl_trip >> 3)] = wall_clock64();
+                                tl_trip++;
+                            }
                             uint32_t wn[kLightBlocks][4];
 #pragma unroll
                             for (int b = 0; b < kLightBlocks; b++) light_philox(D, blk + kLightBlocks + b, mi, episode, gid, wn[b]);
@@ -350,6 +393,7 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
                         active = S.t < end;
                     }
                     const uint64_t am = __ballot(active);
+                    if (prof_on(D) && tl_r1 == 0) tl_r1 = wall_clock64();   // (profile build: when the first round of round_packets ended)
                     if (!am || (uint32_t)__popcll(am) <= D.takeover_lanes) break;
                 }
                 q = S.q; tu = S.tu; t = S.t;
@@ -404,32 +448,53 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
         for (;;) {
             if (active) {
                 if (!TRACE) {
-                    // lockstep blocks of four packets of the merged stream; the sender of a packet
-                    // is a select, not a branch, so lanes with different interleavings stay together
-                    for (uint32_t budget4 = D.round_packets / 4;
-                         budget4 && (nsend[NS - 1] < nsend[0] ? nsend[NS - 1] : nsend[0]) < end; budget4--) {
-                        uint32_t w[4];
-                        philox4x32_10(blk, mi, episode, gid, D.key0, D.key1, w);
+                    // lockstep blocks of four packets of the merged stream; the sender of a packet is a select, not a branch, so
+                    // lanes with different interleavings stay together.  Like the one-sender rounds (round 6): the packet is
+                    // branch-free (light_packet2), the Philox rounds of the NEXT block are in the same basic block, and the blocks
+                    // whose packets are certainly before `end` run without the exit test -- sender s has at least
+                    // (end - nsend[s]) / gap[s] - 2 more packets before `end`, and the first c0 + c1 packets of the merge are then
+                    // all before `end` (they are the c0 + c1 earliest of at least that many).
+                    Light2State S;
+                    S.q = q; S.tu = tu;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        const int s = s2 < NS ? s2 : 0;
+                        S.nsend[s2] = nsend[s]; S.a4[s2] = ta[s] << 4; S.d4[s2] = td[s] << 4; S.sent[s2] = sent[s];
+                    }
+                    const uint32_t a4_0[2] = {S.a4[0], S.a4[1]}, d4_0[2] = {S.d4[0], S.d4[1]};
+                    const double ah0 = (end - S.nsend[0]) / gap[0] - 2.0, ah1 = (end - S.nsend[1]) / gap[NS - 1] - 2.0;
+                    const double ahead = (ah0 > 0.0 ? floor(ah0) : 0.0) + (ah1 > 0.0 ? floor(ah1) : 0.0);
+                    uint32_t safe4 = ahead >= 4.0 ? (uint32_t)fmin(ahead, (double)D.round_packets) >> 2 : 0u;
+                    uint32_t budget4 = D.round_packets / 4 - safe4;
+                    uint32_t w[4];
+                    light_philox(D, blk, mi, episode, gid, w);
+                    for (; safe4; safe4--) {
+                        uint32_t wn[4];
+                        light_philox(D, blk + 1u, mi, episode, gid, wn);
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            light_packet2(S, always || w[k] < thr, dl, maxq, ebw, gap[0], gap[NS - 1], bases[0], bases[NS - 1], mask_bs[0], mask_bs[NS - 1],
+                                          dmask_bs[0], dmask_bs[NS - 1], cap_bs[0], cap_bs[NS - 1]);
                         blk++;
 #pragma unroll
+                        for (int k = 0; k < 4; k++) w[k] = wn[k];
+                    }
+                    for (; budget4 && (S.nsend[1] < S.nsend[0] ? S.nsend[1] : S.nsend[0]) < end; budget4--) {
+#pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const bool s1 = nsend[NS - 1] < nsend[0];  // equal times: sender 0 first (heap order)
-                            const double t = s1 ? nsend[NS - 1] : nsend[0];
-                            if (k > 0 && !(t < end)) break;
-                            bool dropped;
-                            const double2 rec = link_send(t, always || w[k] < thr, dl, maxq, ebw, q, tu, dropped);
-                            const uint32_t a_s = s1 ? ta[NS - 1] : ta[0], d_s = s1 ? td[NS - 1] : td[0];
-                            const uint32_t off = dropped ? (s1 ? cap_bs[NS - 1] : cap_bs[0]) + ((d_s << 4) & (s1 ? dmask_bs[NS - 1] : dmask_bs[0]))
-                                                         : ((a_s << 4) & (s1 ? mask_bs[NS - 1] : mask_bs[0]));
-                            st_rec(reinterpret_cast<double2 *>((s1 ? bases[NS - 1] : bases[0]) + off), rec);
-                            const uint32_t acc = dropped ? 0u : 1u, drp = dropped ? 1u : 0u;
-                            if (s1) {
-                                ta[NS - 1] += acc; td[NS - 1] += drp; sent[NS - 1]++;  // ns:260-262
-                                nsend[NS - 1] = t + gap[NS - 1];                       // ns:161
-                            } else {
-                                ta[0] += acc; td[0] += drp; sent[0]++;
-                                nsend[0] = t + gap[0];
-                            }
+                            if (k > 0 && !((S.nsend[1] < S.nsend[0] ? S.nsend[1] : S.nsend[0]) < end)) break;
+                            light_packet2(S, always || w[k] < thr, dl, maxq, ebw, gap[0], gap[NS - 1], bases[0], bases[NS - 1], mask_bs[0], mask_bs[NS - 1],
+                                          dmask_bs[0], dmask_bs[NS - 1], cap_bs[0], cap_bs[NS - 1]);
+                        }
+                        blk++;
+                        light_philox(D, blk, mi, episode, gid, w);
+                    }
+                    q = S.q; tu = S.tu;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        if (s2 < NS) {
+                            nsend[s2 < NS ? s2 : 0] = S.nsend[s2]; sent[s2 < NS ? s2 : 0] = S.sent[s2];
+                            ta[s2 < NS ? s2 : 0] += (S.a4[s2] - a4_0[s2]) >> 4; td[s2 < NS ? s2 : 0] += (S.d4[s2] - d4_0[s2]) >> 4;
                         }
                     }
                 } else {
@@ -468,7 +533,9 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
         for (int s = 0; s < NS; s++) { E.nsend[s] = nsend[s]; E.ta[s] = ta[s]; E.td[s] = td[s]; E.sent[s] = sent[s]; }
         E.q = q; E.tu = tu;
     }
-    if (prof_on(D)) timeline_record<NS>(D, lane, tl_slot, E, tl0, wall_clock64(), 0, 0, 0, 0, 0);
+    // (profile build: word 6 of a light item's record = ticks from its start to the end of its first round)
+    if (prof_on(D)) timeline_record<NS>(D, lane, tl_slot, E, tl0, wall_clock64(), 0, lane == 0 && tl_r1 ? tl_r1 - tl0 : 0, 0, 0, 0,
+                                        __builtin_readcyclecounter() - cy0);
     if (E.live) store_env<NS>(D, i, E);
     uint32_t pk = 0;
 #pragma unroll
@@ -492,6 +559,7 @@ struct EnvSlot {
     int64_t i;
     uint32_t cap[NS], ta[NS], td[NS], ha[NS], hd[NS], sent[NS];
     uint32_t thr, episode, mi, gid, flags, bits;  // bits: 1 = always lost, 2 = the interval is not empty, 4 = live
+    uint32_t cost0, pad;                          // low word of the clock when the wave path took the env (SndBlk::send_cost): parked here, not in a register
 };
 
 __device__ __forceinline__ double uni_f64(double v) {  // a value every lane holds alike -> scalar registers
@@ -563,6 +631,7 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
             uint32_t before = 0;
 #pragma unroll
             for (int s = 0; s < NS; s++) before += sent_new[s];
+            if (lane == 0) slots[k].cost0 = (uint32_t)wall_clock64();   // (SndBlk::send_cost; const_cast-free: the slot is this wavefront's)
             if (bits & 2u) {
                 if constexpr (NS == 1) {
                     SendState st;
@@ -605,6 +674,10 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
             // ---- the env's state back to memory (one lane: every value is wave-uniform)
             if (lane == 0 && writer) {
                 D.env[ie].q = q_new; D.env[ie].tu = tu_new;
+                if (fresh) {   // (a whole interval by the wave path: what it cost, for the retire half's filing)
+                    const uint32_t ticks = (uint32_t)wall_clock64() - S.cost0;   // (mod 2^32: 43 s)
+                    D.snd[sidx(D, 0, ie)].send_cost = (ticks < 0xFFFFFFu ? ticks : 0xFFFFFFu) | (S.mi << 24);
+                }
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
                     // never silent: more packets in flight than a ring holds means records were overwritten

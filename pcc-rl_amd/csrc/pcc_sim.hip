@@ -53,6 +53,7 @@ struct pcc_sim {
     size_t list_bytes;
     void *noise_blob;   // heap + RTT samples of the latency-noise option (allocated when it is switched on)
     void *noise_out_blob;  // ... and the per-env results of the heap-free interval (pcc_noise_sorted.hip)
+    uint32_t light_wgs; // PCC_TUNE_LIGHT_WGS: light workgroups per partition of the send launch (0 = what stays resident)
     int noise_sorted;   // PCC_TUNE_NOISE_SORTED: 1 = latency noise alone on one sender runs its intervals by sorting, 2 = only the small instance, 0 = the event loop
     size_t noise_bytes;
     uint32_t ring_capacity;
@@ -167,7 +168,7 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
     // (the classes from light_half_predict up go E / 2 envs to an item: the worst case is all of them)
     const int64_t E_min = d.light_half_predict < 1e9f && E >= 2 ? E / 2 : E;
     const int64_t light_items_part = ((int64_t)d.part_envs + E_min - 1) / E_min + kClasses;
-    const unsigned light_grid = (unsigned)(P * ((light_items_part + 3) / 4));
+    const unsigned worst_light_grid = (unsigned)(P * ((light_items_part + 3) / 4));
     // restart items can only be in lists that a retire launch with `restart` filed
     const bool rs = sim->read_has_restarts;
     const bool wave = !d.use_cwnd && d.heavy_predict < 1e9;  // (USE_CWND sends every env lane-serially: no wave-path classes)
@@ -175,6 +176,12 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
     int64_t waves = (int64_t)sim->cu_count * d.send_waves;
     if (waves > d.n) waves = d.n;
     const unsigned wave_grid = wave ? (unsigned)(P * (((waves + 3) / 4 + P - 1) / P)) : 0u;
+    // Light workgroups: an item per wavefront in the worst case.  (Round 6 measured the alternative -- only as many as stay
+    // resident next to the wave-path workgroups, their wavefronts taking a second item, PCC_TUNE_LIGHT_WGS: the ones that wait
+    // for a slot start 40-60 us into the launch -- and it is no faster: 0.0974 against 0.0961 ms, settings alternating every
+    // step on one handle, profiles/r06_knob_sweeps.json.)
+    unsigned light_grid = worst_light_grid;
+    if (wave && sim->light_wgs && (int64_t)sim->light_wgs * P < (int64_t)light_grid) light_grid = (unsigned)((int64_t)sim->light_wgs * P);
     const unsigned restart_grid = (unsigned)(sim->cu_count < (d.n + 3) / 4 ? sim->cu_count : (d.n + 3) / 4);
     if (rs && d.shadows) {
         // with shadows nearly every restart is a swap inside the retire half: the restart list holds only the envs whose shadow
@@ -494,13 +501,14 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     d.max_steps = 400;      // ns:41
     d.round_packets = 256;
     d.takeover_lanes = 1;  // the last lane of a light item goes to the wave path (more lanes handed over measured slower)
-    d.send_waves = 12;  // persistent wavefronts of the wave kernel per compute unit (beside them: the light kernel's items)
+    d.send_waves = 13;  // persistent wavefronts of the wave path per compute unit (beside them: the light items).  12 until round 6; re-swept with
+                        // the settings alternating every step (tools/ab_step.py, profiles/r06_knob_sweeps.json): 12 / 13 / 14 / 15 = 0.0915 / 0.0906 / 0.0924 / 0.115 ms
     d.send_envs_per_wave = 64;
     // (two senders: the lane rounds cost about the same per packet as with one, the wave passes more -- 64 positions per pass)
     // (measured on one handle each, profiles/r04_experiments.json -- heavy_predict / heavy_item_packets: config 5
     // 1024 / 2048 -> 0.252 ms per send launch, 640-768 / 768-1024 -> 0.219-0.223; config 3 512 / 2048 -> 0.0988,
     // 384 / 1024 -> 0.0942, 320 / 768 -> 0.105: the longest light items are the launch's critical path down to ~384)
-    d.heavy_predict = n_senders == 2 ? 640.0 : 384.0;
+    d.heavy_predict = n_senders == 2 ? 640.0 : 480.0;   // (one sender: 384 until round 6's lane rounds -- cheaper per packet, so more classes stay light: 384 / 448 / 512 / 576 = 0.0984 / 0.0915 / 0.0920 / 0.1029 ms)
     d.team_predict = 4096.0;
     d.heavy_item_packets = 1024.0f;
     // (the wide classes are cut by COUNT in the end: the grid has room for retire_grid_frac of the envs at 16 lanes, the
@@ -789,6 +797,10 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
         case PCC_TUNE_RETIRE_WIDE_PREDICT:
             if (!(value >= 0.0)) return fail(PCC_EINVAL, "retire_wide_predict out of range");
             sim->d.retire_wide_predict = value >= 1e9 ? 1e9f : (float)value;
+            return PCC_OK;
+        case PCC_TUNE_LIGHT_WGS:
+            if (!(value >= 0.0 && value <= 65536.0)) return fail(PCC_EINVAL, "light_wgs out of range");
+            sim->light_wgs = (uint32_t)value;
             return PCC_OK;
         case PCC_TUNE_NOISE_SORTED:
             if (value != 0.0 && value != 1.0 && value != 2.0) return fail(PCC_EINVAL, "noise_sorted must be 0, 1 or 2");

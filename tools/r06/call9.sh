@@ -1,0 +1,15 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r06_c9
+mkdir -p $O
+cd $R
+PCC_DEBUG_TIMELINE=1 PCC_SIM_LIBRARY=$R/pcc-rl_amd/lib/libpcc_sim_prof.so timeout 300 python tools/send_timeline.py > $O/tl.json 2> $O/tl.err
+python - <<'PY'
+import json, os
+d = json.load(open(os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/r06_c9/tl.json"))
+for s in d:
+    if s["step"] in (100, 300):
+        print("step", s["step"], "span", s["span_us"], "light running", s["light_items_running_at_us"], "wave running", s["wave_items_running_at_us"])
+        for w in s["slowest"]:
+            print("   ", w)
+PY

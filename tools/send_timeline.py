@@ -33,6 +33,21 @@ for t in range(400):
     if t in sample:
         raw = env.debug_timeline().astype(np.int64)
         tl = raw[:2 * N]             # item slots: light items from 0 (a range per partition), wave-path items from N (ditto), team items behind them
+        fine = None
+        if N >= 32768:
+            # the light items' own progress (profile build): a stamp every 32 packets of the wavefront in slots 8192 + 2 s, 8193 + 2 s
+            cand = np.nonzero((tl[:4096, 0] > 0) & (tl[:4096, 3] == 0))[0]
+            if len(cand):
+                t00 = tl[tl[:, 0] > 0][:, 0].min()
+                last = cand[np.argsort(-tl[cand, 2])[:4]]
+                fine = []
+                for sl in last:
+                    st_ = raw[8192 + 2 * sl: 8194 + 2 * sl].reshape(-1)[:16].astype(np.int64)
+                    st_ = st_[(st_ >= tl[sl, 0]) & (st_ <= tl[sl, 2])]     # (stale stamps of earlier steps fall outside the item's span)
+                    us = [round(float(v - t00) / 100.0, 2) for v in st_]
+                    fine.append({"start_us": round(float(tl[sl, 0] - t00) / 100.0, 2), "finish_us": round(float(tl[sl, 2] - t00) / 100.0, 2),
+                                 "largest_env": int(tl[sl, 5]), "stamp_us_every_32_packets": us,
+                                 "ns_per_iteration_by_stretch": [round(1e3 * (us[k + 1] - us[k]) / 32.0) for k in range(len(us) - 1)]})
         tl = tl[tl[:, 0] > 0]        # (the retire launch clears the slots: what is there belongs to this send launch)
         t0 = tl[:, 0].min()
         start, mid, fin = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0   # us
@@ -42,14 +57,21 @@ for t in range(400):
         rec = {"step": t, "waves": int(len(tl)), "span_us": float(fin.max()),
                "start_us_p50_p90_p99_max": pct(start),
                "rounds_end_us": pct(mid), "finish_us": pct(fin),
-               "packets_total": int(tl[:, 4].sum()), "wave_path_packets": int(tl[:, 6].sum()),
+               "packets_total": int(tl[:, 4].sum()), "wave_path_packets": int(tl[tl[:, 3] > 0, 6].sum()),
+               # light items still running at 10-us marks of the launch (how many lane-round wavefronts share the machine in the tail)
+               "light_items_running_at_us": {str(m): int(((tl[:, 3] == 0) & (start <= m) & (fin > m)).sum()) for m in range(10, 100, 10)},
+               "wave_items_running_at_us": {str(m): int(((tl[:, 3] > 0) & (start <= m) & (fin > m)).sum()) for m in range(10, 100, 10)},
                "wave_path_envs": int(tl[:, 3].sum()),
                "busy_wave_us_total": float((fin - start).sum()),
                "slowest": [{"start": float(start[i]), "rounds_end": float(mid[i]), "finish": float(fin[i]),
                             "wave_path_envs": int(tl[i, 3]), "packets": int(tl[i, 4]), "largest_env": int(tl[i, 5]),
-                            "wave_path_packets": int(tl[i, 6]), "live": int(tl[i, 7])} for i in order]}
+                            "wave_path_packets": int(tl[i, 6]) if tl[i, 3] > 0 else 0,
+                            "first_round_us": float(tl[i, 6]) / 100.0 if tl[i, 3] == 0 else None,   # light items: start -> end of the first round (round_packets iterations)
+                            "shader_clock_ghz": float((tl[i, 7] >> 32) / max(1e-9, (mid[i] - start[i]) * 1e3)) if tl[i, 3] == 0 else None,   # light items: cycles / wall time
+                            "live": int(tl[i, 7] & 0xFF)} for i in order]}
         if os.environ.get("PCC_TL_RAW") and t in (100, 300):
             np.save(os.path.join(os.environ["PCC_TL_RAW"], "items_step%d.npy" % t), tl)
+        rec["longest_light_items_progress"] = fine
         hv = tl[:, 3] > 0
         lt_ = ~hv
         dur = fin - start
