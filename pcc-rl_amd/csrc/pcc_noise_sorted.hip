@@ -7,7 +7,7 @@
 // in EVENT order -- a SEND takes two draws (noise, loss), an arrival at the return link (hop 1) one, an arrival at the sender
 // (hop 2) none -- so the draw a packet gets depends on how the events of all packets interleave, and they overtake each other.
 // What is parallel all the same (restated and checked bit for bit against the oracle's event loop on the CPU:
-// tests/proto_noise_sorting.py, tests/test_noise_formulation.py):
+// tests/models/noise_sorting_model.py, tests/test_noise_formulation.py):
 //   * SEND times depend on nothing drawn: t_0 = the pending SEND, t_{k+1} = t_k + 1/rate.
 //   * The draw index of an event inside the interval = 2 x (SENDs before it) + (hop-1 arrivals before it).
 //   * A hop-1 arrival is at least dl behind its SEND (noise factor >= 1, queue delay >= 0): the arrivals before SEND k belong

@@ -1,4 +1,4 @@
-"""tests/proto_noise_sorting.py for ONE OR TWO senders on the link (the reference's two-sender envs share one queue and one
+"""tests/models/noise_sorting_model.py for ONE OR TWO senders on the link (the reference's two-sender envs share one queue and one
 random stream): the same restatement of a monitor interval with USE_LATENCY_NOISE -- counts, two sorts and a scan, no heap --
 checked bit for bit against the oracle's event loop (tests/test_noise_formulation.py).  TEST INFRASTRUCTURE: the design
 study for the two-sender version of pcc-rl_amd/csrc/pcc_noise_sorted.hip, which is not built (two senders with latency noise

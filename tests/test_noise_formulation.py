@@ -1,10 +1,14 @@
-"""The heap-free restatement of USE_LATENCY_NOISE (tests/proto_noise_sorting.py: counts, two sorts and a scan per interval)
+"""The heap-free restatement of USE_LATENCY_NOISE (tests/models/noise_sorting_model.py, the numpy design study of pcc_noise_sorted.hip: counts, two sorts and a scan per interval)
 against the oracle's event loop: every observation, reward, count and clock bit for bit.  CPU only."""
 import numpy as np
 import pytest
 
 from oracle.pcc_oracle_py import PyOracleEnv
-from tests.proto_noise_sorting import SortedNoiseEnv
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "models"))
+from noise_sorting_model import SortedNoiseEnv   # noqa: E402
 
 
 def run_pair(seed, n_steps, scale=1.0, fixed=None):
@@ -39,8 +43,8 @@ def test_lossy_shallow_queue_matches():
     run_pair(3, 100, fixed=(150.0, 0.08, 2, 0.04, 200.0))
 
 
-# ---- one or two senders on the link (tests/proto_noise_sorting2.py)
-from tests.proto_noise_sorting2 import SortedNoiseEnvS
+# ---- one or two senders on the link (tests/models/noise_sorting2_model.py)
+from noise_sorting2_model import SortedNoiseEnvS   # noqa: E402
 
 
 def run_pair_s(seed, n_steps, n_senders, scale=1.0, fixed=None):

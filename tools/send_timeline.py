@@ -25,6 +25,8 @@ for k, v in os.environ.items():
         env.set_tuning(**{k[9:].lower(): float(v)})
 gen = torch.Generator(device=dev).manual_seed(1234)
 acts = torch.rand((400, N, S), generator=gen, device=dev) * 2 - 1   # one action vector per episode step, like bench.py
+if os.environ.get("PCC_TL_ACTIONS") == "randn":   # what an untrained Gaussian policy sends (bench.py: policy_in_loop)
+    acts = torch.randn((400, N, S), generator=gen, device=dev)
 env.reset()
 out = []
 sample = {2, 10, 30, 60, 100, 150, 200, 250, 300, 350, 398}
@@ -38,7 +40,7 @@ for t in range(400):
             # the light items' own progress (profile build): a stamp every 32 packets of the wavefront in slots 8192 + 2 s, 8193 + 2 s
             cand = np.nonzero((tl[:4096, 0] > 0) & (tl[:4096, 3] == 0))[0]
             if len(cand):
-                t00 = tl[tl[:, 0] > 0][:, 0].min()
+                t00 = min(tl[:8192][tl[:8192, 0] > 0][:, 0].min(), tl[N:][tl[N:, 0] > 0][:, 0].min() if (tl[N:, 0] > 0).any() else 1 << 62)
                 last = cand[np.argsort(-tl[cand, 2])[:4]]
                 fine = []
                 for sl in last:
@@ -48,6 +50,9 @@ for t in range(400):
                     fine.append({"start_us": round(float(tl[sl, 0] - t00) / 100.0, 2), "finish_us": round(float(tl[sl, 2] - t00) / 100.0, 2),
                                  "largest_env": int(tl[sl, 5]), "stamp_us_every_32_packets": us,
                                  "ns_per_iteration_by_stretch": [round(1e3 * (us[k + 1] - us[k]) / 32.0) for k in range(len(us) - 1)]})
+        if N >= 32768:
+            tl = tl.copy()
+            tl[8192:16384] = 0       # (the progress stamps above are not items)
         tl = tl[tl[:, 0] > 0]        # (the retire launch clears the slots: what is there belongs to this send launch)
         t0 = tl[:, 0].min()
         start, mid, fin = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0   # us
