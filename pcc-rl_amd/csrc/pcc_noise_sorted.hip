@@ -466,6 +466,471 @@ __global__ __launch_bounds__(T) void noise_sorted_kernel(Dev D, int warm, uint32
     }
 }
 
+
+// =====================================================================================================================
+// Two senders on the link (round 6).  The reference orders events as (time, sender, 'A' < 'S', hop, latency, dropped) -- the
+// sender id comes BEFORE the kind of event -- and both senders' events consume ONE draw stream, so (restated in numpy and
+// checked bit for bit against the oracle's event loop: tests/models/noise_sorting2_model.py, tests/test_noise_formulation.py):
+//   * the SENDs of both senders are one sequence merged by (time, sender); the link's queue recurrence scans it in that order;
+//   * a hop-1 arrival (a, s') comes before the SEND (t, s) iff (a, s') <= (t, s) lexicographically; a SEND (t, s) before the
+//     arrival (a, s') iff (t, s) < (a, s');
+//   * the draw index of an event = 2 x (SENDs of either sender before it) + (hop-1 arrivals of either sender before it);
+//   * hop-1 and hop-2 arrivals sort by (time, sender, latency, dropped); acknowledgements and RTT lists are per sender, in
+//     that order; blocks of SENDs are cut by TIME: everything sent less than 0.9 dl after the block's first SEND (an arrival
+//     is at least dl behind its SEND: none of the block's own can come before a SEND of the block).
+// One instance, no sub-intervals: an env whose due events or SENDs do not fit the arrays, or whose arrays in memory could
+// fill up, is left to the event loop of the retire launch (NoiseOut::seq says who ran the interval); results do not depend on it.
+// Events in flight stay in the senders' own arrays (Dev::noise_heap [S][N]), loose (bit 31 of SndBlk::heap_n).
+// NoiseOut: entry i = sender 0's counts and the env's clock / link state / flags / seq; entry N + i = sender 1's counts.
+// =====================================================================================================================
+__device__ __forceinline__ bool ev_less2(double ax, uint32_t as, double ay, double bx, uint32_t bs, double by) {
+    if (ax != bx) return ax < bx;
+    if (as != bs) return as < bs;
+    const double la = fabs(ay), lb = fabs(by);
+    if (la != lb) return la < lb;
+    return !sign_of(ay) && sign_of(by);   // dropped: False < True
+}
+// (x, s, y)[0, n) into the order of ev_less2 by the workgroup's T threads (bitonic over the next power of two, +inf padding)
+template <int T>
+__device__ void sort_events2(double *x, uint32_t *sd, double *y, uint32_t n, uint32_t tid) {
+    bool bad = false;
+    for (uint32_t j = tid; j + 1u < n; j += T) bad |= ev_less2(x[j + 1u], sd[j + 1u], y[j + 1u], x[j], sd[j], y[j]);
+    if (!__syncthreads_or(bad ? 1 : 0)) return;
+    uint32_t P = 2u;
+    while (P < n) P <<= 1;
+    for (uint32_t j = n + tid; j < P; j += T) { x[j] = INFINITY; sd[j] = 0u; y[j] = 0.0; }
+    __syncthreads();
+    for (uint32_t k = 2u; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+            for (uint32_t idx = tid; idx < (P >> 1); idx += T) {
+                const uint32_t lo = ((idx & ~(j - 1u)) << 1) | (idx & (j - 1u)), hi = lo | j;
+                const bool up = (lo & k) == 0u;
+                const double ax = x[lo], ay = y[lo], bx = x[hi], by = y[hi];
+                const uint32_t as = sd[lo], bs = sd[hi];
+                if (ev_less2(bx, bs, by, ax, as, ay) == up) { x[lo] = bx; y[lo] = by; sd[lo] = bs; x[hi] = ax; y[hi] = ay; sd[hi] = as; }
+            }
+            __syncthreads();
+        }
+    }
+}
+// (time, sender) pairs by (time, sender)
+template <int T>
+__device__ void sort_pairs(double *x, uint32_t *sd, uint32_t n, uint32_t tid) {
+    uint32_t P = 2u;
+    while (P < n) P <<= 1;
+    for (uint32_t j = n + tid; j < P; j += T) { x[j] = INFINITY; sd[j] = 0u; }
+    __syncthreads();
+    for (uint32_t k = 2u; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+            for (uint32_t idx = tid; idx < (P >> 1); idx += T) {
+                const uint32_t lo = ((idx & ~(j - 1u)) << 1) | (idx & (j - 1u)), hi = lo | j;
+                const bool up = (lo & k) == 0u;
+                const double a = x[lo], b = x[hi];
+                const uint32_t as = sd[lo], bs = sd[hi];
+                const bool b_first = b < a || (b == a && bs < as);
+                if (b_first == up) { x[lo] = b; sd[lo] = bs; x[hi] = a; sd[hi] = as; }
+            }
+            __syncthreads();
+        }
+    }
+}
+// how many of the (time, sender)-sorted pairs are < (v, vs) / <= (v, vs), lexicographically
+__device__ __forceinline__ uint32_t count_pairs_lt(const double *x, const uint32_t *sd, uint32_t n, double v, uint32_t vs) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (x[m] < v || (x[m] == v && sd[m] < vs)) lo = m + 1u; else hi = m; }
+    return lo;
+}
+__device__ __forceinline__ uint32_t count_pairs_le(const double *x, const uint32_t *sd, uint32_t n, double v, uint32_t vs) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (x[m] < v || (x[m] == v && sd[m] <= vs)) lo = m + 1u; else hi = m; }
+    return lo;
+}
+
+// sender `sdr`'s events that are due by `bound` from its array H[0, n) to LDS, tagged; the others move up in place (one wavefront)
+__device__ __forceinline__ uint32_t take_due2(double2 *H, uint32_t n, double bound, uint32_t sdr, double *x1, uint32_t *s1, double *y1, uint32_t &m1,
+                                              double *x2, uint32_t *s2, double *y2, uint32_t &m2, uint32_t lane) {
+    uint32_t keep = 0;
+    constexpr int kDeep = 4;
+    for (uint32_t base = 0; base < n; base += kDeep * kWave) {
+        double2 evs[kDeep];
+#pragma unroll
+        for (int b = 0; b < kDeep; b++) {
+            const uint32_t j = base + (uint32_t)b * kWave + lane;
+            evs[b].x = 0.0; evs[b].y = 0.0;
+            if (j < n) evs[b] = ld_rec(heap_node(H, j));
+        }
+#pragma unroll
+        for (int b = 0; b < kDeep; b++) {
+            const uint32_t j = base + (uint32_t)b * kWave + lane;
+            const bool in = j < n;
+            const double2 ev = evs[b];
+            const bool due = in && fabs(ev.x) <= bound;
+            const bool t1 = due && !sign_of(ev.x), t2 = due && sign_of(ev.x), stay = in && !due;
+            const uint64_t b1 = __ballot(t1), b2 = __ballot(t2), bs = __ballot(stay);
+            if (t1) { const uint32_t p = m1 + count_below(b1); x1[p] = ev.x; s1[p] = sdr; y1[p] = ev.y; }
+            if (t2) { const uint32_t p = m2 + count_below(b2); x2[p] = -ev.x; s2[p] = sdr; y2[p] = ev.y; }
+            if (stay) st_rec(heap_node(H, keep + count_below(bs)), ev);
+            m1 += (uint32_t)__popcll(b1);
+            m2 += (uint32_t)__popcll(b2);
+            keep += (uint32_t)__popcll(bs);
+        }
+    }
+    return keep;
+}
+
+// SPLIT as in the one-sender kernel: the first instance (one wavefront per env) takes the envs whose interval fits its arrays in one go
+// and leaves the others alone; the second runs those as sub-intervals.
+template <int CAP, int CAPK, int CHUNK, bool SPLIT, int T>
+__global__ __launch_bounds__(T) void noise_sorted2_kernel(Dev D, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64) {
+    if (gate && __hip_atomic_load(D.any_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != D.step_seq) return;
+    const int64_t i = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1u);
+    const bool wave0 = tid < (uint32_t)kWave;
+    if (warm && !D.env[i].resetting) return;
+    NoiseOut *const out0 = D.noise_out + i, *const out1 = D.noise_out + D.n + i;
+    if (out0->seq == D.noise_seq) return;
+
+    constexpr uint32_t kShare = (uint32_t)CAPK / 2u;   // SENDs of one sender per sub-interval
+    __shared__ double e1x[CAP], e1y[CAP], e2x[CAP], e2y[CAP], mt[CAPK + 2], nx[CAPK], un[CHUNK], ul[CHUNK], tsd[2][kShare + 1];
+    __shared__ uint32_t e1s[CAP], e2s[CAP], ms[CAPK + 2], nsd[CAPK];
+    __shared__ uint32_t s_a, s_b, s_c, s_d, s_cnt[2], s_gen[2], s_kind, s_flags, s_ks, s_ak[2], s_ls[2];
+    __shared__ double s_q, s_tu, s_now, s_xx, s_xy, s_nsend[2];
+
+    double rate[2], gap[2], cur[2];
+    uint32_t n_heap[2];
+    double2 *H[2], *R[2];
+    const uint32_t noise_cap = D.noise_cap;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int64_t ks = sidx(D, s, i);
+        rate[s] = D.snd[ks].rate;
+        if (!warm) {   // apply_rate_delta (ns:235-241, 275-281): as the retire launch does it for the same env (it stores the rate)
+            const int64_t a = i * 2 + s;
+            double delta = actions_f64 ? ((const double *)actions)[a] : (double)((const float *)actions)[a];
+            if (delta != delta) delta = 0.0;
+            delta *= D.delta_scale;
+            rate[s] = delta >= 0.0 ? rate[s] * (1.0 + delta) : rate[s] / (1.0 - delta);
+            if (rate[s] > kMaxRate) rate[s] = kMaxRate;
+            if (rate[s] < kMinRate) rate[s] = kMinRate;
+        }
+        gap[s] = 1.0 / rate[s];
+        cur[s] = D.snd[ks].next_send;
+        n_heap[s] = D.snd[ks].heap_n & 0x7FFFFFFFu;
+        const int64_t kh = (int64_t)s * D.n + i;   // (the event arrays are [S][N])
+        H[s] = D.noise_heap + (size_t)kh * (noise_cap + kHeapPad);
+        R[s] = D.noise_rtt + (size_t)kh * noise_cap;
+    }
+    const double nsend_in[2] = {cur[0], cur[1]};
+    const double dl = D.env[i].dl, lr = D.env[i].lr, maxq = D.env[i].maxq, ebw = D.env[i].ebw, span = D.noise_span;
+    const double start = D.env[i].now, end = start + D.env[i].run_dur;
+    if (!(end + 0.5 * dl > end)) return;   // (a latency below the clock's resolution: the event loop's, see the one-sender kernel)
+    DrawCtx dc;
+    dc.trace_row = D.rng_mode == PCC_RNG_TRACE ? D.trace + i * D.trace_stride : nullptr;
+    dc.trace_stride = D.trace_stride;
+    dc.ep0 = D.env[i].ep_draws; dc.key0 = D.key0; dc.key1 = D.key1;
+    dc.gid = D.gid_base + (uint32_t)env_of(D, i);
+    dc.episode = D.env[i].episode - 1;
+    dc.mi = warm ? warm_mi : D.env[i].steps + 2;
+    uint32_t flags = 0;
+
+    if (!(start < end)) {   // ns:128: the loop body never runs
+        if (tid == 0) {
+            D.env[i].mi_draws = 0;
+            out0->now = start; out0->q = D.env[i].q; out0->tu = D.env[i].tu; out0->nsend = nsend_in[0]; out1->nsend = nsend_in[1];
+            out0->sent = out0->acked = out0->lost = 0; out1->sent = out1->acked = out1->lost = 0; out0->flags = 0;
+            out0->seq = D.noise_seq;
+        }
+        return;
+    }
+
+    // what the sub-intervals hand on
+    uint32_t draws = 0, sent[2] = {0u, 0u}, acked[2] = {0u, 0u}, lost[2] = {0u, 0u}, kind = 3u, ksd = 0u;
+    bool first = true, no_sends_before = false, give_up = false;
+    if (tid == 0) { s_q = D.env[i].q; s_tu = D.env[i].tu; s_now = start; s_nsend[0] = cur[0]; s_nsend[1] = cur[1]; }
+
+    for (;;) {
+        // ---- the SEND times of this sub-interval, per sender (the reference's own additions): up to kShare of each before `end`
+        __syncthreads();
+        if (tid < 2u) {
+            const uint32_t s = tid;
+            uint32_t k = 0;
+            double t = cur[s];
+            while (t < end && k < kShare) { tsd[s][k++] = t; t = t + gap[s]; }
+            tsd[s][k] = t;       // the sender's next SEND: at or after `end`, or the first that did not fit
+            s_gen[s] = k;
+        }
+        __syncthreads();
+        const uint32_t g0 = s_gen[0], g1 = s_gen[1];
+        // the sub-interval's boundary in event order: `end`, or the first SEND that did not fit -- (time, sender), the earlier one
+        bool final = !(tsd[0][g0] < end) && !(tsd[1][g1] < end);
+        double lim_t = end;
+        uint32_t lim_s = 0u;
+        if (!final) {
+            const bool o0 = tsd[0][g0] < end, o1 = tsd[1][g1] < end;
+            if (o0 && (!o1 || tsd[0][g0] <= tsd[1][g1])) { lim_t = tsd[0][g0]; lim_s = 0u; }
+            else { lim_t = tsd[1][g1]; lim_s = 1u; }
+        }
+        // the senders' SENDs before the boundary: (t, s) < (lim_t, lim_s) (every one of them when the boundary is `end`)
+        uint32_t Ks[2];
+        Ks[0] = final ? g0 : (lim_s == 0u ? count_lt(tsd[0], g0, lim_t) : count_le(tsd[0], g0, lim_t));
+        Ks[1] = final ? g1 : count_lt(tsd[1], g1, lim_t);
+        // (sender 0's SEND at exactly lim_t comes before (lim_t, 1) and is not before (lim_t, 0); sender 1's at lim_t never is)
+        for (uint32_t k = tid; k < Ks[0]; k += T) { mt[k] = tsd[0][k]; ms[k] = 0u; }
+        for (uint32_t k = tid; k < Ks[1]; k += T) { mt[Ks[0] + k] = tsd[1][k]; ms[Ks[0] + k] = 1u; }
+        uint32_t K = Ks[0] + Ks[1];
+        if (!SPLIT && !final) return;      // (nothing written yet: the larger instance's)
+        __syncthreads();
+        sort_pairs<T>(mt, ms, K, tid);
+        __syncthreads();
+        // ---- does what is due by the boundary fit the arrays, and have the senders' arrays in memory room?  If not, fewer SENDs.
+        double t_bound = final ? (tsd[0][g0] <= tsd[1][g1] ? tsd[0][g0] : tsd[1][g1]) : lim_t;
+        for (;;) {
+            __syncthreads();
+            if (wave0) {
+                uint32_t due1 = 0, due2 = 0;
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+                    for (uint32_t base = 0; base < n_heap[s]; base += kWave) {
+                        const uint32_t j = base + lane;
+                        const double x = j < n_heap[s] ? ld_t1(heap_node(H[s], j)) : INFINITY;
+                        const bool due = fabs(x) <= t_bound;
+                        due1 += (uint32_t)__popcll(__ballot(due && !sign_of(x)));
+                        due2 += (uint32_t)__popcll(__ballot(due && sign_of(x)));
+                    }
+                if (lane == 0) { s_a = due1; s_b = due2; }
+            }
+            __syncthreads();
+            const uint32_t due1 = s_a, due2 = s_b;
+            const bool room = n_heap[0] + Ks[0] + 2u < noise_cap && n_heap[1] + Ks[1] + 2u < noise_cap;
+            if (room && due1 + K + 1u <= (uint32_t)CAP && due2 + due1 + K + 1u <= (uint32_t)CAP) break;
+            if (!SPLIT || K == 0u) {
+                if (first) return;                      // (nothing written yet: the larger instance's, or the event loop's)
+                flags |= room ? PCC_FLAG_INTERNAL : PCC_FLAG_RING_OVERFLOW;
+                give_up = true;
+                break;
+            }
+            // half the merged SENDs: the boundary is the first one left out
+            K >>= 1;
+            lim_t = mt[K]; lim_s = ms[K];
+            final = false;
+            t_bound = lim_t;
+            if (wave0) {   // the senders' shares of the shorter prefix
+                uint32_t c1 = 0;
+                for (uint32_t base = 0; base < K; base += kWave) c1 += (uint32_t)__popcll(__ballot(base + lane < K && ms[base + lane] == 1u));
+                if (lane == 0) s_c = c1;
+            }
+            __syncthreads();
+            Ks[1] = s_c; Ks[0] = K - Ks[1];
+        }
+        if (!final && K == 0u) {   // (a sub-interval without a SEND must not follow one: nothing would move)
+            if (no_sends_before) flags |= PCC_FLAG_INTERNAL;
+            no_sends_before = true;
+        } else no_sends_before = false;
+        if (give_up || (flags & PCC_FLAG_INTERNAL)) break;
+
+        // ---- the events that are due, by hop, tagged with their sender; the others close up in place
+        __syncthreads();
+        if (wave0) {
+            uint32_t m1 = 0, m2 = 0;
+            const uint32_t kp0 = take_due2(H[0], n_heap[0], t_bound, 0u, e1x, e1s, e1y, m1, e2x, e2s, e2y, m2, lane);
+            const uint32_t kp1 = take_due2(H[1], n_heap[1], t_bound, 1u, e1x, e1s, e1y, m1, e2x, e2s, e2y, m2, lane);
+            if (lane == 0) { s_a = m1; s_b = m2; s_c = kp0; s_d = kp1; }
+        }
+        __syncthreads();
+        uint32_t n1 = s_a, n2 = s_b;
+        const uint32_t keep0 = s_c, keep1 = s_d;
+        sort_events2<T>(e1x, e1s, e1y, n1, tid);
+        sort_events2<T>(e2x, e2s, e2y, n2, tid);
+        __syncthreads();
+        const uint32_t n1_old = n1, n2_old = n2;
+
+        // ---- SENDs in blocks cut by time: the hop-1 arrivals before SEND (t, s) = old ones <= (t, s) + new ones of EARLIER blocks <= (t, s)
+        uint32_t n_news = 0;
+        for (uint32_t b0 = 0; b0 < K;) {
+            const double t_cut = mt[b0] + 0.9 * dl;
+            uint32_t b1 = count_lt(mt, K, t_cut);   // (mt is sorted by time first)
+            if (b1 <= b0) b1 = b0 + 1u;
+            for (uint32_t c0 = b0; c0 < b1; c0 += (uint32_t)CHUNK) {
+                const uint32_t c1 = (b1 - c0 > (uint32_t)CHUNK) ? c0 + (uint32_t)CHUNK : b1;
+                for (uint32_t k = c0 + tid; k < c1; k += T) {
+                    const double tk = mt[k];
+                    const uint32_t sk = ms[k];
+                    const uint32_t idx = draws + 2u * k + count_pairs_le(e1x, e1s, n1_old, tk, sk) + count_pairs_le(nx, nsd, n_news, tk, sk);
+                    un[k - c0] = draw_at(dc, idx, flags);
+                    ul[k - c0] = draw_at(dc, idx + 1u, flags);
+                }
+                __syncthreads();
+                if (tid == 0) {   // the queue recurrence over the merged SENDs: a scan
+                    LinkState L; L.q = s_q; L.tu = s_tu;
+                    for (uint32_t k = c0; k < c1; k++) {
+                        double ax, ay;
+                        send_one(mt[k], un[k - c0], ul[k - c0], dl, lr, maxq, ebw, span, L, ax, ay);
+                        e1x[n1_old + k] = ax; e1y[n1_old + k] = ay; e1s[n1_old + k] = ms[k];
+                    }
+                    s_q = L.q; s_tu = L.tu;
+                }
+                __syncthreads();
+            }
+            if (b1 < K) {   // the next block searches these arrivals too
+                for (uint32_t k = b0 + tid; k < b1; k += T) { nx[k] = e1x[n1_old + k]; nsd[k] = e1s[n1_old + k]; }
+                n_news = b1;
+                __syncthreads();
+                sort_pairs<T>(nx, nsd, n_news, tid);
+                __syncthreads();
+            }
+            b0 = b1;
+        }
+        n1 = n1_old + K;
+        __syncthreads();
+        sort_events2<T>(e1x, e1s, e1y, n1, tid);
+        __syncthreads();
+
+        // ---- hop-1 arrivals before the boundary: a draw each, in their order; their hop-2 events
+        const uint32_t n1p = final ? count_lt(e1x, n1, end) : count_pairs_le(e1x, e1s, n1, lim_t, lim_s);
+        for (uint32_t j = tid; j < n1p; j += T) {
+            const double a = e1x[j], y = e1y[j];
+            const uint32_t sp = e1s[j];
+            const uint32_t idx = draws + 2u * count_pairs_lt(mt, ms, K, a, sp) + j;   // SENDs (t, s) < (a, sp), arrivals before it
+            double ll = dl + max0(0.0 - (a - 0.0));                                    // the return link never queues (ns:147-153)
+            ll *= 1.0 + span * draw_at(dc, idx, flags);
+            const double lat = fabs(y) + ll;
+            e2x[n2_old + j] = a + ll;
+            e2y[n2_old + j] = sign_of(y) ? -lat : lat;
+            e2s[n2_old + j] = sp;
+        }
+        n2 = n2_old + n1p;
+        __syncthreads();
+        sort_events2<T>(e2x, e2s, e2y, n2, tid);
+        __syncthreads();
+
+        // ---- hop-2 arrivals before the boundary: acknowledgements (their RTTs in this order, per sender) and loss reports
+        const uint32_t n2p = final ? count_lt(e2x, n2, end) : count_pairs_le(e2x, e2s, n2, lim_t, lim_s);
+        if (wave0) {
+            uint32_t ak[2] = {acked[0], acked[1]}, ls[2] = {lost[0], lost[1]}, fl = 0;
+            for (uint32_t base = 0; base < n2p; base += kWave) {
+                const uint32_t j = base + lane;
+                const bool in = j < n2p;
+                const double y = in ? e2y[j] : 0.0;
+                const uint32_t sp = in ? e2s[j] : 0u;
+#pragma unroll
+                for (uint32_t s = 0; s < 2u; s++) {
+                    const bool ok = in && sp == s && !sign_of(y), bad = in && sp == s && sign_of(y);
+                    const uint64_t mo = __ballot(ok), mb = __ballot(bad);
+                    if (ok) {
+                        const uint32_t p = ak[s] + count_below(mo);
+                        if (p < noise_cap) { double2 r; r.x = 0.0; r.y = y; st_rec(R[s] + p, r); }
+                        else fl |= PCC_FLAG_RING_OVERFLOW;
+                    }
+                    ak[s] += (uint32_t)__popcll(mo);
+                    ls[s] += (uint32_t)__popcll(mb);
+                }
+            }
+            flags |= fl;
+            if (lane == 0) { s_ak[0] = ak[0]; s_ak[1] = ak[1]; s_ls[0] = ls[0]; s_ls[1] = ls[1]; }
+        }
+        __syncthreads();
+        acked[0] = s_ak[0]; acked[1] = s_ak[1]; lost[0] = s_ls[0]; lost[1] = s_ls[1];
+        sent[0] += Ks[0]; sent[1] += Ks[1];
+
+        // ---- the last sub-interval: the event that ends the interval -- the smallest of the senders' next SENDs, the first hop-1
+        // and the first hop-2 arrival not yet due, by (time, sender, 'A' < 'S', hop)
+        kind = 3u;
+        double next0 = tsd[0][Ks[0]], next1 = tsd[1][Ks[1]];   // the senders' next SENDs after this sub-interval
+        if (final) {
+            if (tid == 0) {
+                double bt = next0; uint32_t bsd = 0u, bk = 1u, bh = 0u, kd = 0u;   // kd: 0 = SEND of sender bsd, 1 = hop-1 arrival, 2 = hop-2 arrival
+                auto better = [&](double t, uint32_t sdr, uint32_t knd, uint32_t hop) -> bool {
+                    if (t != bt) return t < bt;
+                    if (sdr != bsd) return sdr < bsd;
+                    if (knd != bk) return knd < bk;
+                    return hop < bh;
+                };
+                if (better(next1, 1u, 1u, 0u)) { bt = next1; bsd = 1u; bk = 1u; bh = 0u; kd = 0u; }
+                if (n1p < n1 && better(e1x[n1p], e1s[n1p], 0u, 1u)) { bt = e1x[n1p]; bsd = e1s[n1p]; bk = 0u; bh = 1u; kd = 1u; }
+                if (n2p < n2 && better(e2x[n2p], e2s[n2p], 0u, 2u)) { bt = e2x[n2p]; bsd = e2s[n2p]; bk = 0u; bh = 2u; kd = 2u; }
+                LinkState L; L.q = s_q; L.tu = s_tu;
+                double xx = 0.0, xy = 0.0, ns0 = next0, ns1 = next1;
+                uint32_t fl = 0;
+                if (kd == 0u) {
+                    const uint32_t idx = draws + 2u * K + n1p;
+                    const double u0 = draw_at(dc, idx, fl), u1 = draw_at(dc, idx + 1u, fl);
+                    send_one(bt, u0, u1, dl, lr, maxq, ebw, span, L, xx, xy);   // a hop-1 event of sender bsd, not due
+                    if (bsd == 0u) ns0 = bt + gap[0]; else ns1 = bt + gap[1];   // ns:161
+                } else if (kd == 1u) {
+                    const double a = e1x[n1p], y = e1y[n1p];
+                    double ll = dl + max0(0.0 - (a - 0.0));
+                    ll *= 1.0 + span * draw_at(dc, draws + 2u * K + n1p, fl);
+                    const double lat = fabs(y) + ll;
+                    xx = a + ll;            // a hop-2 event of sender bsd, not due
+                    xy = sign_of(y) ? -lat : lat;
+                } else {
+                    const double y = e2y[n2p];
+                    xx = sign_of(y) ? 1.0 : 0.0;   // (a loss report, or an acknowledgement: its RTT is the sender's last of the interval)
+                    if (!sign_of(y)) {
+                        const uint32_t p = bsd == 0u ? s_ak[0] : s_ak[1];
+                        if (p < noise_cap) { double2 r; r.x = 0.0; r.y = y; st_rec(R[bsd] + p, r); }
+                        else fl |= PCC_FLAG_RING_OVERFLOW;
+                    }
+                }
+                s_xx = xx; s_xy = xy; s_kind = kd; s_ks = bsd; s_now = bt; s_nsend[0] = ns0; s_nsend[1] = ns1; s_q = L.q; s_tu = L.tu; s_flags = fl;
+            }
+            __syncthreads();
+            kind = s_kind; ksd = s_ks;
+            flags |= s_flags;
+            if (kind == 2u) { if (s_xx != 0.0) lost[ksd]++; else acked[ksd]++; }
+            if (kind == 0u) sent[ksd]++;
+        }
+
+        // ---- what was due and is still in flight, and the new events, go back behind what stayed, each to its sender's array
+        const uint32_t f1 = n1p + (kind == 1u ? 1u : 0u), f2 = n2p + (kind == 2u ? 1u : 0u);
+        __syncthreads();
+        if (tid == 0) { s_cnt[0] = keep0; s_cnt[1] = keep1; }
+        __syncthreads();
+        for (uint32_t j = f1 + tid; j < n1; j += T) {
+            const uint32_t sp = e1s[j];
+            const uint32_t p = atomicAdd(&s_cnt[sp], 1u);
+            if (p < noise_cap) { double2 r; r.x = e1x[j]; r.y = e1y[j]; st_rec(heap_node(H[sp], p), r); }
+            else flags |= PCC_FLAG_RING_OVERFLOW;
+        }
+        for (uint32_t j = f2 + tid; j < n2; j += T) {
+            const uint32_t sp = e2s[j];
+            const uint32_t p = atomicAdd(&s_cnt[sp], 1u);
+            if (p < noise_cap) { double2 r; r.x = -e2x[j]; r.y = e2y[j]; st_rec(heap_node(H[sp], p), r); }
+            else flags |= PCC_FLAG_RING_OVERFLOW;
+        }
+        __syncthreads();
+        if (tid == 0 && (kind == 0u || kind == 1u)) {
+            const uint32_t p = s_cnt[ksd]++;
+            if (p < noise_cap) { double2 r; r.x = kind == 0u ? s_xx : -s_xx; r.y = s_xy; st_rec(heap_node(H[ksd], p), r); }
+            else flags |= PCC_FLAG_RING_OVERFLOW;
+        }
+        __threadfence_block();
+        __syncthreads();   // (the arrays, and the senders' arrays in memory, are the next sub-interval's)
+        n_heap[0] = s_cnt[0] < noise_cap ? s_cnt[0] : noise_cap; n_heap[1] = s_cnt[1] < noise_cap ? s_cnt[1] : noise_cap;
+        draws += 2u * K + n1p + (kind == 0u ? 2u : kind == 1u ? 1u : 0u);
+        cur[0] = next0; cur[1] = next1;
+        first = false;
+        if (final) break;
+    }
+
+    // every thread's flags
+    for (uint32_t bit = 1u; bit <= PCC_FLAG_INTERNAL; bit <<= 1)
+        if (__syncthreads_or((flags & bit) != 0u ? 1 : 0)) flags |= bit;
+    if (tid == 0) {
+        D.snd[sidx(D, 0, i)].heap_n = n_heap[0] | 0x80000000u;
+        D.snd[sidx(D, 1, i)].heap_n = n_heap[1] | 0x80000000u;
+        D.env[i].ep_draws = dc.ep0 + draws;
+        D.env[i].mi_draws = dc.trace_row ? 0u : draws;
+        if (give_up || (flags & PCC_FLAG_INTERNAL)) { s_nsend[0] = cur[0]; s_nsend[1] = cur[1]; }
+        out0->now = s_now; out0->q = s_q; out0->tu = s_tu; out0->nsend = s_nsend[0]; out1->nsend = s_nsend[1];
+        out0->sent = sent[0]; out0->acked = acked[0]; out0->lost = lost[0];
+        out1->sent = sent[1]; out1->acked = acked[1]; out1->lost = lost[1];
+        out0->flags = flags;
+        __threadfence();
+        out0->seq = D.noise_seq;
+    }
+}
+
 }  // namespace
 
 namespace pcc {
@@ -476,6 +941,14 @@ namespace pcc {
 void launch_noise_sorted(const Dev &d, hipStream_t st, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64,
                          int only_small) {
     const unsigned grid = (unsigned)d.n;
+    if (d.ns == 2) {   // two senders: 256 due events per hop / 128 SENDs of both senders in one go by one wavefront, then 512 / 256 with sub-intervals by two
+        // (measured at 16 384 envs x 2 senders, ms per step: this pair 11.8; 1 024 / 512 by four wavefronts as the second instance
+        // 15.0 -- its 62 KB of LDS leave two workgroups per compute unit; one 256 / 128 instance with sub-intervals 15.1)
+        hipLaunchKernelGGL((noise_sorted2_kernel<256, 128, 128, false, 64>), dim3(grid), dim3(64), 0, st, d, warm, warm_mi, gate, actions, actions_f64);
+        if (only_small) return;
+        hipLaunchKernelGGL((noise_sorted2_kernel<512, 256, 128, true, 128>), dim3(grid), dim3(128), 0, st, d, warm, warm_mi, gate, actions, actions_f64);
+        return;
+    }
     hipLaunchKernelGGL((noise_sorted_kernel<256, 128, 128, false, 64>), dim3(grid), dim3(64), 0, st, d, warm, warm_mi, gate, actions, actions_f64);
     if (only_small) return;
     hipLaunchKernelGGL((noise_sorted_kernel<1024, 512, 256, true, 256>), dim3(grid), dim3(256), 0, st, d, warm, warm_mi, gate, actions, actions_f64);

@@ -1112,10 +1112,14 @@ __device__ __forceinline__ float retire_env(const Dev &D, const int64_t i, const
         for (int s = 0; s < NS; s++) { o.nsend[s] = nsend[s]; o.sent[s] = o.acked[s] = o.lost[s] = 0; }
         if (lead) {
             bool ran = false;
-            if (NS == 1 && D.noise_out != nullptr && D.noise_out[i].seq == D.noise_seq) {   // pcc_noise_sorted.hip has run this interval
+            if (D.noise_out != nullptr && D.noise_out[i].seq == D.noise_seq) {   // pcc_noise_sorted.hip has run this interval
                 const NoiseOut r = D.noise_out[i];
                 o.now = r.now; o.q = r.q; o.tu = r.tu; o.nsend[0] = r.nsend;
                 o.sent[0] = r.sent; o.acked[0] = r.acked; o.lost[0] = r.lost; o.flags = r.flags;
+                if constexpr (NS == 2) {   // (entry N + i: sender 1's)
+                    const NoiseOut r1 = D.noise_out[D.n + i];
+                    o.nsend[NS - 1] = r1.nsend; o.sent[NS - 1] = r1.sent; o.acked[NS - 1] = r1.acked; o.lost[NS - 1] = r1.lost;
+                }
                 ran = true;
             }
             if (!ran) o = event_engine<NS>(D, i, start, end, rate, nsend, warm ? warm_mi : steps + 2, cw);

@@ -317,7 +317,7 @@ int launch_mi(pcc_sim_t *sim, int warm, uint32_t warm_mi, int last_warm, int gat
         // runs the event loop for the envs that were left alone.
         sim->d.noise_seq++;
         Dev d = sim->d;
-        const bool sorted = sim->noise_sorted && d.use_noise && !d.use_cwnd && d.ns == 1 && d.noise_out != nullptr;
+        const bool sorted = sim->noise_sorted && d.use_noise && !d.use_cwnd && d.noise_out != nullptr;
         if (!sorted) d.noise_out = nullptr;
         else launch_noise_sorted(d, st, warm, warm_mi, gate, actions, actions_f64, sim->noise_sorted == 2);
         const unsigned grid = (unsigned)((d.n + kRetireEnvsPerBlockNarrow - 1) / kRetireEnvsPerBlockNarrow);
@@ -922,7 +922,7 @@ int update_engine(pcc_sim_t *sim) {
         const size_t heaps = senders * (sim->ring_capacity + kHeapSlack) * sizeof(double2), lists = senders * sim->ring_capacity * sizeof(double2);
         // both blobs are allocated before either is published: a failure leaves the handle as it was (a retry starts over)
         void *p = nullptr, *po = nullptr;
-        const size_t outs = (size_t)sim->d.n * sizeof(NoiseOut);
+        const size_t outs = (size_t)sim->d.n * sim->d.ns * sizeof(NoiseOut);   // [S][N]: entry s * N + i = sender s of env i (the env's own fields in sender 0's)
         if (hipMalloc(&p, heaps + lists) != hipSuccess)
             return fail(PCC_ENOMEM, "hipMalloc of %zu bytes for the event heaps failed", heaps + lists);
         if (hipMalloc(&po, outs) != hipSuccess) {

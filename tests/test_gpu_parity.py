@@ -1059,6 +1059,35 @@ def test_engine_options_with_two_senders_philox_batches_match_oracle(cwnd, noise
     env.close()
 
 
+@pytest.mark.parametrize("scale,n_envs,n_steps", [(1.0, 384, 70), (8.0, 256, 90)])
+def test_two_senders_latency_noise_without_the_event_loop_matches_oracle(scale, n_envs, n_steps):
+    """Two senders with USE_LATENCY_NOISE run their intervals by sorting too (round 6: noise_sorted2_kernel -- the two SEND streams
+    merged by (time, sender) on one draw stream, the sender id ahead of the kind of event in every comparison, blocks of SENDs cut by
+    time; the numpy study is tests/models/noise_sorting2_model.py).  Random links, both senders' counts, clocks, rewards, every metric and
+    the observations against the oracle's event loop; large actions push the rates from the floor to the ceiling, so that intervals
+    of many hundred SENDs -- run as sub-intervals -- are in the comparison.  (tests/test_variants.py runs this with the event loop for
+    every env and with the two crossed from env to env.)"""
+    seed = 23
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, n_senders=2, record_steps=True, auto_reset=False, latency_noise=1.1)
+    obs0 = env.reset().clone()
+    acts = np.random.RandomState(seed).uniform(-1, 1, (n_envs, n_steps, 2)) * scale
+    a = torch.as_tensor(acts, dtype=torch.float64, device=DEV)
+    rows, obs = [], []
+    for t in range(n_steps):
+        o, r, dn, info = env.step(a[:, t])
+        rows.append(info["steps"].clone()); obs.append(o.clone())
+    env.check_flags()
+    steps = torch.stack(rows, 2).cpu().numpy()                     # [N, S, T, 19]
+    got_obs = torch.stack(obs, 2).cpu().numpy()                    # [N, S, T, HF]
+    ref = oracle.run_batch(acts, n_senders=2, rng_mode=oracle.RNG_PHILOX, seed=seed, latency_noise=1.1)
+    assert np.array_equal(obs0.cpu().numpy().reshape(ref["obs0"].shape), ref["obs0"].astype(np.float32))
+    assert np.array_equal(steps[..., :3], ref["steps"][..., :3])
+    assert np.array_equal(steps, ref["steps"])
+    assert np.array_equal(got_obs.reshape(ref["obs"].shape), ref["obs"].astype(np.float32))
+    assert float(steps[..., 0].max()) >= (400 if scale > 1 else 100)   # (intervals of many SENDs are in the batch)
+    env.close()
+
+
 def test_event_loop_build_has_no_send_half():
     env = pcc_rl_amd.BatchedNetworkEnv(8, device=DEV, n_senders=2, use_cwnd=True, auto_reset=False)
     env.reset()

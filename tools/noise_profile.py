@@ -7,11 +7,12 @@ import torch, pcc_rl_amd
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 dev = torch.device("cuda:0")
-env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, latency_noise=1.1)
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, latency_noise=1.1, n_senders=S)
 if os.environ.get("NOISE_SORTED"):
     env.set_tuning(noise_sorted=int(os.environ["NOISE_SORTED"]))
 gen = torch.Generator(device=dev).manual_seed(1234)
-acts = torch.rand((K, N), generator=gen, device=dev) * 2 - 1
+acts = torch.rand((K, N, S), generator=gen, device=dev) * 2 - 1
 env.reset()
 torch.cuda.synchronize()
 import time
