@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t ld_u32_agent(const uint32_t *p) { return __h
 // The light items of the partition whose list set is `view`, off ONE cursor, longest class first (light_body deals the same
 // items statically: here an item must belong to a wavefront that is running).  After an item: its envs into ready queue 0.
 template <int NS, bool TRACE>
-__device__ __forceinline__ void fused_light_loop(const Dev &D, SendLds<NS> &lds, const uint32_t lane, const uint32_t wv, const int read_buf,
+__device__ __forceinline__ void fused_light_loop(const Dev &D, SendLds<NS, 4> &lds, const uint32_t lane, const uint32_t wv, const int read_buf,
                                                  const uint32_t part, const void *actions, const int actions_f64, const uint32_t xcc) {
     const uint32_t view = list_view(D, read_buf, part);
     const uint32_t E = D.send_envs_per_wave;
@@ -298,13 +298,13 @@ __global__ __launch_bounds__(4 * kWave, NS == 2 ? PCC_FUSED_OCC2 : PCC_FUSED_OCC
         D.timeline[(int64_t)19 * D.n + 1] = wall_clock64();
         D.timeline[(int64_t)19 * D.n + 2] = D.step_seq;
     }
-    __shared__ SendLds<NS> lds;
+    __shared__ SendLds<NS, 4> lds;   // (the frozen one-launch step keeps 4 positions per lane: its register and LDS budget are what they were)
     const uint32_t part = blockIdx.x & (D.parts - 1u);
     const uint32_t xcc = xcc_id();
     // (light_front: the workgroups in FRONT of the wave-path ones start with the light items -- the rest of the light-first
     // workgroups follow behind them)
     if (blockIdx.x >= light_front && blockIdx.x - light_front < wave_wgs)
-        wave_body<NS, TRACE, true>(D, lds, lane, wv, wave_wgs, read_buf, actions, actions_f64, xcc, blockIdx.x - light_front);
+        wave_body<NS, TRACE, true, SendLds<NS, 4>>(D, lds, lane, wv, wave_wgs, read_buf, actions, actions_f64, xcc, blockIdx.x - light_front);
     fused_light_loop<NS, TRACE>(D, lds, lane, wv, read_buf, part, actions, actions_f64, xcc);
     // (retire_on = 0, PCC_TUNE_FUSED = 2: an experiment -- this launch is the send half only, a retire launch follows)
     if (retire_on) fused_retire_loop<NS>(D, lane, read_buf, fill_buf, xcc, obs_out, reward_out, done_out, steps_out);

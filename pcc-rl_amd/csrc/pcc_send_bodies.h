@@ -13,12 +13,24 @@
 
 namespace {
 
-template <int NS>
+// positions per lane of a wave-path item's closed-form passes (heavy_mi's NP; team passes and the light items' stragglers: 4).
+// 8 (passes of 512 positions: the per-pass work -- header, regime constants, token division, scans -- over twice the packets) was
+// built in round 6, is exact (the parity suite ran through it) and is NOT faster: 0.0908 / 0.0935 ms per send launch at thresholds
+// 480 / 384 against 0.0907 / 0.0921 with 4 (tools/ab_block.py, profiles/r06_knob_sweeps.json) -- the launch's tail is its longest
+// lane-round items, and an env of 300-500 packets fills neither pass length.  -DPCC_WAVE_POS=8 builds it (40 KB of LDS per workgroup).
+#ifndef PCC_WAVE_POS
+#define PCC_WAVE_POS 4
+#endif
+constexpr int kWaveItemPos = PCC_WAVE_POS;
+
+// POS: positions per lane of the wave-path items' passes in this kernel (the staging buffer holds a pass of one wavefront)
+template <int NS, int POS = (NS == 1 ? kWaveItemPos : 4)>
 struct SendLds {
+    static constexpr int kPos = POS;
     EnvSlot<NS> slots[4][kSlots];      // send_wave_item's parked envs, per wavefront
     uint32_t tab[4][6][kClasses];      // wave_body's class table, per wavefront
     TeamX team;                        // what the wavefronts of a team pass tell each other
-    double2 stage[4][4 * kWave];       // heavy_mi<.., STAGE>: the records of a closed-form pass on their way out, per wavefront
+    double2 stage[4][(NS == 1 ? POS : 0) * kWave + 1];   // heavy_mi<.., STAGE> (one sender): the records of a closed-form pass on their way out, per wavefront
 };
 #ifndef PCC_STAGE_RECORDS
 #define PCC_STAGE_RECORDS 1
@@ -32,8 +44,8 @@ constexpr bool kStageRecords = PCC_STAGE_RECORDS != 0;
 // share a compute unit, one per SIMD; dealt in snake order (workgroup b: ranks b, 2Q-1-b, 2Q+b, 4Q-1-b) a workgroup's items
 // add up to about the same number of packets -- the lane rounds' scattered 16-byte record stores go through the compute
 // unit's one address path.
-template <int NS, bool TRACE>
-__device__ __forceinline__ void light_body(const Dev &D, SendLds<NS> &lds, const uint32_t lane, const uint32_t wv, const uint32_t b_wg,
+template <int NS, bool TRACE, class LDS = SendLds<NS>>
+__device__ __forceinline__ void light_body(const Dev &D, LDS &lds, const uint32_t lane, const uint32_t wv, const uint32_t b_wg,
                                            const uint32_t Q, const int view, const uint32_t tl_base, const int warm, const uint32_t warm_mi,
                                            const void *actions, const int actions_f64) {
     const uint32_t n_waves = Q * 4u;
@@ -111,8 +123,8 @@ __device__ __forceinline__ void light_body(const Dev &D, SendLds<NS> &lds, const
 // cost the kernel its spill-free register budget whichever way the hop count was kept.)
 // FUSED (pcc_fused.hip): every env that is sent goes into the ready queue of the wave-path classes of this wavefront's XCD
 // (fused_push), after the wavefronts that stored for it have drained their stores.
-template <int NS, bool TRACE, bool FUSED = false>
-__device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const uint32_t lane, const uint32_t wv, const uint32_t wave_wgs,
+template <int NS, bool TRACE, bool FUSED = false, class LDS = SendLds<NS>>
+__device__ __forceinline__ void wave_body(const Dev &D, LDS &lds, const uint32_t lane, const uint32_t wv, const uint32_t wave_wgs,
                                           const int read_buf, const void *actions, const int actions_f64, const uint32_t xcc = 0u,
                                           const uint32_t blk = blockIdx.x) {
     // workgroup blockIdx.x of the wave_wgs wave-path workgroups: number b_wg of the G of its partition.  (Computed from
@@ -237,8 +249,8 @@ __device__ __forceinline__ void wave_body(const Dev &D, SendLds<NS> &lds, const 
             const int64_t i = has ? (int64_t)list[idx] : 0;
             const bool prio = t < D.prio_wave_items;
             if (prio) set_prio(D.prio_level);
-            (void)send_wave_item<NS, TRACE, 1, kStageRecords && NS == 1>(D, lane, i, has, true, tl_base + t < tl_end ? tl_base + t : 0xFFFFFFFFu, 0, 0, actions, actions_f64, lds.slots[wv],
-                                                                         0u, nullptr, false, nullptr, lds.stage[wv]);
+            (void)send_wave_item<NS, TRACE, 1, kStageRecords && NS == 1, LDS::kPos>(D, lane, i, has, true, tl_base + t < tl_end ? tl_base + t : 0xFFFFFFFFu, 0, 0, actions, actions_f64, lds.slots[wv],
+                                                                                       0u, nullptr, false, nullptr, lds.stage[wv]);
             if constexpr (FUSED) {
                 fused_drain();
                 fused_push(D, read_buf, xcc, 1u, __ballot(has), lane, i);

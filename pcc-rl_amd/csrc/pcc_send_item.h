@@ -575,7 +575,8 @@ __device__ __forceinline__ uint64_t uni_u64(uint64_t v) { return ((uint64_t)uni_
 // (heavy_mi<.., W>); every wavefront loads the env's state and computes everything alike, wavefront 0 writes.
 // Returns the packets the item sent (wave-uniform; the launch statistics of pcc_get_send_split).
 // STAGE / stage: the closed-form passes' records leave through 256 LDS slots of this wavefront (heavy_mi; one sender).
-template <int NS, bool TRACE, int W, bool STAGE = false>
+// P: positions per lane of the closed-form passes (heavy_mi; one sender).
+template <int NS, bool TRACE, int W, bool STAGE = false, int P = 4>
 __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t lane, const int64_t i, const bool in_range,
                                                    const bool fresh, const uint32_t tl_slot, const int warm, const uint32_t warm_mi,
                                                    const void *actions, const int actions_f64, EnvSlot<NS> *slots,
@@ -640,7 +641,7 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
                     st.a = ta_new[0]; st.d = td_new[0]; st.flags = 0;
                     st.prof_closed = 0; st.prof_other = 0;
                     st.sent = sent_new[0];  // packets of this MI the lane rounds already sent
-                    heavy_mi<TRACE, W, STAGE>(D, lane, wv, X, uni_f64(S.dl), uni_f64(S.lr), uni_u32(S.thr), (bits & 1u) != 0u, uni_f64(S.maxq),
+                    heavy_mi<TRACE, W, STAGE, P>(D, lane, wv, X, uni_f64(S.dl), uni_f64(S.lr), uni_u32(S.thr), (bits & 1u) != 0u, uni_f64(S.maxq),
                                               uni_f64(S.ebw), uni_f64(S.gap[0]), uni_f64(S.end), uni_u32(S.episode), uni_u32(S.mi), uni_u32(S.gid),
                                               reinterpret_cast<const double *>(uni_u64(reinterpret_cast<uint64_t>(S.trace))),
                                               reinterpret_cast<char *>(uni_u64(reinterpret_cast<uint64_t>(S.base[0]))), uni_u32(S.cap[0]), st, stage);

@@ -118,14 +118,20 @@ __device__ __forceinline__ double pow2_f64(int e_unbiased) {  // 2^e for a norma
 // profiles/r06_lane_round_microbench.txt, r06_send_timeline_*.json).  Staged, the accepted records of the pass sit in LDS in
 // ring order from slot 0 up, the dropped ones from slot 255 down, and lane l stores slot 64 k + l: 1 KB of consecutive ring
 // bytes per instruction, a quarter of the requests.  Same records, same ring slots.
-template <bool TRACE, int W, bool STAGE = false>
+// NP: positions per lane of a closed-form pass (a multiple of 4: whole Philox blocks; 4 in the product).  Round 6 built 8 for the
+// wave path's items -- the pass header, the regime constants, the token division and the scans are per PASS, ~345 of a
+// 4-position pass's ~765 vector instructions -- and measured no gain (pcc_send_bodies.h: PCC_WAVE_POS).  Same decisions, same
+// records at either length: the passes are exact whatever their length (tests/models/send_pass_model.c checks 256 and 1 024
+// positions; the GPU parity suite ran through 512).
+template <bool TRACE, int W, bool STAGE = false, int NP = 4>
 __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint32_t wv, TeamX *X, double dl, double lr,
                                          uint32_t thr, bool always, double maxq, double ebw, double gap, double end,
                                          uint32_t episode, uint32_t mi, uint32_t gid, const double *trace, char *base,
                                          uint32_t cap, SendState &st, double2 *stage = nullptr) {
     static_assert(W >= 1 && W <= kTeamMax, "team size");
     const uint32_t mask_b = (cap - 1u) << 4, dmask_b = (2u * cap - 1u) << 4, cap_b = cap << 4;
-    constexpr uint32_t kPass = 4u * kWave * W;
+    static_assert(NP % 4 == 0 && NP >= 4 && NP <= 16, "whole Philox blocks per lane; the per-position bits fit a word");
+    constexpr uint32_t kLanePos = (uint32_t)NP, kWavePos = kLanePos * kWave, kPass = kWavePos * W, kPosMask = (1u << NP) - 1u;
     const uint32_t glane = (W > 1 ? wv * kWave : 0u) + lane;  // lane of the team
     const bool first_lane = glane == 0u;
     const bool writer = W == 1 || wv == 0u;  // who stores what every wavefront of the team computes alike
@@ -241,11 +247,11 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
 
         if (regime != 0) {
             // ---- loss decisions of the lane's four positions (bit i: lost at random, ns:73)
-            const int kbase = 4 * (int)glane - (int)skip;  // packet index (within the pass) of position 0 of this lane
+            const int kbase = NP * (int)glane - (int)skip;  // packet index (within the pass) of position 0 of this lane
             uint32_t rnd4 = 0;
             if (TRACE) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < NP; i++) {
                     const int k = kbase + i;
                     const int64_t pos = (int64_t)((uint64_t)st.a + st.d) + k;
                     double uu = 1.0;
@@ -253,15 +259,18 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                     rnd4 |= (uu < lr ? 1u : 0u) << i;
                 }
             } else {
-                uint32_t w[4];
-                philox4x32_10((st.sent >> 2) + glane, mi, episode, gid, D.key0, D.key1, w);
 #pragma unroll
-                for (int i = 0; i < 4; i++) rnd4 |= ((always || w[i] < thr) ? 1u : 0u) << i;
+                for (int blk = 0; blk < NP / 4; blk++) {   // (position p of the pass is packet 4 (sent >> 2) + p of the interval)
+                    uint32_t w[4];
+                    philox4x32_10((st.sent >> 2) + (uint32_t)(NP / 4) * glane + (uint32_t)blk, mi, episode, gid, D.key0, D.key1, w);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rnd4 |= ((always || w[i] < thr) ? 1u : 0u) << (4 * blk + i);
+                }
             }
             // ---- which positions hold a packet of this MI, and which of those reach the queue
             uint32_t ex4 = 0, m4 = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NP; i++) {
                 const int k = kbase + i;
                 const double tki = t0 + (double)(k < 0 ? 0 : k) * G;  // exact
                 const bool ex = k >= 0 && tki < lim;
@@ -280,7 +289,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 acc4 = m4;
                 int in_wave = 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < NP; i++) {
                     const uint64_t bm = __ballot((acc4 >> i) & 1u);
                     j_base += (int)count_below(bm);
                     in_wave += (int)__popcll(bm);
@@ -304,7 +313,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                     if (rem >= Ri) { N++; rem -= Ri; }
                     int ssum = 0, cmax = kLindNone;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < NP; i++) {
                         int a = 0;
                         if (kbase + i >= 0) {  // arrivals run on past the MI end: harmless
                             rem += Gi;
@@ -341,7 +350,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                     if (first_lane && !(free_mode || Ci >= 0)) acc4 &= ~(1u << skip);
                     int in_wave = 0;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < NP; i++) {
                         const uint64_t bm = __ballot((acc4 >> i) & 1u);
                         j_base += (int)count_below(bm);
                         in_wave += (int)__popcll(bm);
@@ -361,7 +370,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                     int64_t xk = xi;
                     int jr = j_base;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < NP; i++) {
                         const bool m = (m4 >> i) & 1u;
                         const bool a = m && b > 0;
                         acc4 |= (a ? 1u : 0u) << i;
@@ -383,7 +392,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                     const uint32_t kap = (uint32_t)((Ii3 + cl3) & 1);
                     uint32_t fn = 0;  // identity
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < NP; i++) {
                         if ((acc4 >> i) & 1u) {
                             if ((up4 >> i) & 1u) fn = 1u;          // constant 0
                             else fn ^= kap << 1;                   // flip (of the constant, or of the flip)
@@ -405,7 +414,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                     // corrections c' = c - cl of the lane's accepted packets, and their sum
                     int csum = 0;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < NP; i++) {
                         if ((acc4 >> i) & 1u) {
                             int c;
                             if ((up4 >> i) & 1u) { c = (int)((P + (uint32_t)Ii3) & 1u); P = 0; }
@@ -426,7 +435,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 } else {
                 double x = x_base;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < NP; i++) {
                     const bool m = (m4 >> i) & 1u;
                     bool a;
                     if (over) {
@@ -447,15 +456,15 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 }
             }
             // ---- the pass stops at the first position that is past the MI end or breaks a precondition
-            uint32_t stop4 = (~ex4 | flag4) & 0xFu;
+            uint32_t stop4 = (~ex4 | flag4) & kPosMask;
             if (first_lane) stop4 &= ~((1u << skip) - 1u);  // positions before `skip` are not part of the pass
             const uint64_t stop_lanes = __ballot(stop4 != 0u);
-            uint32_t p_stop = 4u * kWave, j_stop;  // (in this wavefront's 256 positions)
+            uint32_t p_stop = kWavePos, j_stop;  // (in this wavefront's positions)
             bool stopped_by_flag = false;
             if (stop_lanes) {
                 const uint32_t ls = (uint32_t)__ffsll((unsigned long long)stop_lanes) - 1u;
-                const uint32_t is = ((uint32_t)__ffs((int)stop4) - 1u) & 3u;
-                p_stop = 4u * ls + rl_u32(is, ls);
+                const uint32_t is = ((uint32_t)__ffs((int)stop4) - 1u) & (kLanePos - 1u);
+                p_stop = kLanePos * ls + rl_u32(is, ls);
                 j_stop = rl_u32((uint32_t)j_base + (uint32_t)__popc(acc4 & ((1u << is) - 1u)), ls);
                 stopped_by_flag = rl_u32((flag4 >> is) & 1u, ls) != 0u;
             } else {
@@ -465,8 +474,8 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 if (lane == 0) { X->pstop[wv] = p_stop; X->jstop[wv] = j_stop; X->sflag[wv] = stopped_by_flag ? 1u : 0u; }
                 __syncthreads();
                 uint32_t w2 = 0;
-                while (w2 + 1u < (uint32_t)W && X->pstop[w2] == 4u * kWave) w2++;
-                p_stop = w2 * 4u * kWave + X->pstop[w2];
+                while (w2 + 1u < (uint32_t)W && X->pstop[w2] == kWavePos) w2++;
+                p_stop = w2 * kWavePos + X->pstop[w2];
                 j_stop = X->jstop[w2];
                 stopped_by_flag = X->sflag[w2] != 0u;
             }
@@ -493,12 +502,12 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 uint32_t acc0 = 0, drp0 = 0, n_acc_w = 0, n_com_w = 0;
                 if constexpr (STAGE) {
                     acc0 = rl_u32((uint32_t)j_base, 0);
-                    const uint32_t p0 = W > 1 ? wv * 4u * kWave : 0u, pv = p0 > skip ? p0 : skip;   // (this wavefront's first position)
+                    const uint32_t p0 = W > 1 ? wv * kWavePos : 0u, pv = p0 > skip ? p0 : skip;   // (this wavefront's first position)
                     drp0 = (pv - skip) - acc0;
                 }
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t p = 4u * glane + (uint32_t)i;
+                for (int i = 0; i < NP; i++) {
+                    const uint32_t p = kLanePos * glane + (uint32_t)i;
                     const bool a = (acc4 >> i) & 1u;
                     const int cpr = (int)((cp4 >> (2 * i)) & 3u) - 1;  // regime C: this packet's correction c' (0 elsewhere)
                     if (regime == 3) x = (double)xt * u;  // exact: even from B up
@@ -515,7 +524,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                         rec.y = dl + qc;                          // ns:170
                         rec.x = tki + rec.y;                      // ns:174
                         if constexpr (STAGE) {
-                            stage[a ? j - acc0 : 255u - ((kk - j) - drp0)] = rec;
+                            stage[a ? j - acc0 : (kWavePos - 1u) - ((kk - j) - drp0)] = rec;
                         } else {
                             const uint32_t off = a ? (((st.a + j) << 4) & mask_b) : cap_b + (((st.d + (kk - j)) << 4) & dmask_b);
                             st_rec(reinterpret_cast<double2 *>(base + off), rec);
@@ -543,7 +552,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                     for (uint32_t sl = lane; sl < n_acc_w; sl += kWave)
                         st_rec(reinterpret_cast<double2 *>(base + (((a0 + sl) << 4) & mask_b)), stage[sl]);
                     for (uint32_t sl = lane; sl < n_drp_w; sl += kWave)
-                        st_rec(reinterpret_cast<double2 *>(base + cap_b + (((d0 + sl) << 4) & dmask_b)), stage[255u - sl]);
+                        st_rec(reinterpret_cast<double2 *>(base + cap_b + (((d0 + sl) << 4) & dmask_b)), stage[(kWavePos - 1u) - sl]);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();   // (the next pass stages into the same slots)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
