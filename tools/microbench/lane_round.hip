@@ -329,6 +329,164 @@ __device__ __forceinline__ void rounds_t(Lane &L, uint32_t key0, uint32_t key1, 
     L.q = S.q; L.tu = S.tu; L.t = S.t; L.a = S.a4 >> 4; L.d = S.d4 >> 4;
 }
 
+
+// ---- variant 8: write-behind.  A compute wavefront only WRITES its accepted records into an LDS ring (no read, no wait on the
+// address path: dropped records still leave at once); a drain wavefront of the same workgroup reads the ring transposed -- lanes
+// 4 e .. 4 e + 3 take the (up to) four records of env e's block -- and issues the global stores: 16 envs x <= 64 consecutive ring
+// bytes per store instruction, and the stalls on the compute unit's address path are the drain wavefront's, not the packet chain's.
+constexpr int kWbDepth = 4;   // blocks of four packets in flight between a compute wavefront and its drain wavefront
+struct WbLds {
+    double2 ring[kWbDepth][64][4];   // [block % depth][lane][j-th accepted record of the block]
+    uint2 meta[kWbDepth][64];        // a_old4 (byte offset of the block's first accepted record before masking), count
+    unsigned long long base[64];     // the lanes' ring bases
+    uint32_t prod, cons, total;      // blocks published / drained; total blocks (0xFFFFFFFF until the compute wavefront is done)
+    uint32_t pad;
+};
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t *p) { return *(volatile const uint32_t *)p; }
+__device__ __forceinline__ void packet_wb(PacketState &S, const bool lost, const double dl, const double maxq, const double ebw, const double gap,
+                                          char *base, const uint32_t dmask_b, const uint32_t cap_b, double2 *row, double2 *trash, uint32_t &jk) {
+    const double t = S.t;
+    const double qcur = max0(S.q - (t - S.tu));
+    const double grown = qcur + ebw;
+    const double lat0 = dl + qcur;
+    const double lim = __hiloint2double(lost ? (int)0xBFF00000u : __double2hiint(maxq), __double2loint(maxq));
+    const bool dropped = grown > lim;
+    const double keep = lost ? S.q : qcur;
+    S.q = dropped ? keep : grown;
+    S.tu = lost ? S.tu : t;
+    double2 rec;
+    rec.x = t + lat0;
+    rec.y = lat0;
+    *(dropped ? trash : row + jk) = rec;
+    if (dropped) st_rec(reinterpret_cast<double2 *>(base + cap_b + (S.d4 & dmask_b)), rec);
+    const uint32_t inc = dropped ? 16u : 0u;
+    jk += dropped ? 0u : 1u;
+    S.d4 += inc;
+    S.a4 += 16u - inc;
+    S.t = t + gap;
+}
+__device__ __forceinline__ void wb_publish(WbLds &X, const uint32_t lane, const uint32_t blkno, const uint32_t a_old4, const uint32_t jk) {
+    X.meta[blkno % kWbDepth][lane] = make_uint2(a_old4, jk);
+    asm volatile("" ::: "memory");           // (LDS accesses of a wavefront execute in order: the count below follows the records)
+    if (lane == 0) *(volatile uint32_t *)&X.prod = blkno + 1u;
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void wb_wait_slot(WbLds &X, const uint32_t blkno) {   // the ring slot of block `blkno` is free again
+    while (blkno >= lds_peek(&X.cons) + (uint32_t)kWbDepth) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void rounds_wb_compute(Lane &L, uint32_t key0, uint32_t key1, uint32_t round_packets, WbLds &X, const uint32_t lane) {
+    const double dl = L.dl, maxq = L.maxq, ebw = L.ebw, gap = L.gap, end = L.end;
+    const uint32_t thr = L.thr, gid = L.gid, episode = L.episode, mi = L.mi;
+    const bool always = L.always;
+    char *base = L.base;
+    const uint32_t dmask_b = (2u * kCap - 1u) << 4, cap_b = kCap << 4;
+    PacketState S;
+    S.q = L.q; S.tu = L.tu; S.t = L.t; S.a4 = L.a << 4; S.d4 = L.d << 4;
+    X.base[lane] = (unsigned long long)(uintptr_t)base;
+    __shared__ double2 s_trash[8][64];
+    double2 *trash = &s_trash[threadIdx.x >> 6][lane];
+    uint32_t blk = 0, blkno = 0;
+    bool active = S.t < end;
+    for (;;) {
+        const double ahead = (end - S.t) / gap - 2.0;
+        uint32_t safe4 = (active && ahead >= 4.0) ? (uint32_t)fmin(ahead, (double)round_packets) >> 2 : 0u;
+        uint32_t budget4 = active ? round_packets / 4 - safe4 : 0u;
+        uint32_t w[4];
+        philox_c(blk, mi, episode, gid, key0, key1, w);
+        while (__ballot(safe4 != 0u)) {
+            uint32_t wn[4];
+            const bool on = safe4 != 0u;
+            philox_c(blk + (on ? 1u : 0u), mi, episode, gid, key0, key1, wn);
+            wb_wait_slot(X, blkno);
+            double2 *row = X.ring[blkno % kWbDepth][lane];
+            const uint32_t a_old4 = S.a4;
+            uint32_t jk = 0;
+            if (on) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) packet_wb(S, always || w[k] < thr, dl, maxq, ebw, gap, base, dmask_b, cap_b, row, trash, jk);
+                blk++;
+                safe4--;
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = wn[k];
+            }
+            wb_publish(X, lane, blkno, a_old4, jk);
+            blkno++;
+        }
+        while (__ballot(budget4 != 0u && S.t < end)) {
+            const bool on = budget4 != 0u && S.t < end;
+            wb_wait_slot(X, blkno);
+            double2 *row = X.ring[blkno % kWbDepth][lane];
+            const uint32_t a_old4 = S.a4;
+            uint32_t jk = 0;
+            if (on) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k > 0 && !(S.t < end)) break;
+                    packet_wb(S, always || w[k] < thr, dl, maxq, ebw, gap, base, dmask_b, cap_b, row, trash, jk);
+                }
+                blk++;
+                budget4--;
+                philox_c(blk, mi, episode, gid, key0, key1, w);
+            }
+            wb_publish(X, lane, blkno, a_old4, jk);
+            blkno++;
+        }
+        active = active && S.t < end;
+        if (!__ballot(active)) break;
+    }
+    if (lane == 0) *(volatile uint32_t *)&X.total = blkno;
+    L.q = S.q; L.tu = S.tu; L.t = S.t; L.a = S.a4 >> 4; L.d = S.d4 >> 4;
+}
+__device__ __forceinline__ void rounds_wb_drain(WbLds &X, const uint32_t lane) {
+    const uint32_t mask_b = (kCap - 1u) << 4;
+    const uint32_t r = lane & 3u;
+    uint32_t b = 0;
+    for (;;) {
+        uint32_t have;
+        for (;;) {
+            have = lds_peek(&X.prod);
+            if (have > b || lds_peek(&X.total) == b) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (have <= b) break;                 // drained everything the compute wavefront published, and it is done
+        for (; b < have; b++) {
+            const uint32_t slot = b % kWbDepth;
+#pragma unroll
+            for (uint32_t g = 0; g < 4u; g++) {
+                const uint32_t sl = 16u * g + (lane >> 2);
+                const uint2 M = X.meta[slot][sl];
+                const double2 R = X.ring[slot][sl][r];
+                const unsigned long long bs = X.base[sl];
+                if (r < M.y) st_rec(reinterpret_cast<double2 *>(reinterpret_cast<char *>((uintptr_t)bs) + ((M.x + r * 16u) & mask_b)), R);
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) *(volatile uint32_t *)&X.cons = b + 1u;   // (the loads above have been issued: LDS executes them in order before a later write lands)
+        }
+    }
+}
+template <int DUMMY>
+__global__ __launch_bounds__(512) void k_rounds_wb(const EnvP *P, EnvOut *O, char *rings, const uint32_t *perm, uint32_t key0, uint32_t key1, long long *ticks) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    __shared__ WbLds s_wb[4];
+    if (threadIdx.x < 4u) { s_wb[threadIdx.x].prod = 0; s_wb[threadIdx.x].cons = 0; s_wb[threadIdx.x].total = 0xFFFFFFFFu; }
+    __syncthreads();
+    if (wv >= 4u) { rounds_wb_drain(s_wb[wv - 4u], lane); return; }
+    const uint32_t wave = blockIdx.x * 4u + wv;
+    const uint32_t e = perm[wave * 64u + lane];
+    Lane L;
+    L.dl = P[e].dl; L.maxq = P[e].maxq; L.ebw = P[e].ebw; L.gap = P[e].gap; L.end = P[e].end; L.q = P[e].q; L.tu = P[e].tu; L.t = P[e].t;
+    L.a = P[e].a; L.d = P[e].d; L.gid = P[e].gid; L.episode = P[e].episode; L.mi = P[e].mi;
+    const double thr_d = ceil(P[e].lr * 4294967296.0);
+    L.always = thr_d >= 4294967296.0;
+    L.thr = L.always ? 0xFFFFFFFFu : (thr_d > 0.0 ? (uint32_t)thr_d : 0u);
+    L.base = rings + (size_t)e * kRingBytes;
+    const long long r0 = (long long)wall_clock64();
+    rounds_wb_compute(L, key0, key1, 256u, s_wb[wv], lane);
+    const long long r1 = (long long)wall_clock64();
+    O[e].q = L.q; O[e].tu = L.tu; O[e].t = L.t; O[e].a = L.a; O[e].d = L.d;
+    if (lane == 0) ticks[wave] = r1 - r0;
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void k_rounds(const EnvP *P, EnvOut *O, char *rings, const uint32_t *perm, int n_probe_waves, int neighbours,
                                                    uint32_t key0, uint32_t key1, long long *ticks) {
@@ -407,7 +565,8 @@ int main(int argc, char **argv) {
     std::vector<EnvOut> ref;
     std::vector<char> ring_ref;
     const int probe_envs = n_probe * 64;
-    for (int v : {0, 6, 1, 2, 5, 7, 9}) {
+    for (int v : {0, 6, 1, 2, 5, 7, 8, 9}) {
+        if (v == 8 && (wg_waves != 4 || neighbours)) continue;   // (write-behind: workgroups of 4 compute + 4 drain wavefronts)
         std::vector<long long> ht(n_probe);
         double best_med = 1e30, best_max = 1e30;
         for (int rep = 0; rep < 3; rep++) {
@@ -415,6 +574,7 @@ int main(int argc, char **argv) {
             CK(hipDeviceSynchronize());
 #define L(V) hipLaunchKernelGGL(k_rounds<V>, dim3(n_waves / wg_waves), dim3(64 * wg_waves), 0, 0, dP, dO, rings, dperm, n_probe, neighbours, 0x1234u, 0x5678u, dt)
             if (v == 0) L(0); if (v == 1) L(1); if (v == 2) L(2); if (v == 3) L(3); if (v == 4) L(4); if (v == 5) L(5); if (v == 6) L(6); if (v == 7) L(7); if (v == 9) L(9);
+            if (v == 8) hipLaunchKernelGGL(k_rounds_wb<0>, dim3(n_waves / 4), dim3(512), 0, 0, dP, dO, rings, dperm, 0x1234u, 0x5678u, dt);
 #undef L
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(ht.data(), dt, 8 * n_probe, hipMemcpyDeviceToHost));
