@@ -732,6 +732,18 @@ def main():
                                               "frac": retire_gbps / HBM_PEAK_GBPS, "kernel_ms": retire_ms,
                                               "algorithmic_bytes_per_launch": retire_bytes}],
                            "whole_step": {"achieved": both, "frac": both / HBM_PEAK_GBPS}}
+        if not fused and not small and S == 1:
+            # what the dominant kernel's traffic IS: scattered 16-byte ring appends, one per packet.  The chip absorbs ~205 G of
+            # them per second (3.3 TB/s) whatever the coding -- measured by tools/microbench/lane_round (variants 2 / 7 / 8:
+            # one record per request, four per request through LDS, four per request by a drain wavefront) and round 4's
+            # store_bench4 -- and the send launch's busy phase (its first ~55 us, before the serial tail) runs at 196 G/s.
+            out["roofline"]["scattered_record_ceiling"] = {
+                "records_per_s": 2.05e11, "GB/s": 3280.0, "frac_of_hbm_peak": 3280.0 / HBM_PEAK_GBPS,
+                "launch_average_records_per_s": N * pk_roof / (send_ms * 1e-3),
+                "launch_average_frac_of_ceiling": N * pk_roof / (send_ms * 1e-3) / 2.05e11,
+                "note": "supplementary: the rate at which the memory system takes scattered 16-byte records (profiles/r06_lane_round_microbench.txt); "
+                        "the launch average includes the serial tail of the longest lane-round items (profiles/r06_send_tail.json), "
+                        "during which that bandwidth idles"}
         # HBM traffic from the counters: measured now, by two profiled runs of this script (unless --no-pmc / not one GPU);
         # else the newest committed summary, labelled as such
         kname = out["roofline"]["kernel"]
