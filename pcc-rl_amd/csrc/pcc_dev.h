@@ -467,6 +467,12 @@ __device__ __forceinline__ uint32_t count_below(uint64_t mask) {
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
 }
+// v of the lane below (DPP wave_shr:1, no LDS); lane 0 gets `first`
+__device__ __forceinline__ double wave_shr1_f64(double v, double first) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(first), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double rl_f64(double v, uint32_t l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), (int)l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), (int)l);

@@ -585,7 +585,7 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
     static_assert(W == 1 || NS == 1, "team items are built for one sender");
     const bool writer = W == 1 || wv == 0u;
     const uint64_t tl0 = prof_on(D) ? wall_clock64() : 0;
-    uint64_t tl1 = 0, tl_closed = 0, tl_other = 0, tl_env = 0, tl_envs = 0, tl_max = 0;
+    uint64_t tl1 = 0, tl_closed = 0, tl_other = 0, tl_env = 0, tl_envs = 0, tl_max = 0, tl_why = 0;
     uint32_t total = 0;
     uint64_t todo = __ballot(in_range);
     while (todo) {
@@ -651,6 +651,7 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
                 } else {
                     SendState2 st;
                     st.q = q_new; st.tu = tu_new; st.flags = 0;
+                    st.prof_closed = 0; st.prof_other = 0; st.prof_why = 0;
 #pragma unroll
                     for (int s = 0; s < 2; s++) {
                         st.t[s] = nsend_new[s < NS ? s : 0]; st.a[s] = ta_new[s < NS ? s : 0]; st.d[s] = td_new[s < NS ? s : 0];
@@ -663,6 +664,7 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
                                      reinterpret_cast<char *>(uni_u64(reinterpret_cast<uint64_t>(S.base[NS - 1]))),
                                      uni_u32(S.cap[0]), uni_u32(S.cap[NS - 1]), st);
                     q_new = st.q; tu_new = st.tu; flags |= st.flags;
+                    if (kProfile) { tl_closed += st.prof_closed; tl_other += st.prof_other; tl_env = (uint64_t)ie; tl_why |= st.prof_why; }
 #pragma unroll
                     for (int s = 0; s < NS; s++) { nsend_new[s] = st.t[s]; ta_new[s] = st.a[s]; td_new[s] = st.d[s]; sent_new[s] = st.sent[s]; }
                 }
@@ -696,7 +698,7 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
     }
     if (prof_on(D) && lane == 0 && writer && tl_slot != 0xFFFFFFFFu) {
         uint64_t *w = D.timeline + (int64_t)tl_slot * 8;
-        w[0] = tl0; w[1] = tl1; w[2] = wall_clock64(); w[3] = tl_envs | (tl_env << 16); w[4] = total; w[5] = tl_max; w[6] = total;
+        w[0] = tl0; w[1] = tl1; w[2] = wall_clock64(); w[3] = tl_envs | (tl_env << 16); w[4] = total; w[5] = tl_max | (tl_why << 32); w[6] = total;
         w[7] = tl_envs | (tl_closed << 8) | (tl_other << 24);
     }
     return total;

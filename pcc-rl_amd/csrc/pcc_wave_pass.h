@@ -20,6 +20,11 @@ struct SendState {  // wave-uniform while an env is processed by the whole wave
 // (s2, c2) after (s1, c1) = (s1 + s2, max(c1 + s2, c2)), so the tokens every lane starts with come
 // from one prefix scan of the lanes' composites: six DPP steps, no LDS.
 constexpr int kLindNone = -(1 << 28);  // "-inf" with room for every shift a pass can add
+#ifndef PCC_RELAX_SWEEPS
+#define PCC_RELAX_SWEEPS 1
+#endif
+// 1: the accept chain of heavy_mi2 by sweeps over all its packets side by side; 0: from accepted packet to accepted packet
+constexpr int kRelaxSweeps = PCC_RELAX_SWEEPS;
 constexpr uint32_t kMaxPasses = 1u << 22;  // passes of one env and interval before the wave path gives up (PCC_FLAG_INTERNAL)
 
 template <int CTRL, int ROW_MASK>
@@ -717,6 +722,8 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
 struct SendState2 {
     double q, tu, t[2];
     uint32_t a[2], d[2], sent[2], flags;
+    uint32_t prof_closed, prof_other;  // profile build: token passes / chain passes (low half) and plain-recurrence passes (high half)
+    uint32_t prof_why;                 // profile build: which preconditions refused a token pass (bits 0-10) or the chain (16-20)
 };
 
 template <bool TRACE>
@@ -730,6 +737,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
     uint32_t guard = 0;
     while ((st.t[0] < st.t[1] ? st.t[0] : st.t[1]) < end) {
         if (++guard > kMaxPasses) { st.flags |= PCC_FLAG_INTERNAL; break; }
+        const uint64_t dbg_c0 = prof_counters(D) ? __builtin_readcyclecounter() : 0;
         // ---- token pass, up to 256 packets: the queue stays backlogged in one binade (heavy_mi's regime B, here for the
         // merged stream; lane l owns the positions 4 l .. 4 l + 3 = one Philox block).  Every quantity is a multiple of
         // u = ulp(q): the queue in front of merged position p is x_p = Q0 + j_p R - D_p (j_p packets accepted before it,
@@ -744,15 +752,18 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             constexpr uint32_t kPass = 4u * kWave;
             double G2[2];
             bool okb = true;
-            double tend_max = 0.0;
+            double tend_max = 0.0, lim = end;
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 const double t0 = st.t[s], t1s = t0 + gap[s];
                 G2[s] = t1s - t0;
                 const double t2s = t1s + gap[s], tend = t0 + (double)kPass * G2[s];
-                // (t0 + c G is exact for c <= 256, and stays in t0's binade)
+                // (t0 + c G is exact for c <= 256 while it stays in t0's binade: positions whose send time leaves the binade of
+                // either sender are not part of the pass, which ends at lim = min(end, top of the lower binade) -- like heavy_mi)
+                const double ttop = pow2_f64((int)exponent_bits(t0) - 1022);
+                lim = ttop < lim ? ttop : lim;
                 okb = okb && (t2s - t1s == G2[s]) && (G2[s] > 0.0) && (t0 >= ((double)kPass + 4.0) * gap[s]) &&
-                      (exponent_bits(t0) == exponent_bits(tend));
+                      (exponent_bits(t0) == exponent_bits(t2s));
                 tend_max = tend > tend_max ? tend : tend_max;
             }
             const uint32_t e = exponent_bits(st.q), eb = exponent_bits(ebw);
@@ -760,6 +771,19 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             const double x0 = st.q - (T0 - st.tu);
             okb = okb && (st.tu + st.tu >= tend_max) && (st.q > 0.0) && e > 64u && e < 1100u && (x0 > 0.0) && eb <= e &&
                   exponent_bits(st.tu) >= e && exponent_bits(maxq) >= e;
+            if (kProfile && !okb) {
+                uint32_t why = 0;
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const double t0 = st.t[s], t1s = t0 + gap[s], g = t1s - t0, t2s = t1s + gap[s];
+                    why |= (t2s - t1s == g ? 0u : 1u) | (t0 >= ((double)kPass + 4.0) * gap[s] ? 0u : 2u) |
+                           (exponent_bits(t0) == exponent_bits(t2s) ? 0u : 4u);
+                }
+                why |= (st.tu + st.tu >= tend_max ? 0u : 8u) | (st.q > 0.0 ? 0u : 16u) | ((e > 64u && e < 1100u) ? 0u : 32u) |
+                       (x0 > 0.0 ? 0u : 64u) | (eb <= e ? 0u : 128u) | (exponent_bits(st.tu) >= e ? 0u : 256u) |
+                       (exponent_bits(maxq) >= e ? 0u : 512u);
+                st.prof_why |= why;
+            }
             double u = 0.0, R = 0.0;
             int64_t Q0i = 0, Ri = 1, Mi = 0, Dsi[2] = {0, 0}, Gsi[2] = {0, 0};
             bool free_mode = false, maxq_above = false;
@@ -787,6 +811,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                     maxq_above = exponent_bits(maxq) > e;
                 }
             }
+            if (kProfile && !okb && !(st.prof_why & 0x3FFu)) st.prof_why |= 1024u;   // (the grid of u: a tie on odd multiples, a span too wide)
             if (okb) {
                 const uint32_t sent_all = st.sent[0] + st.sent[1];
                 const uint32_t skip = sent_all & 3u;   // positions of lane 0's Philox block that were sent before this pass
@@ -832,7 +857,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                     tk[i] = is1 ? B : A;
                     Dp[i] = is1 ? Dsi[1] + (int64_t)c1 * Gsi[1] : Dsi[0] + (int64_t)c0 * Gsi[0];
                     const bool there = kbase + i >= 0;
-                    const bool ex = there && tk[i] < end;
+                    const bool ex = there && tk[i] < lim;
                     s4 |= (is1 ? 1u : 0u) << i;
                     ex4 |= (ex ? 1u : 0u) << i;
                     m4 |= ((ex && !((rnd4 >> i) & 1u)) ? 1u : 0u) << i;
@@ -905,6 +930,17 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                 }
                 const uint32_t ncommit = p_stop - skip;
                 if (p_stop < kPass && ncommit < 32u) chain_left = 2u;   // q hovers around a binade edge or keeps running empty
+                if (kProfile) st.prof_closed++;
+                if (prof_counters(D) && lane == 0) {   // (profile build: token passes / their packets / their cycles)
+                    atomicAdd(&D.pass_stats[1], 1ull);
+                    atomicAdd(&D.pass_stats[5], (unsigned long long)ncommit);
+                    atomicAdd(&D.pass_stats[13], (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));
+                    if (ncommit < 32u) {   // ... and the short ones among them
+                        atomicAdd(&D.pass_stats[10], 1ull);
+                        atomicAdd(&D.pass_stats[11], (unsigned long long)ncommit);
+                        atomicAdd(&D.pass_stats[12], (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));
+                    }
+                }
                 if (ncommit) {
                     if (TRACE && (int64_t)((uint64_t)st.a[0] + st.d[0] + st.a[1] + st.d[1] + ncommit) > D.trace_stride)
                         st.flags |= PCC_FLAG_TRACE_OVERRUN;
@@ -959,8 +995,9 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                     }
                     const uint32_t a0n = (uint32_t)(total & 0xFFFFu), d0n = (uint32_t)((total >> 16) & 0xFFFFu);
                     const uint32_t a1n = (uint32_t)((total >> 32) & 0xFFFFu), d1n = (uint32_t)((total >> 48) & 0xFFFFu);
-                    st.t[0] = st.t[0] + (double)(a0n + d0n) * G2[0];   // exact
-                    st.t[1] = st.t[1] + (double)(a1n + d1n) * G2[1];
+                    // ns:161 on each sender's last packet's (exact) send time: the next one may be the first of a new binade
+                    if (a0n + d0n) st.t[0] = (st.t[0] + (double)(a0n + d0n - 1u) * G2[0]) + gap[0];
+                    if (a1n + d1n) st.t[1] = (st.t[1] + (double)(a1n + d1n - 1u) * G2[1]) + gap[1];
                     st.a[0] += a0n; st.d[0] += d0n; st.sent[0] += a0n + d0n;
                     st.a[1] += a1n; st.d[1] += d1n; st.sent[1] += a1n + d1n;
                     continue;
@@ -984,20 +1021,36 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
         // ---- per-sender send sequences: t0 + k*G, exact while the preconditions hold
         double G[2];
         bool ok = (st.tu >= maxq);
-        double tend_max = 0.0;
+        double tend_max = 0.0, lim = end;   // (lim: the interval's end or the top of the lower binade of the two send times)
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const double t0 = st.t[s], t1s = t0 + gap[s];
             G[s] = t1s - t0;
             const double t2s = t1s + gap[s], tend = t0 + 64.0 * G[s];
-            ok = ok && (t2s - t1s == G[s]) && (t0 >= 128.0 * gap[s]) && (exponent_bits(t0) == exponent_bits(tend)) &&
+            const double ttop = pow2_f64((int)exponent_bits(t0) - 1022);
+            lim = ttop < lim ? ttop : lim;
+            ok = ok && (t2s - t1s == G[s]) && (t0 >= 128.0 * gap[s]) && (exponent_bits(t0) == exponent_bits(t2s)) &&
                  (G[s] > 0.0);
             tend_max = tend > tend_max ? tend : tend_max;
         }
         ok = ok && (st.tu + st.tu >= tend_max);
+        if (kProfile && !ok) {
+            uint32_t why = st.tu >= maxq ? 0u : 0x10000u;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const double t0 = st.t[s], t1s = t0 + gap[s], g = t1s - t0, t2s = t1s + gap[s];
+                why |= (t2s - t1s == g ? 0u : 0x20000u) | (t0 >= 128.0 * gap[s] ? 0u : 0x40000u) |
+                       (exponent_bits(t0) == exponent_bits(t2s) ? 0u : 0x80000u);
+            }
+            why |= st.tu + st.tu >= tend_max ? 0u : 0x100000u;
+            st.prof_why |= why;
+        }
         double my_t = 0.0, my_lat = 0.0;
         bool my_drop = true;
         uint32_t my_s = 0, nv;
+        bool dbg_settled = false;
+        int dbg_sweeps = 0;
+        const uint64_t dbg_c1 = prof_counters(D) ? __builtin_readcyclecounter() : 0;
         if (!ok) {
             // ---- serial pass: the plain merged recurrence, wave-uniform, lane k keeps packet k
             uint32_t k = 0;
@@ -1028,36 +1081,78 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             const double A = st.t[0] + (double)c0 * G[0], B = st.t[1] + (double)c1 * G[1];
             my_s = (A <= B) ? 0u : 1u;
             const double tk = my_s ? B : A;
-            const bool valid = tk < end;
+            const bool valid = tk < lim;
             const uint64_t vmask = __ballot(valid);
             nv = (uint32_t)__popcll(vmask);  // merged times increase: valid lanes are a prefix
             const uint64_t rmask = rm;
-            // phase 1: accepted packet to accepted packet
-            double qm = st.q, tm = st.tu;
-            uint64_t open = vmask & ~rmask, amask = 0;
-            uint32_t na = 0;
-            double seg_q = 0.0, seg_t = 0.0;
-            while (open) {
-                const double qc = max0(qm - (tk - tm));
-                const bool full = ebw + qc > maxq;
-                const uint64_t cm = open & ~__ballot(full);
-                if (!cm) break;
-                const uint32_t ks = (uint32_t)__ffsll((unsigned long long)cm) - 1u;
-                qm = rl_f64(ebw + qc, ks);
-                tm = rl_f64(tk, ks);
-                if (lane == na) { seg_q = qm; seg_t = tm; }
-                na++;
-                amask |= 1ull << ks;
-                open &= ~((2ull << ks) - 1ull);
+            const uint64_t openm = vmask & ~rmask;  // packets that reach the queue
+            bool settled = false;
+            double qc = 0.0;
+            if (kRelaxSweeps != 0) {
+                // ---- phase 1, side by side.  Every lane holds the link state (queue, time of the last update) BEHIND its
+                // packet: an accepted packet leaves (1/bw + the queue it found, its send time), any other packet -- lost at
+                // random, refused by the full queue, past the interval's end -- hands on what it was given, which is what
+                // the chain from accepted packet to accepted packet does by skipping it.  One sweep = every lane takes the
+                // state of the lane below it (lane 0: the state the pass started from) and redoes its own packet; after
+                // sweep i the lanes 0 .. i-1 are final, so nv sweeps are the serial result bit for bit (the same
+                // expressions on the same operands), and a sweep that moves nothing has reached that fixed point early:
+                // a packet that finds the queue drained leaves (1/bw, t_k) whatever came before it, so with the guess
+                // "everybody found it drained" sweep i settles the i-th packet of EVERY busy period of the pass at once.
+                const uint64_t upto = openm & ((2ull << lane) - 1ull);   // packets that reach the queue, up to this lane
+                const bool mine = (openm >> lane) & 1ull;
+                const int gl = upto ? 63 - (int)__clzll((long long)upto) : 0;
+                double oq = ebw, ot = __shfl(tk, gl);
+                if (!upto) { oq = st.q; ot = st.tu; }
+                bool full = false, moved = false;
+                for (uint32_t sweep = 0; sweep < nv; sweep += 4u) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const double iq = wave_shr1_f64(oq, st.q), it = wave_shr1_f64(ot, st.tu);
+                        qc = max0(iq - (tk - it));
+                        full = ebw + qc > maxq;
+                        const bool acc = mine && !full;
+                        const double nq = acc ? ebw + qc : iq, nt = acc ? tk : it;
+                        if (r == 3)
+                            moved = valid && (__double_as_longlong(nq) != __double_as_longlong(oq) ||
+                                              __double_as_longlong(nt) != __double_as_longlong(ot));
+                        oq = nq;
+                        ot = nt;
+                    }
+                    if (kProfile) dbg_sweeps += 4;
+                    if (!__ballot(moved)) break;
+                }
+                settled = true;
+                if (kProfile) dbg_settled = true;
+                my_drop = !(mine && !full);
             }
-            // phase 2: every lane finishes its own packet
-            const uint32_t seg = (uint32_t)count_below(amask);
-            const int src = seg ? (int)seg - 1 : 0;
-            double q_seg = __shfl(seg_q, src), t_seg = __shfl(seg_t, src);
-            if (!seg) { q_seg = st.q; t_seg = st.tu; }
-            const double qc = max0(q_seg - (tk - t_seg));
+            if (!settled) {
+                // phase 1: accepted packet to accepted packet
+                double qm = st.q, tm = st.tu;
+                uint64_t open = openm, amask = 0;
+                uint32_t na = 0;
+                double seg_q = 0.0, seg_t = 0.0;
+                while (open) {
+                    const double qk = max0(qm - (tk - tm));
+                    const bool full = ebw + qk > maxq;
+                    const uint64_t cm = open & ~__ballot(full);
+                    if (!cm) break;
+                    const uint32_t ks = (uint32_t)__ffsll((unsigned long long)cm) - 1u;
+                    qm = rl_f64(ebw + qk, ks);
+                    tm = rl_f64(tk, ks);
+                    if (lane == na) { seg_q = qm; seg_t = tm; }
+                    na++;
+                    amask |= 1ull << ks;
+                    open &= ~((2ull << ks) - 1ull);
+                }
+                // phase 2: every lane finishes its own packet
+                const uint32_t seg = (uint32_t)count_below(amask);
+                const int src = seg ? (int)seg - 1 : 0;
+                double q_seg = __shfl(seg_q, src), t_seg = __shfl(seg_t, src);
+                if (!seg) { q_seg = st.q; t_seg = st.tu; }
+                qc = max0(q_seg - (tk - t_seg));
+                my_drop = !((amask >> lane) & 1ull);
+            }
             my_lat = dl + qc;
-            my_drop = !((amask >> lane) & 1ull);
             const double my_q_after = my_drop ? qc : ebw + qc;
             my_t = tk + my_lat;
             const uint64_t touch = vmask & ~rmask;
@@ -1067,8 +1162,8 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                 st.tu = rl_f64(tk, kl);
             }
             const uint32_t n1 = (uint32_t)__popcll(__ballot(valid && my_s == 1u)), n0 = nv - n1;
-            st.t[0] = st.t[0] + (double)n0 * G[0];   // exact
-            st.t[1] = st.t[1] + (double)n1 * G[1];
+            if (n0) st.t[0] = (st.t[0] + (double)(n0 - 1u) * G[0]) + gap[0];   // ns:161 on the last packet's (exact) send time
+            if (n1) st.t[1] = (st.t[1] + (double)(n1 - 1u) * G[1]) + gap[1];
         }
         // ---- records: four dense runs (sender x accepted/dropped)
         const bool valid = lane < nv;
@@ -1090,6 +1185,14 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             st.a[s] += (uint32_t)__popcll(am);
             st.d[s] += (uint32_t)__popcll(dm);
             st.sent[s] += (uint32_t)__popcll(am) + (uint32_t)__popcll(dm);
+        }
+        if (kProfile) st.prof_other += ok ? 1u : 0x10000u;
+        if (prof_counters(D) && lane == 0) {   // (profile build: 0 = settled side by side, 2 = serial chain, 3 = plain recurrence)
+            const int c = !ok ? 3 : dbg_settled ? 0 : 2;
+            atomicAdd(&D.pass_stats[c], 1ull);
+            atomicAdd(&D.pass_stats[4 + c], (unsigned long long)nv);
+            atomicAdd(&D.pass_stats[ok ? 14 : 9], (unsigned long long)(__builtin_readcyclecounter() - dbg_c1));
+            if (dbg_settled) atomicAdd(&D.pass_stats[8], (unsigned long long)dbg_sweeps);
         }
     }
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Two builds of the library against each other (GPU box): send and retire launch times at 65 536 envs, steps 20..400 of an
+"""Two builds of the library against each other (GPU box): send and retire launch times at 65 536 envs (AB_ENVS, AB_SENDERS), steps 20..400 of an
 episode, HIP events around each launch, one fresh process per run, interleaved (a handle's retire launch has a fast and a
 slow mode of its own: profiles/r05_placement.json).
    python tools/ab_libraries.py [reps] path/libA.so path/libB.so ..."""
@@ -12,9 +12,10 @@ def child():
     import torch, pcc_rl_amd
     dev = torch.device("cuda:0")
     N = int(os.environ.get("AB_ENVS", "65536"))
+    NS = int(os.environ.get("AB_SENDERS", "1"))
     gen = torch.Generator(device=dev).manual_seed(1234)
-    acts = torch.rand((400, N, 1), generator=gen, device=dev) * 2 - 1
-    env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0)
+    acts = torch.rand((400, N, NS) if NS > 1 else (400, N, 1), generator=gen, device=dev) * 2 - 1
+    env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, n_senders=NS)
     env.reset()
     for t in range(20):
         env.step(acts[t])

@@ -38,7 +38,7 @@ for t in range(1300):
                           "light": {"n": int((~hv).sum()), "busy_us": round(float(dur[~hv].sum())), "packets": int(tl[~hv, 4].sum()),
                                     "rounds_end": pct(mid[~hv]) if (~hv).any() else None},
                           "slowest": [{"start": round(float(start[i]), 1), "rounds_end": round(float(mid[i]), 1), "fin": round(float(fin[i]), 1),
-                                       "pk": int(tl[i, 4]), "largest": int(tl[i, 5]), "wp_envs": int(tl[i, 3]), "env": int(envid[i]),
+                                       "pk": int(tl[i, 4]), "largest": int(tl[i, 5] & 0xFFFFFFFF), "wp_envs": int(tl[i, 3]), "env": int(envid[i]),
                                        "closed": int(closed[i]), "chain": int(chain[i]), "serial": int(serial[i])} for i in order]}), flush=True)
         for i in order[:2]:
             e = int(envid[i])

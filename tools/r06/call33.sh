@@ -1,0 +1,8 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r06_c33
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_full_size.py -m gpu -x -q -k "two_sender" > $O/tests.log 2>&1; tail -5 $O/tests.log
+AB_ENVS=32768 AB_SENDERS=2 timeout 600 python tools/ab_libraries.py 3 pcc-rl_amd/lib/libpcc_sim_norelax.so pcc-rl_amd/lib/libpcc_sim.so > $O/ab.txt 2>&1; tail -2 $O/ab.txt
+timeout 300 python bench.py --config 5 --no-scaling > $O/bench_c5.log 2>&1; tail -1 $O/bench_c5.log | cut -c1-400

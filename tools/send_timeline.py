@@ -48,7 +48,7 @@ for t in range(400):
                     st_ = st_[(st_ >= tl[sl, 0]) & (st_ <= tl[sl, 2])]     # (stale stamps of earlier steps fall outside the item's span)
                     us = [round(float(v - t00) / 100.0, 2) for v in st_]
                     fine.append({"start_us": round(float(tl[sl, 0] - t00) / 100.0, 2), "finish_us": round(float(tl[sl, 2] - t00) / 100.0, 2),
-                                 "largest_env": int(tl[sl, 5]), "stamp_us_every_32_packets": us,
+                                 "largest_env": int(tl[sl, 5] & 0xFFFFFFFF), "stamp_us_every_32_packets": us,
                                  "ns_per_iteration_by_stretch": [round(1e3 * (us[k + 1] - us[k]) / 32.0) for k in range(len(us) - 1)]})
         if N >= 32768:
             tl = tl.copy()
@@ -69,7 +69,7 @@ for t in range(400):
                "wave_path_envs": int(tl[:, 3].sum()),
                "busy_wave_us_total": float((fin - start).sum()),
                "slowest": [{"start": float(start[i]), "rounds_end": float(mid[i]), "finish": float(fin[i]),
-                            "wave_path_envs": int(tl[i, 3]), "packets": int(tl[i, 4]), "largest_env": int(tl[i, 5]),
+                            "wave_path_envs": int(tl[i, 3]), "packets": int(tl[i, 4]), "largest_env": int(tl[i, 5] & 0xFFFFFFFF),
                             "wave_path_packets": int(tl[i, 6]) if tl[i, 3] > 0 else 0,
                             "first_round_us": float(tl[i, 6]) / 100.0 if tl[i, 3] == 0 else None,   # light items: start -> end of the first round (round_packets iterations)
                             "shader_clock_ghz": float((tl[i, 7] >> 32) / max(1e-9, (mid[i] - start[i]) * 1e3)) if tl[i, 3] == 0 else None,   # light items: cycles / wall time
