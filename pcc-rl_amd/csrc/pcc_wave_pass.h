@@ -738,6 +738,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
     while ((st.t[0] < st.t[1] ? st.t[0] : st.t[1]) < end) {
         if (++guard > kMaxPasses) { st.flags |= PCC_FLAG_INTERNAL; break; }
         const uint64_t dbg_c0 = prof_counters(D) ? __builtin_readcyclecounter() : 0;
+        uint32_t dbg_sweeps256 = 0;
         // ---- token pass, up to 256 packets: the queue stays backlogged in one binade (heavy_mi's regime B, here for the
         // merged stream; lane l owns the positions 4 l .. 4 l + 3 = one Philox block).  Every quantity is a multiple of
         // u = ulp(q): the queue in front of merged position p is x_p = Q0 + j_p R - D_p (j_p packets accepted before it,
@@ -746,9 +747,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
         // map per position -- uneven token arrivals, because the two senders' send times interleave unevenly -- and the maps
         // compose by one prefix scan (lind_exclusive_scan).  A position whose queue runs empty or leaves the binade ends the
         // pass in front of it; the accept chain below (no such precondition, 64 packets) takes over from there.
-        if (chain_left) {
-            chain_left--;
-        } else {
+        {
             constexpr uint32_t kPass = 4u * kWave;
             double G2[2];
             bool okb = true;
@@ -769,8 +768,14 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             const uint32_t e = exponent_bits(st.q), eb = exponent_bits(ebw);
             const double T0 = st.t[0] <= st.t[1] ? st.t[0] : st.t[1];
             const double x0 = st.q - (T0 - st.tu);
-            okb = okb && (st.tu + st.tu >= tend_max) && (st.q > 0.0) && e > 64u && e < 1100u && (x0 > 0.0) && eb <= e &&
+            okb = okb && (st.tu + st.tu >= tend_max);
+            // ---- sweep pass (below): the same 256 positions decided by the accept chain side by side; it needs the send
+            // times and the drains exact (tu >= maxq), not the queue in one binade.  Taken for the passes after a token
+            // pass that stopped early, and when the token pass is refused.
+            const bool oks = kRelaxSweeps != 0 && okb && (st.tu >= maxq);
+            okb = okb && chain_left == 0u && (st.q > 0.0) && e > 64u && e < 1100u && (x0 > 0.0) && eb <= e &&
                   exponent_bits(st.tu) >= e && exponent_bits(maxq) >= e;
+            if (chain_left) chain_left--;
             if (kProfile && !okb) {
                 uint32_t why = 0;
 #pragma unroll
@@ -812,7 +817,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                 }
             }
             if (kProfile && !okb && !(st.prof_why & 0x3FFu)) st.prof_why |= 1024u;   // (the grid of u: a tie on odd multiples, a span too wide)
-            if (okb) {
+            if (okb || oks) {
                 const uint32_t sent_all = st.sent[0] + st.sent[1];
                 const uint32_t skip = sent_all & 3u;   // positions of lane 0's Philox block that were sent before this pass
                 const int kbase = 4 * (int)lane - (int)skip;   // packet index (within the pass) of this lane's position 0
@@ -866,7 +871,42 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                 // ---- accept decisions
                 uint32_t acc4 = 0;
                 int jb = 0;   // packets accepted before the lane's first position
-                if (free_mode) {
+                double xq[4] = {0.0, 0.0, 0.0, 0.0};   // the queue in front of every position (ns:66-67 before max0)
+                double sw_q = 0.0, sw_t = 0.0;         // sweep pass: the link state behind the lane's four positions
+                uint32_t flag4 = 0;
+                if (!okb) {
+                    // ---- sweep pass.  Every lane holds the link state behind its four positions; one sweep = the lane takes
+                    // the state behind the lane below it (lane 0: the state the pass starts from), sends its positions one
+                    // after the other (ns:66-82; a packet lost at random, refused by the full queue or not of this pass hands
+                    // the state on) and keeps what is behind them.  After sweep i the lanes 0 .. i-1 are final, so 64 sweeps are
+                    // the serial recurrence bit for bit; a sweep that moves no lane's state has reached that fixed point early.
+                    // The first guess is "the lane below left the queue drained", which is right wherever a busy period ends
+                    // inside a lane: sweep i then settles the busy periods that span i lanes, all of them at once -- a link
+                    // that keeps running empty (what stops the token pass) takes two or three sweeps for its 256 packets.
+                    double iq = 0.0, it = st.tu;
+                    for (uint32_t sweep = 0; sweep <= kWave; sweep++) {
+                        if (sweep) { iq = wave_shr1_f64(sw_q, st.q); it = wave_shr1_f64(sw_t, st.tu); }
+                        double q = iq, t = it;
+                        uint32_t a4n = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const double qc = max0(q - (tk[i] - t));
+                            const bool m = (m4 >> i) & 1u;
+                            const bool a = m && !(ebw + qc > maxq);
+                            xq[i] = qc;
+                            a4n |= (a ? 1u : 0u) << i;
+                            q = a ? ebw + qc : q;
+                            t = a ? tk[i] : t;
+                        }
+                        const bool moved = __double_as_longlong(q) != __double_as_longlong(sw_q) ||
+                                           __double_as_longlong(t) != __double_as_longlong(sw_t) || sweep == 0u;
+                        sw_q = q;
+                        sw_t = t;
+                        acc4 = a4n;
+                        if (kProfile) dbg_sweeps256++;
+                        if (sweep && !__ballot(moved)) break;
+                    }
+                } else if (free_mode) {
                     acc4 = m4;
 #pragma unroll
                     for (int i = 0; i < 4; i++) jb += (int)count_below(__ballot((acc4 >> i) & 1u));
@@ -905,13 +945,13 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                     }
                 }
                 // ---- the queue in front of every position, exactly; positions that break a precondition
-                uint32_t flag4 = 0;
-                {
+                if (okb) {
                     int j = jb;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int64_t xi = Q0i + (int64_t)j * Ri - Dp[i];
                         const double x = (double)xi * u;   // exact
+                        xq[i] = x;
                         const double sx = x + R;           // the queue behind this packet if it is accepted (ns:82)
                         const uint32_t es = exponent_bits(sx);
                         const bool m = (m4 >> i) & 1u;
@@ -929,9 +969,16 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                     p_stop = 4u * ls + rl_u32(((uint32_t)__ffs((int)stop4) - 1u) & 3u, ls);
                 }
                 const uint32_t ncommit = p_stop - skip;
-                if (p_stop < kPass && ncommit < 32u) chain_left = 2u;   // q hovers around a binade edge or keeps running empty
-                if (kProfile) st.prof_closed++;
-                if (prof_counters(D) && lane == 0) {   // (profile build: token passes / their packets / their cycles)
+                // q hovers around a binade edge or keeps running empty: the next passes by sweeps
+                if (okb && p_stop < kPass && ncommit < 32u) chain_left = oks ? 3u : 2u;
+                if (kProfile) st.prof_closed += okb ? 1u : 0x100u;   // (token passes in the low byte, sweep passes above)
+                if (prof_counters(D) && lane == 0 && !okb) {   // (profile build: sweep passes / their packets / sweeps / cycles)
+                    atomicAdd(&D.pass_stats[2], 1ull);
+                    atomicAdd(&D.pass_stats[6], (unsigned long long)ncommit);
+                    atomicAdd(&D.pass_stats[8], (unsigned long long)dbg_sweeps256);
+                    atomicAdd(&D.pass_stats[14], (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));
+                }
+                if (prof_counters(D) && lane == 0 && okb) {   // (profile build: token passes / their packets / their cycles)
                     atomicAdd(&D.pass_stats[1], 1ull);
                     atomicAdd(&D.pass_stats[5], (unsigned long long)ncommit);
                     atomicAdd(&D.pass_stats[13], (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));
@@ -975,7 +1022,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                             const uint32_t kind = 2u * (sdr ? 1u : 0u) + (a ? 0u : 1u);
                             const uint32_t idx = (uint32_t)(before >> (16u * kind)) & 0xFFFFu;
                             before += 1ull << (16u * kind);
-                            const double x = (double)(Q0i + (int64_t)j * Ri - Dp[i]) * u;   // exact (as above)
+                            const double x = xq[i];
                             double2 rec;
                             rec.y = dl + max0(x);         // ns:66-67, 170
                             rec.x = tk[i] + rec.y;        // ns:174
@@ -983,7 +1030,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                             const uint32_t off = a ? ((((sdr ? st.a[1] : st.a[0]) + idx) << 4) & ((cp - 1u) << 4))
                                                    : (cp << 4) + ((((sdr ? st.d[1] : st.d[0]) + idx) << 4) & ((2u * cp - 1u) << 4));
                             st_rec(reinterpret_cast<double2 *>((sdr ? base1 : base0) + off), rec);
-                            if ((m4 >> i) & 1u) { have_last = true; last_t = tk[i]; last_q = a ? x + R : x; }   // ns:75-82
+                            if ((m4 >> i) & 1u) { have_last = true; last_t = tk[i]; last_q = a ? x + (okb ? R : ebw) : x; }   // ns:75-82
                         }
                         j += a ? 1 : 0;
                     }

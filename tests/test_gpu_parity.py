@@ -375,6 +375,24 @@ def test_two_sender_philox_batches_match_oracle(knobs):
     env.close()
 
 
+def test_two_sender_wave_path_across_powers_of_two_in_time_matches_oracle():
+    """160 intervals of overdriven two-sender envs sent by the wave path alone: every env's send times cross 1, 2, 4, 8 ...
+    seconds inside some interval.  A pass of heavy_mi2 ends at the top of the binade of the send times (t0 + k G is exact
+    only below it) and the next send time is ns:161 on the last packet's time -- round 6; before, such an interval fell back
+    to 62 packets per pass."""
+    n_envs, n_steps, seed = 256, 160, 47
+    env = pcc_rl_amd.BatchedNetworkEnv(n_envs, device=DEV, seed=seed, n_senders=2, record_steps=True, auto_reset=False)
+    env.set_tuning(takeover_lanes=64, round_packets=4, heavy_predict=100.0)
+    env.reset()
+    rs = np.random.RandomState(seed)
+    acts = rs.uniform(-0.6, 1.6, (n_envs, n_steps, 2))
+    steps, obs, done = run_gpu(env, acts, n_steps)
+    ref = oracle.run_batch(acts, n_senders=2, rng_mode=oracle.RNG_PHILOX, seed=seed)
+    assert np.array_equal(steps, ref["steps"])
+    assert np.array_equal(obs, ref["obs"].astype(np.float32))
+    env.close()
+
+
 def test_two_sender_wave_path_on_golden_trace():
     d = load("two_sender")
     d["features"] = np.array(pcc_rl_amd.DEFAULT_FEATURES.split(","))

@@ -2,8 +2,8 @@
 """Counters of the send half's wave passes on the bench workload (GPU box only).
 usage: PCC_DEBUG_TIMELINE=1 pass_stats.py '[{knobs}, ...]' [n_envs] [steps] [senders]
 With two senders the slots read: pass_empty/pk_empty = chain passes settled side by side, pass_scan/pk_scan = token passes,
-pass_free/pk_free = chain passes sent serially, pass_serial/pk_serial = plain recurrence, scan_nothing_committed = sweeps of the
-settled passes, cycles_committed = token passes' cycles, cycles_serial = the other passes' cycles."""
+pass_free/pk_free = 256-packet sweep passes, pass_serial/pk_serial = plain recurrence, scan_nothing_committed = sweeps of
+both kinds, cycles_committed = token passes' cycles, cycles_serial = the other passes' cycles."""
 import json, os, sys
 os.environ.setdefault("PCC_DEBUG_TIMELINE", "2")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The slowest wave-path items of the send launch and the passes they ran (GPU box, profile build).
-   PCC_DEBUG_TIMELINE=1 python tools/slow_wave_items.py [n_envs] [senders]
-A row per item: start and finish (us from the launch's first stamp), envs, packets, closed-form (token) passes, chain passes,
+   PCC_DEBUG_TIMELINE=1 python tools/slow_wave_items.py [n_envs] [senders] [episodes] [rows]
+A row per item: start and finish (us from the launch's first stamp), envs, packets, closed-form (token) passes, 256-packet sweep passes (two senders), chain passes,
 plain-recurrence passes, ns per packet."""
 import json, os, sys
 os.environ.setdefault("PCC_DEBUG_TIMELINE", "1")
@@ -21,12 +21,15 @@ def why_names(m):
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+EPS = int(sys.argv[3]) if len(sys.argv) > 3 else 1     # episodes (auto-reset on): the link parameters are drawn again at every reset
+TOP = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 dev = torch.device("cuda:0")
 env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, n_senders=S)
 gen = torch.Generator(device=dev).manual_seed(1234)
 acts = torch.rand((400, N, S), generator=gen, device=dev) * 2 - 1
 env.reset()
-for t in range(400):
+for tt in range(400 * EPS):
+    t = tt % 400
     env.step_send(acts[t])
     if t in (100, 200, 300):
         raw = env.debug_timeline().astype(np.int64)
@@ -39,19 +42,19 @@ for t in range(400):
         light = np.nonzero(live & (tl[:, 3] == 0))[0]
         fin = (tl[:, 2] - t0) / 100.0
         rows = []
-        for i in wave[np.argsort(-fin[wave])[:12]]:
+        for i in wave[np.argsort(-fin[wave])[:TOP]]:
             w7 = int(tl[i, 7])
             dur = (tl[i, 2] - tl[i, 0]) / 100.0
             rows.append({"start": round((tl[i, 0] - t0) / 100.0, 1), "finish": round(float(fin[i]), 1), "envs": int(tl[i, 3] & 0xFFFF),
-                         "packets": int(tl[i, 4]), "closed": (w7 >> 8) & 0xFFFF, "chain": (w7 >> 24) & 0xFFFF, "plain": (w7 >> 40) & 0xFFFF,
+                         "packets": int(tl[i, 4]), "closed": (w7 >> 8) & 0xFF, "sweep256": (w7 >> 16) & 0xFF, "chain": (w7 >> 24) & 0xFFFF, "plain": (w7 >> 40) & 0xFFFF,
                          "ns_per_packet": round(1e3 * dur / max(1, int(tl[i, 4])), 1), "refused_by": why_names(int(tl[i, 5]) >> 32)})
         # every single-env item: ns per packet against the share of its packets the chain sent (62 per pass)
         one = wave[(tl[wave, 3] & 0xFFFF) == 1]
         pk = tl[one, 4].astype(np.float64)
         dur = (tl[one, 2] - tl[one, 0]) / 100.0
         chain = ((tl[one, 7] >> 24) & 0xFFFF).astype(np.float64)
-        closed = ((tl[one, 7] >> 8) & 0xFFFF).astype(np.float64)
-        print(json.dumps({"step": t, "span_us": round(float(fin[live].max()), 1), "light_last_us": round(float(fin[light].max()), 1) if len(light) else None,
+        closed = (((tl[one, 7] >> 8) & 0xFF) + ((tl[one, 7] >> 16) & 0xFF)).astype(np.float64)
+        print(json.dumps({"episode": tt // 400, "step": t, "span_us": round(float(fin[live].max()), 1), "light_last_us": round(float(fin[light].max()), 1) if len(light) else None,
                           "wave_items": int(len(wave)), "single_env_items": int(len(one)),
                           "single_env_us_total": round(float(dur.sum()), 0), "single_env_us_in_items_with_chain": round(float(dur[chain > 0].sum()), 0),
                           "single_env_items_with_chain": int((chain > 0).sum()),
