@@ -201,7 +201,7 @@ __device__ __forceinline__ void light_packet(LightState &S, const bool lost, con
 // 0 first, the heap's order; ns:42-43).  Ring indices times 16, per sender.
 struct Light2State {
     double q, tu, nsend[2];
-    uint32_t a4[2], d4[2], sent[2];
+    uint32_t a4[2], d4[2];   // ring positions in bytes; the packets a sender sent in the rounds are their growth / 16
 };
 __device__ __forceinline__ void light_packet2(Light2State &S, const bool lost, const double dl, const double maxq, const double ebw,
                                               const double gap0, const double gap1, char *base0, char *base1, const uint32_t mask_b0,
@@ -209,6 +209,7 @@ __device__ __forceinline__ void light_packet2(Light2State &S, const bool lost, c
                                               const uint32_t cap_b1) {
     const bool s1 = S.nsend[1] < S.nsend[0];
     const double t = s1 ? S.nsend[1] : S.nsend[0];
+    const double n0 = S.nsend[0] + gap0, n1 = S.nsend[1] + gap1;   // ns:161 for whichever of the two sends
     const double qcur = max0(S.q - (t - S.tu));
     const double grown = qcur + ebw;
     const double lat0 = dl + qcur;            // ns:170
@@ -223,13 +224,13 @@ __device__ __forceinline__ void light_packet2(Light2State &S, const bool lost, c
     const uint32_t a4 = s1 ? S.a4[1] : S.a4[0], d4 = s1 ? S.d4[1] : S.d4[0];
     const uint32_t off_a = a4 & (s1 ? mask_b1 : mask_b0), off_d = (s1 ? cap_b1 : cap_b0) + (d4 & (s1 ? dmask_b1 : dmask_b0));
     st_rec(reinterpret_cast<double2 *>((s1 ? base1 : base0) + (dropped ? off_d : off_a)), rec);
+    // the sender's ring position by multiply-adds with 0 / 1 (v_mad_u32_u24), not by four more selects
+    const uint32_t is1 = s1 ? 1u : 0u, is0 = 1u - is1;
     const uint32_t inc_d = dropped ? 16u : 0u, inc_a = 16u - inc_d;
-    S.a4[0] += s1 ? 0u : inc_a; S.a4[1] += s1 ? inc_a : 0u;
-    S.d4[0] += s1 ? 0u : inc_d; S.d4[1] += s1 ? inc_d : 0u;
-    S.sent[0] += s1 ? 0u : 1u; S.sent[1] += s1 ? 1u : 0u;            // ns:260-262
-    const double next = t + (s1 ? gap1 : gap0);                     // ns:161
-    S.nsend[0] = s1 ? S.nsend[0] : next;
-    S.nsend[1] = s1 ? next : S.nsend[1];
+    S.a4[0] = __umul24(inc_a, is0) + S.a4[0]; S.a4[1] = __umul24(inc_a, is1) + S.a4[1];
+    S.d4[0] = __umul24(inc_d, is0) + S.d4[0]; S.d4[1] = __umul24(inc_d, is1) + S.d4[1];   // ns:260-262
+    S.nsend[0] = s1 ? S.nsend[0] : n0;
+    S.nsend[1] = s1 ? n1 : S.nsend[1];
 }
 #ifndef PCC_LIGHT_BLOCKS
 #define PCC_LIGHT_BLOCKS 1
@@ -459,7 +460,7 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
 #pragma unroll
                     for (int s2 = 0; s2 < 2; s2++) {
                         const int s = s2 < NS ? s2 : 0;
-                        S.nsend[s2] = nsend[s]; S.a4[s2] = ta[s] << 4; S.d4[s2] = td[s] << 4; S.sent[s2] = sent[s];
+                        S.nsend[s2] = nsend[s]; S.a4[s2] = ta[s] << 4; S.d4[s2] = td[s] << 4;
                     }
                     const uint32_t a4_0[2] = {S.a4[0], S.a4[1]}, d4_0[2] = {S.d4[0], S.d4[1]};
                     const double ah0 = (end - S.nsend[0]) / gap[0] - 2.0, ah1 = (end - S.nsend[1]) / gap[NS - 1] - 2.0;
@@ -493,7 +494,8 @@ __device__ __forceinline__ uint64_t send_light_item(const Dev &D, const uint32_t
 #pragma unroll
                     for (int s2 = 0; s2 < 2; s2++) {
                         if (s2 < NS) {
-                            nsend[s2 < NS ? s2 : 0] = S.nsend[s2]; sent[s2 < NS ? s2 : 0] = S.sent[s2];
+                            nsend[s2 < NS ? s2 : 0] = S.nsend[s2];
+                            sent[s2 < NS ? s2 : 0] += ((S.a4[s2] - a4_0[s2]) + (S.d4[s2] - d4_0[s2])) >> 4;   // (far fewer than 2^27 an interval)
                             ta[s2 < NS ? s2 : 0] += (S.a4[s2] - a4_0[s2]) >> 4; td[s2 < NS ? s2 : 0] += (S.d4[s2] - d4_0[s2]) >> 4;
                         }
                     }

@@ -23,6 +23,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 EPS = int(sys.argv[3]) if len(sys.argv) > 3 else 1     # episodes (auto-reset on): the link parameters are drawn again at every reset
 TOP = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+STEPS = tuple(int(v) for v in os.environ.get("PCC_TL_STEPS", "100,200,300").split(","))   # steps of an episode to look at
 dev = torch.device("cuda:0")
 env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, n_senders=S)
 gen = torch.Generator(device=dev).manual_seed(1234)
@@ -31,7 +32,7 @@ env.reset()
 for tt in range(400 * EPS):
     t = tt % 400
     env.step_send(acts[t])
-    if t in (100, 200, 300):
+    if t in STEPS:
         raw = env.debug_timeline().astype(np.int64)
         tl = raw[:2 * N].copy()
         if N >= 32768:
