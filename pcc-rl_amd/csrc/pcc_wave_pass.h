@@ -768,12 +768,12 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             const uint32_t e = exponent_bits(st.q), eb = exponent_bits(ebw);
             const double T0 = st.t[0] <= st.t[1] ? st.t[0] : st.t[1];
             const double x0 = st.q - (T0 - st.tu);
-            okb = okb && (st.tu + st.tu >= tend_max);
-            // ---- sweep pass (below): the same 256 positions decided by the accept chain side by side; it needs the send
-            // times and the drains exact (tu >= maxq), not the queue in one binade.  Taken for the passes after a token
-            // pass that stopped early, and when the token pass is refused.
-            const bool oks = kRelaxSweeps != 0 && okb && (st.tu >= maxq);
-            okb = okb && chain_left == 0u && (st.q > 0.0) && e > 64u && e < 1100u && (x0 > 0.0) && eb <= e &&
+            // ---- sweep pass (below): the same 256 positions decided by the plain recurrence, lane after lane.  It evaluates the
+            // reference's expressions on the reference's operands (ns:66-82), so all it needs is the positions' send times
+            // (the conditions above) -- not exact drains, not the queue in one binade.  Taken for the passes after a token
+            // pass that stopped early, and whenever the token pass is refused.
+            const bool oks = kRelaxSweeps != 0 && okb;
+            okb = okb && (st.tu + st.tu >= tend_max) && chain_left == 0u && (st.q > 0.0) && e > 64u && e < 1100u && (x0 > 0.0) && eb <= e &&
                   exponent_bits(st.tu) >= e && exponent_bits(maxq) >= e;
             if (chain_left) chain_left--;
             if (kProfile && !okb) {
@@ -877,8 +877,8 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                 if (!okb) {
                     // ---- sweep pass.  Every lane holds the link state behind its four positions; one sweep = the lane takes
                     // the state behind the lane below it (lane 0: the state the pass starts from), sends its positions one
-                    // after the other (ns:66-82; a packet lost at random, refused by the full queue or not of this pass hands
-                    // the state on) and keeps what is behind them.  After sweep i the lanes 0 .. i-1 are final, so 64 sweeps are
+                    // after the other (ns:66-82: a packet lost at random or not of this pass hands the state on, one refused by
+                    // the full queue leaves it drained to its send time, an accepted one adds 1/bw) and keeps what is behind them.  After sweep i the lanes 0 .. i-1 are final, so 64 sweeps are
                     // the serial recurrence bit for bit; a sweep that moves no lane's state has reached that fixed point early.
                     // The first guess is "the lane below left the queue drained", which is right wherever a busy period ends
                     // inside a lane: sweep i then settles the busy periods that span i lanes, all of them at once -- a link
@@ -895,8 +895,8 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                             const bool a = m && !(ebw + qc > maxq);
                             xq[i] = qc;
                             a4n |= (a ? 1u : 0u) << i;
-                            q = a ? ebw + qc : q;
-                            t = a ? tk[i] : t;
+                            q = m ? (a ? ebw + qc : qc) : q;   // ns:75-82
+                            t = m ? tk[i] : t;                 // ns:76
                         }
                         const bool moved = __double_as_longlong(q) != __double_as_longlong(sw_q) ||
                                            __double_as_longlong(t) != __double_as_longlong(sw_t) || sweep == 0u;
@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
         }
         // ---- per-sender send sequences: t0 + k*G, exact while the preconditions hold
         double G[2];
-        bool ok = (st.tu >= maxq);
+        bool ok = kRelaxSweeps != 0 || (st.tu >= maxq);   // (the sweeps below are the plain recurrence: exact drains are not needed)
         double tend_max = 0.0, lim = end;   // (lim: the interval's end or the top of the lower binade of the two send times)
 #pragma unroll
         for (int s = 0; s < 2; s++) {
@@ -1080,7 +1080,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                  (G[s] > 0.0);
             tend_max = tend > tend_max ? tend : tend_max;
         }
-        ok = ok && (st.tu + st.tu >= tend_max);
+        ok = ok && (kRelaxSweeps != 0 || st.tu + st.tu >= tend_max);
         if (kProfile && !ok) {
             uint32_t why = st.tu >= maxq ? 0u : 0x10000u;
 #pragma unroll
@@ -1137,11 +1137,11 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
             double qc = 0.0;
             if (kRelaxSweeps != 0) {
                 // ---- phase 1, side by side.  Every lane holds the link state (queue, time of the last update) BEHIND its
-                // packet: an accepted packet leaves (1/bw + the queue it found, its send time), any other packet -- lost at
-                // random, refused by the full queue, past the interval's end -- hands on what it was given, which is what
-                // the chain from accepted packet to accepted packet does by skipping it.  One sweep = every lane takes the
+                // packet (ns:72-84): an accepted packet leaves (1/bw + the queue it found, its send time), one refused by the
+                // full queue leaves the queue drained to its send time, one lost at random or past the interval's end hands
+                // on what it was given.  One sweep = every lane takes the
                 // state of the lane below it (lane 0: the state the pass started from) and redoes its own packet; after
-                // sweep i the lanes 0 .. i-1 are final, so nv sweeps are the serial result bit for bit (the same
+                // sweep i the lanes 0 .. i-1 are final, so nv sweeps are the plain recurrence bit for bit (the same
                 // expressions on the same operands), and a sweep that moves nothing has reached that fixed point early:
                 // a packet that finds the queue drained leaves (1/bw, t_k) whatever came before it, so with the guess
                 // "everybody found it drained" sweep i settles the i-th packet of EVERY busy period of the pass at once.
@@ -1157,8 +1157,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                         const double iq = wave_shr1_f64(oq, st.q), it = wave_shr1_f64(ot, st.tu);
                         qc = max0(iq - (tk - it));
                         full = ebw + qc > maxq;
-                        const bool acc = mine && !full;
-                        const double nq = acc ? ebw + qc : iq, nt = acc ? tk : it;
+                        const double nq = mine ? (full ? qc : ebw + qc) : iq, nt = mine ? tk : it;   // ns:75-82
                         if (r == 3)
                             moved = valid && (__double_as_longlong(nq) != __double_as_longlong(oq) ||
                                               __double_as_longlong(nt) != __double_as_longlong(ot));
