@@ -362,7 +362,11 @@ __device__ __forceinline__ bool near_time(double a, double b) {
 typedef double gvec2 __attribute__((ext_vector_type(2)));
 #define PCC_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ double2 ld_rec(const double2 *p) {
+#if defined(PCC_NT_LD) && PCC_NT_LD   // (experiment: the records are read once -- nontemporal loads)
+    const gvec2 v = __builtin_nontemporal_load((const PCC_GLOBAL gvec2 *)(const void *)p);
+#else
     const gvec2 v = *(const PCC_GLOBAL gvec2 *)(const void *)p;
+#endif
     double2 r;
     r.x = v.x; r.y = v.y;
     return r;
@@ -370,9 +374,51 @@ __device__ __forceinline__ double2 ld_rec(const double2 *p) {
 __device__ __forceinline__ void st_rec(double2 *p, const double2 &r) {
     gvec2 v;
     v.x = r.x; v.y = r.y;
+#if defined(PCC_NT_ST) && PCC_NT_ST   // (experiment: every record store nontemporal -- the lane rounds' too: 3x slower)
+    __builtin_nontemporal_store(v, (PCC_GLOBAL gvec2 *)(void *)p);
+#else
     *(PCC_GLOBAL gvec2 *)(void *)p = v;
+#endif
 }
+// ---- nontemporal record stores (round 6).  A record store that fills whole ring lines -- the wave path's staged runs: 1 KB of
+// consecutive ring bytes per instruction -- is issued nontemporal (`global_store_dwordx4 ... nt`).  Measured, not derived: the
+// send launch is unchanged and the RETIRE launch that reads the records one to three launches later is 8-10 % faster
+// (0.0892 -> 0.0813 ms at 65 536 envs, tools/ab_libraries.py, profiles/r06_nontemporal.json): the streamed lines do not
+// displace the env and sender blocks both launches re-read every step.  The lane rounds' scattered 16-byte stores must NOT be
+// nontemporal: they become partial writes to memory (send launch 0.091 -> 0.287 ms), and so must not the position-by-position
+// stores of a pass (two senders: 0.170 -> 0.312 ms) -- hence st_rec_run only where a wavefront writes runs of whole lines.
+// Loads: nontemporal loads of the records in the retire half pin its launch at 0.087 ms whatever the box's mode (0.085 / 0.090)
+// and gain nothing on top of the stores; -DPCC_NT_LD=1 / 2 builds them.  -DPCC_NT_RUN=0 builds plain stores.
+#ifndef PCC_NT_RUN
+#define PCC_NT_RUN 1
+#endif
+__device__ __forceinline__ void st_rec_nt(double2 *p, const double2 &r) {
+    gvec2 v;
+    v.x = r.x; v.y = r.y;
+    __builtin_nontemporal_store(v, (PCC_GLOBAL gvec2 *)(void *)p);
+}
+// a record of a run of consecutive ring slots written by consecutive lanes (whole ring lines per instruction)
+__device__ __forceinline__ void st_rec_run(double2 *p, const double2 &r) {
+#if PCC_NT_RUN
+    st_rec_nt(p, r);
+#else
+    st_rec(p, r);
+#endif
+}
+// a record of a wave pass stored position by position: neighbouring lanes write neighbouring slots of a few dense runs and four
+// instructions fill the lines between them -- plain stores (see above; -DPCC_NT_RUN=2 is the experiment)
+__device__ __forceinline__ void st_rec_pass(double2 *p, const double2 &r) {
+#if PCC_NT_RUN >= 2
+    st_rec_nt(p, r);
+#else
+    st_rec(p, r);
+#endif
+}
+#if defined(PCC_NT_LD) && PCC_NT_LD >= 2
+__device__ __forceinline__ double ld_f64(const void *p) { return __builtin_nontemporal_load((const PCC_GLOBAL double *)p); }
+#else
 __device__ __forceinline__ double ld_f64(const void *p) { return *(const PCC_GLOBAL double *)p; }
+#endif
 __device__ __forceinline__ double ld_t1(const double2 *p) { return ld_f64(p); }  // .x of a record
 
 // the rings of one sender: accepted ring of `cap` records at base, dropped ring of 2 * cap after it

@@ -30,7 +30,7 @@ struct SendLds {
     EnvSlot<NS> slots[4][kSlots];      // send_wave_item's parked envs, per wavefront
     uint32_t tab[4][6][kClasses];      // wave_body's class table, per wavefront
     TeamX team;                        // what the wavefronts of a team pass tell each other
-    double2 stage[4][(NS == 1 ? POS : 0) * kWave + 1];   // heavy_mi<.., STAGE> (one sender): the records of a closed-form pass on their way out, per wavefront
+    double2 stage[4][POS * kWave + 1];   // heavy_mi / heavy_mi2 <.., STAGE>: the records of a 256-position pass on their way out, per wavefront
 };
 #ifndef PCC_STAGE_RECORDS
 #define PCC_STAGE_RECORDS 1
@@ -102,7 +102,7 @@ __device__ __forceinline__ void light_body(const Dev &D, LDS &lds, const uint32_
             // the item's last lanes (see send_light_item) go on by the wave path, from the state the item just stored: what
             // one lane wrote is read by others of this wavefront -- a workgroup-scope fence orders that (same L1)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            (void)send_wave_item<NS, TRACE, 1, kStageRecords && NS == 1>(D, lane, i, ((left >> lane) & 1ull) != 0ull, false, 0xFFFFFFFFu, warm, warm_mi,
+            (void)send_wave_item<NS, TRACE, 1, kStageRecords>(D, lane, i, ((left >> lane) & 1ull) != 0ull, false, 0xFFFFFFFFu, warm, warm_mi,
                                                                          actions, actions_f64, lds.slots[wv], 0u, nullptr, false, nullptr, lds.stage[wv]);
         }
         if (prio) set_prio(0u);
@@ -181,7 +181,7 @@ __device__ __forceinline__ void wave_body(const Dev &D, LDS &lds, const uint32_t
                     const uint32_t off = tt - (uni_u32(tab[4][L]) - uni_u32(tab[5][L]));
                     const uint32_t *list = cls_list_of(D, view, kClasses - 1u - L);
                     const int64_t i = lane == 0 ? (int64_t)list[off] : 0;
-                    (void)send_wave_item<NS, TRACE, kTeams ? kTeamMax : 1, kStageRecords && NS == 1>(D, lane, i, lane == 0, true, tl_base + n_items + tt < tl_end ? tl_base + n_items + tt : 0xFFFFFFFFu, 0, 0, actions,
+                    (void)send_wave_item<NS, TRACE, kTeams ? kTeamMax : 1, kStageRecords>(D, lane, i, lane == 0, true, tl_base + n_items + tt < tl_end ? tl_base + n_items + tt : 0xFFFFFFFFu, 0, 0, actions,
                                                                            actions_f64, lds.slots[wv], wv, &lds.team, false, nullptr, lds.stage[wv]);
                     if constexpr (FUSED) {   // all four wavefronts stored records: each drains, then wavefront 0 publishes
                         fused_drain();
@@ -249,7 +249,7 @@ __device__ __forceinline__ void wave_body(const Dev &D, LDS &lds, const uint32_t
             const int64_t i = has ? (int64_t)list[idx] : 0;
             const bool prio = t < D.prio_wave_items;
             if (prio) set_prio(D.prio_level);
-            (void)send_wave_item<NS, TRACE, 1, kStageRecords && NS == 1, LDS::kPos>(D, lane, i, has, true, tl_base + t < tl_end ? tl_base + t : 0xFFFFFFFFu, 0, 0, actions, actions_f64, lds.slots[wv],
+            (void)send_wave_item<NS, TRACE, 1, kStageRecords, LDS::kPos>(D, lane, i, has, true, tl_base + t < tl_end ? tl_base + t : 0xFFFFFFFFu, 0, 0, actions, actions_f64, lds.slots[wv],
                                                                                        0u, nullptr, false, nullptr, lds.stage[wv]);
             if constexpr (FUSED) {
                 fused_drain();

@@ -576,7 +576,7 @@ __device__ __forceinline__ uint64_t uni_u64(uint64_t v) { return ((uint64_t)uni_
 // W > 1: a TEAM item -- one env (lane 0 of every wavefront names it) sent by the W wavefronts of the workgroup together
 // (heavy_mi<.., W>); every wavefront loads the env's state and computes everything alike, wavefront 0 writes.
 // Returns the packets the item sent (wave-uniform; the launch statistics of pcc_get_send_split).
-// STAGE / stage: the closed-form passes' records leave through 256 LDS slots of this wavefront (heavy_mi; one sender).
+// STAGE / stage: the 256-position passes' records leave through 256 LDS slots of this wavefront (heavy_mi, heavy_mi2).
 // P: positions per lane of the closed-form passes (heavy_mi; one sender).
 template <int NS, bool TRACE, int W, bool STAGE = false, int P = 4>
 __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t lane, const int64_t i, const bool in_range,
@@ -659,12 +659,12 @@ __device__ __forceinline__ uint32_t send_wave_item(const Dev &D, const uint32_t 
                         st.t[s] = nsend_new[s < NS ? s : 0]; st.a[s] = ta_new[s < NS ? s : 0]; st.d[s] = td_new[s < NS ? s : 0];
                         st.sent[s] = sent_new[s < NS ? s : 0];
                     }
-                    heavy_mi2<TRACE>(D, lane, uni_f64(S.dl), uni_f64(S.lr), uni_u32(S.thr), (bits & 1u) != 0u, uni_f64(S.maxq), uni_f64(S.ebw),
+                    heavy_mi2<TRACE, STAGE>(D, lane, uni_f64(S.dl), uni_f64(S.lr), uni_u32(S.thr), (bits & 1u) != 0u, uni_f64(S.maxq), uni_f64(S.ebw),
                                      uni_f64(S.gap[0]), uni_f64(S.gap[NS - 1]), uni_f64(S.end), uni_u32(S.episode), uni_u32(S.mi), uni_u32(S.gid),
                                      reinterpret_cast<const double *>(uni_u64(reinterpret_cast<uint64_t>(S.trace))),
                                      reinterpret_cast<char *>(uni_u64(reinterpret_cast<uint64_t>(S.base[0]))),
                                      reinterpret_cast<char *>(uni_u64(reinterpret_cast<uint64_t>(S.base[NS - 1]))),
-                                     uni_u32(S.cap[0]), uni_u32(S.cap[NS - 1]), st);
+                                     uni_u32(S.cap[0]), uni_u32(S.cap[NS - 1]), st, stage);
                     q_new = st.q; tu_new = st.tu; flags |= st.flags;
                     if (kProfile) { tl_closed += st.prof_closed; tl_other += st.prof_other; tl_env = (uint64_t)ie; tl_why |= st.prof_why; }
 #pragma unroll

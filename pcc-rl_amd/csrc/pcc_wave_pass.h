@@ -532,7 +532,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                             stage[a ? j - acc0 : (kWavePos - 1u) - ((kk - j) - drp0)] = rec;
                         } else {
                             const uint32_t off = a ? (((st.a + j) << 4) & mask_b) : cap_b + (((st.d + (kk - j)) << 4) & dmask_b);
-                            st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                            st_rec_pass(reinterpret_cast<double2 *>(base + off), rec);
                         }
                         if ((m4 >> i) & 1u) {
                             have_last = true;
@@ -555,9 +555,9 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     const uint32_t a0 = st.a + acc0, d0 = st.d + drp0, n_drp_w = n_com_w - n_acc_w;
                     for (uint32_t sl = lane; sl < n_acc_w; sl += kWave)
-                        st_rec(reinterpret_cast<double2 *>(base + (((a0 + sl) << 4) & mask_b)), stage[sl]);
+                        st_rec_run(reinterpret_cast<double2 *>(base + (((a0 + sl) << 4) & mask_b)), stage[sl]);
                     for (uint32_t sl = lane; sl < n_drp_w; sl += kWave)
-                        st_rec(reinterpret_cast<double2 *>(base + cap_b + (((d0 + sl) << 4) & dmask_b)), stage[(kWavePos - 1u) - sl]);
+                        st_rec_run(reinterpret_cast<double2 *>(base + cap_b + (((d0 + sl) << 4) & dmask_b)), stage[(kWavePos - 1u) - sl]);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();   // (the next pass stages into the same slots)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -701,7 +701,7 @@ __device__ __forceinline__ void heavy_mi(const Dev &D, uint32_t lane, const uint
                 rec.y = my_lat;
                 const uint32_t off = my_drop ? cap_b + (((st.d + (uint32_t)count_below(dm)) << 4) & dmask_b)
                                              : (((st.a + (uint32_t)count_below(am)) << 4) & mask_b);
-                st_rec(reinterpret_cast<double2 *>(base + off), rec);
+                st_rec_pass(reinterpret_cast<double2 *>(base + off), rec);
             }
             st.a += (uint32_t)__popcll(am);
             st.d += (uint32_t)__popcll(dm);
@@ -726,11 +726,14 @@ struct SendState2 {
     uint32_t prof_why;                 // profile build: which preconditions refused a token pass (bits 0-10) or the chain (16-20)
 };
 
-template <bool TRACE>
+// STAGE (round 6): the records of a 256-position pass leave through `stage` (256 LDS slots of this wavefront) as four runs
+// in ring order -- sender 0 accepted, sender 0 dropped, sender 1 accepted, sender 1 dropped -- and lane l stores slot 64 k + l of
+// a run: whole ring lines per instruction, nontemporal (st_rec_run).
+template <bool TRACE, bool STAGE = false>
 __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl, double lr, uint32_t thr, bool always,
                                           double maxq, double ebw, double gap0, double gap1, double end,
                                           uint32_t episode, uint32_t mi, uint32_t gid, const double *trace, char *base0,
-                                          char *base1, uint32_t cap0, uint32_t cap1, SendState2 &st) {
+                                          char *base1, uint32_t cap0, uint32_t cap1, SendState2 &st, double2 *stage = nullptr) {
     const uint32_t caps[2] = {cap0, cap1};
     const double gap[2] = {gap0, gap1};
     uint32_t chain_left = 0;  // passes to send by the accept chain before the token pass is tried again
@@ -1011,6 +1014,8 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                     }
                     const unsigned long long total = rl_u64(incl, kWave - 1u);
                     unsigned long long before = incl - cnt;
+                    const uint32_t a0n = (uint32_t)(total & 0xFFFFu), d0n = (uint32_t)((total >> 16) & 0xFFFFu);
+                    const uint32_t a1n = (uint32_t)((total >> 32) & 0xFFFFu), d1n = (uint32_t)((total >> 48) & 0xFFFFu);
                     double last_q = 0.0, last_t = 0.0;
                     bool have_last = false;
                     int j = jb;
@@ -1026,10 +1031,16 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                             double2 rec;
                             rec.y = dl + max0(x);         // ns:66-67, 170
                             rec.x = tk[i] + rec.y;        // ns:174
-                            const uint32_t cp = sdr ? cap1 : cap0;
-                            const uint32_t off = a ? ((((sdr ? st.a[1] : st.a[0]) + idx) << 4) & ((cp - 1u) << 4))
-                                                   : (cp << 4) + ((((sdr ? st.d[1] : st.d[0]) + idx) << 4) & ((2u * cp - 1u) << 4));
-                            st_rec(reinterpret_cast<double2 *>((sdr ? base1 : base0) + off), rec);
+                            if constexpr (STAGE) {
+                                // the run's first slot: the runs follow each other in the order of `kind`
+                                const uint32_t run0 = sdr ? (a ? a0n + d0n : a0n + d0n + a1n) : (a ? 0u : a0n);
+                                stage[run0 + idx] = rec;
+                            } else {
+                                const uint32_t cp = sdr ? cap1 : cap0;
+                                const uint32_t off = a ? ((((sdr ? st.a[1] : st.a[0]) + idx) << 4) & ((cp - 1u) << 4))
+                                                       : (cp << 4) + ((((sdr ? st.d[1] : st.d[0]) + idx) << 4) & ((2u * cp - 1u) << 4));
+                                st_rec_pass(reinterpret_cast<double2 *>((sdr ? base1 : base0) + off), rec);
+                            }
                             if ((m4 >> i) & 1u) { have_last = true; last_t = tk[i]; last_q = a ? x + (okb ? R : ebw) : x; }   // ns:75-82
                         }
                         j += a ? 1 : 0;
@@ -1040,8 +1051,27 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                         st.q = rl_f64(last_q, ll);
                         st.tu = rl_f64(last_t, ll);
                     }
-                    const uint32_t a0n = (uint32_t)(total & 0xFFFFu), d0n = (uint32_t)((total >> 16) & 0xFFFFu);
-                    const uint32_t a1n = (uint32_t)((total >> 32) & 0xFFFFu), d1n = (uint32_t)((total >> 48) & 0xFFFFu);
+                    if constexpr (STAGE) {
+                        // (what the lanes staged is read by other lanes of this wavefront: LDS accesses of one wavefront execute in
+                        // order; the barriers keep the compiler from moving them across)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int s = 0; s < 2; s++) {
+                            char *const bs = s ? base1 : base0;
+                            const uint32_t cp = s ? cap1 : cap0, an = s ? a1n : a0n, dn = s ? d1n : d0n;
+                            const uint32_t ra = s ? a0n + d0n : 0u, rd = ra + an;   // the two runs' first slots
+                            const uint32_t mask_b = (cp - 1u) << 4, dmask_b = (2u * cp - 1u) << 4, cap_b = cp << 4;
+                            for (uint32_t sl = lane; sl < an; sl += kWave)
+                                st_rec_run(reinterpret_cast<double2 *>(bs + (((st.a[s] + sl) << 4) & mask_b)), stage[ra + sl]);
+                            for (uint32_t sl = lane; sl < dn; sl += kWave)
+                                st_rec_run(reinterpret_cast<double2 *>(bs + cap_b + (((st.d[s] + sl) << 4) & dmask_b)), stage[rd + sl]);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();   // (the next pass stages into the same slots)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
                     // ns:161 on each sender's last packet's (exact) send time: the next one may be the first of a new binade
                     if (a0n + d0n) st.t[0] = (st.t[0] + (double)(a0n + d0n - 1u) * G2[0]) + gap[0];
                     if (a1n + d1n) st.t[1] = (st.t[1] + (double)(a1n + d1n - 1u) * G2[1]) + gap[1];
@@ -1226,7 +1256,7 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                 const uint32_t cap_b = caps[s] << 4, mask_b = (caps[s] - 1u) << 4, dmask_b = (2u * caps[s] - 1u) << 4;
                 const uint32_t off = my_drop ? cap_b + (((st.d[s] + (uint32_t)count_below(dm)) << 4) & dmask_b)
                                              : (((st.a[s] + (uint32_t)count_below(am)) << 4) & mask_b);
-                st_rec(reinterpret_cast<double2 *>((s ? base1 : base0) + off), rec);
+                st_rec_pass(reinterpret_cast<double2 *>((s ? base1 : base0) + off), rec);
             }
             st.a[s] += (uint32_t)__popcll(am);
             st.d[s] += (uint32_t)__popcll(dm);
