@@ -13,6 +13,7 @@
 //   9  1 without Philox (loss bits from a counter: WRONG results, a floor for "Philox off the lane round")
 // arg 3: probe wavefronts (1 024 = one per SIMD in workgroups of four; fewer: workgroups of one wavefront, e.g. 256 = one per compute unit, 32 = one per 8)
 // arg 2: neighbours per SIMD running variant 0 on envs of their own (0..3).
+// arg 5: lanes with packets per wavefront (64; 32 / 16: smaller lane-round items).
 #include "pcc_dev.h"
 #include <algorithm>
 #include <vector>
@@ -555,6 +556,14 @@ int main(int argc, char **argv) {
                 const int n = (w % 4 == 0) ? packets[e] : 40 + rand() % 41;
                 packets[e] = n;
                 hp[e].end = hp[e].t + ((double)n - 0.5) * hp[e].gap;
+            }
+    const int lanes = argc > 4 ? atoi(argv[4]) : 64;  // arg 5: lanes of a wavefront that have an env with packets (the others' intervals are empty):
+    if (lanes < 64)                                   // what would a lane-round item of 32 or 16 envs cost per iteration?
+        for (int w = 0; w < n_waves; w++)
+            for (int l = lanes; l < 64; l++) {
+                const int e = perm[w * 64 + l];
+                packets[e] = 0;
+                hp[e].end = hp[e].t;
             }
     EnvP *dP; EnvOut *dO; char *rings; uint32_t *dperm; long long *dt;
     CK(hipMalloc(&dP, sizeof(EnvP) * n_env)); CK(hipMemcpy(dP, hp.data(), sizeof(EnvP) * n_env, hipMemcpyHostToDevice));

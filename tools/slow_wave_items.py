@@ -29,6 +29,12 @@ env = pcc_rl_amd.BatchedNetworkEnv(N, device=dev, seed=0, n_senders=S)
 gen = torch.Generator(device=dev).manual_seed(1234)
 acts = torch.rand((400, N, S), generator=gen, device=dev) * 2 - 1
 env.reset()
+if os.environ.get("PCC_TL_STAGGER"):   # envs out of lockstep like `bench.py --stagger`: env i starts its episode at pre-roll step i % 400
+    phase = torch.arange(N, device=dev) % 400
+    for t in range(400):
+        if t:
+            env.reset(phase == t)
+        env.step(acts[t])
 for tt in range(400 * EPS):
     t = tt % 400
     env.step_send(acts[t])
