@@ -741,9 +741,11 @@ def main():
                 "records_per_s": 2.05e11, "GB/s": 3280.0, "frac_of_hbm_peak": 3280.0 / HBM_PEAK_GBPS,
                 "launch_average_records_per_s": N * pk_roof / (send_ms * 1e-3),
                 "launch_average_frac_of_ceiling": N * pk_roof / (send_ms * 1e-3) / 2.05e11,
-                "note": "supplementary: the rate at which the memory system takes scattered 16-byte records (profiles/r06_lane_round_microbench.txt); "
-                        "the launch average includes the serial tail of the longest lane-round items (profiles/r06_send_tail.json), "
-                        "during which that bandwidth idles"}
+                "note": "supplementary: the rate at which the memory system takes scattered 16-byte records = PARTIAL-LINE writes "
+                        "(profiles/r06_store_bw.txt: 3.0-3.25 TB/s; whole lines, dense or scattered, 5.1-6.6 TB/s; "
+                        "profiles/r06_lane_round_microbench.txt); only the lane rounds' records (45 % of a launch's) are written that "
+                        "way since round 6, the wave path's leave as whole lines; the launch average includes the serial tail of the "
+                        "longest lane-round items (profiles/r06_send_tail.json), during which that bandwidth idles"}
         # HBM traffic from the counters: measured now, by two profiled runs of this script (unless --no-pmc / not one GPU);
         # else the newest committed summary, labelled as such
         kname = out["roofline"]["kernel"]
