@@ -243,6 +243,12 @@ enum { PCC_TUNE_ROUND_PACKETS = 2, PCC_TUNE_TAKEOVER_LANES = 3,
                                     further items when there are more items than wavefronts.  0 (default) = the worst case, an item per
                                     wavefront.  32 = what stays resident next to 12 wave-path wavefronts per compute unit: measured no
                                     faster (profiles/r06_knob_sweeps.json) */,
+       PCC_TUNE_LIGHT_FRONT = 35 /* send launch: so many light workgroups per partition -- the ones with the longest lane-round items --
+                                    are dispatched in FRONT of the wave-path workgroups (block order); the rest behind them as before.
+                                    The launch ends with its longest lane-round items: in front they start ~5 us earlier (the
+                                    dispatcher places the wave-path workgroups first otherwise).  Default 6 (send launch 0.0893 ->
+                                    0.0864 ms at 65 536 envs); not applied to launches that carry restart items (out of lockstep: measured
+                                    slower).  Speed only */,
        PCC_TUNE_FUSED_DEBUG = 31 /* fused step, experiments: bit 0 (1) = an agent-scope release (buffer_wbl2) in front of every publication,
                                     bit 2 (4) = no retire work before every env is sent (the halves one after the other inside the launch);
                                     default 0 */ };

@@ -8,7 +8,7 @@ namespace pcc {
 
 // pcc_send.hip: both kinds of workgroup in one launch -- wave_wgs wave-path workgroups, then light_wgs light workgroups (with
 // lists both are multiples of Dev::parts: workgroup b works for partition b % parts).
-void launch_send(const Dev &d, bool trace, unsigned light_wgs, unsigned wave_wgs, hipStream_t st, int read_buf,
+void launch_send(const Dev &d, bool trace, unsigned light_wgs, unsigned wave_wgs, unsigned light_front, hipStream_t st, int read_buf,
                  int zero_buf, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64);
 // pcc_send_restart.hip.  grid: workgroups of 4 wavefronts, restart items dealt statically.
 void launch_send_restart(const Dev &d, bool trace, unsigned grid, hipStream_t st, int read_buf, const void *actions, int actions_f64);

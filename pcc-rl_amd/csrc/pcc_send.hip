@@ -29,7 +29,7 @@ namespace {
 template <int NS, bool TRACE>
 __global__ __launch_bounds__(4 * kWave, NS == 2 ? PCC_SEND_OCC2 : PCC_SEND_OCC) void send_kernel(Dev D, int read_buf, int zero_buf, int warm,
                                                                                        uint32_t warm_mi, int gate,
-                                                                                       uint32_t wave_wgs, const void *actions,
+                                                                                       uint32_t wave_wgs, uint32_t light_front, const void *actions,
                                                                                        int actions_f64) {
     const uint32_t lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // auto-reset launches of a step in which no env finished have nothing to do (envs at different
@@ -51,13 +51,15 @@ __global__ __launch_bounds__(4 * kWave, NS == 2 ? PCC_SEND_OCC2 : PCC_SEND_OCC) 
         light_body<NS, TRACE>(D, lds, lane, wv, b, gridDim.x, -1, 0u, warm, warm_mi, actions, actions_f64);
         return;
     }
+    // block order = dispatch order: light_front light workgroups (a multiple of P: the longest lane-round items of every partition),
+    // the wave-path workgroups, the other light workgroups.  A block's partition is b % P in all three ranges.
     const uint32_t P = D.parts, part = b % P;
-    if (b < wave_wgs) {
-        wave_body<NS, TRACE>(D, lds, lane, wv, wave_wgs, read_buf, actions, actions_f64);
+    if (b >= light_front && b < light_front + wave_wgs) {
+        wave_body<NS, TRACE>(D, lds, lane, wv, wave_wgs, read_buf, actions, actions_f64, 0u, b - light_front);
     } else {
         // profile build: the timeline slots of a partition's light items (at most part_envs / 32 + a partial one per class)
         const uint32_t tl_base = part * (D.part_envs / 32u + (uint32_t)kClasses + 1u);
-        light_body<NS, TRACE>(D, lds, lane, wv, (b - wave_wgs) / P, (gridDim.x - wave_wgs) / P, (int)list_view(D, read_buf, part), tl_base,
+        light_body<NS, TRACE>(D, lds, lane, wv, (b < light_front ? b : b - wave_wgs) / P, (gridDim.x - wave_wgs) / P, (int)list_view(D, read_buf, part), tl_base,
                               warm, warm_mi, actions, actions_f64);
     }
 }
@@ -66,11 +68,11 @@ __global__ __launch_bounds__(4 * kWave, NS == 2 ? PCC_SEND_OCC2 : PCC_SEND_OCC) 
 
 namespace pcc {
 
-void launch_send(const Dev &d, bool trace, unsigned light_wgs, unsigned wave_wgs, hipStream_t st, int read_buf,
+void launch_send(const Dev &d, bool trace, unsigned light_wgs, unsigned wave_wgs, unsigned light_front, hipStream_t st, int read_buf,
                  int zero_buf, int warm, uint32_t warm_mi, int gate, const void *actions, int actions_f64) {
 #define PCC_S(NS_, TR_)                                                                                                           \
     hipLaunchKernelGGL((send_kernel<NS_, TR_>), dim3(light_wgs + wave_wgs), dim3(4 * kWave), 0, st, d, read_buf, zero_buf, warm, warm_mi, \
-                       gate, wave_wgs, actions, actions_f64)
+                       gate, wave_wgs, light_front, actions, actions_f64)
     if (d.ns == 1) { if (trace) PCC_S(1, true); else PCC_S(1, false); }
     else { if (trace) PCC_S(2, true); else PCC_S(2, false); }
 #undef PCC_S

@@ -54,6 +54,7 @@ struct pcc_sim {
     void *noise_blob;   // heap + RTT samples of the latency-noise option (allocated when it is switched on)
     void *noise_out_blob;  // ... and the per-env results of the heap-free interval (pcc_noise_sorted.hip)
     uint32_t light_wgs; // PCC_TUNE_LIGHT_WGS: light workgroups per partition of the send launch (0 = what stays resident)
+    uint32_t light_front; // PCC_TUNE_LIGHT_FRONT: ... of which so many per partition are dispatched in front of the wave-path workgroups
     int noise_sorted;   // PCC_TUNE_NOISE_SORTED: 1 = latency noise alone on one sender runs its intervals by sorting, 2 = only the small instance, 0 = the event loop
     size_t noise_bytes;
     uint32_t ring_capacity;
@@ -161,7 +162,7 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
     const int64_t E = d.send_envs_per_wave;
     if (read_buf < 0) {
         const unsigned light_grid = (unsigned)(((d.n + E - 1) / E + 3) / 4);
-        pcc::launch_send(d, tr, light_grid, 0u, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+        pcc::launch_send(d, tr, light_grid, 0u, 0u, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
         return check_hip(hipGetLastError(), "send kernel launch");
     }
     const int64_t P = d.parts;
@@ -182,6 +183,12 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
     // step on one handle, profiles/r06_knob_sweeps.json.)
     unsigned light_grid = worst_light_grid;
     if (wave && sim->light_wgs && (int64_t)sim->light_wgs * P < (int64_t)light_grid) light_grid = (unsigned)((int64_t)sim->light_wgs * P);
+    // PCC_TUNE_LIGHT_FRONT: the light workgroups with the longest items in front of the wave-path ones (block order = dispatch
+    // order): the launch ends with those items and the ~830 wave-path workgroups take the dispatcher ~5 us -- send launch
+    // 0.0893 -> 0.0864 ms at 6 per partition (tools/ab_block.py, three episodes a setting).  Not out of lockstep: measured slower
+    // there (0.132 -> 0.137-0.140 ms, bench.py --stagger)
+    unsigned front = (wave && !rs) ? (unsigned)((int64_t)sim->light_front * P) : 0u;
+    if (front > light_grid) front = light_grid / (unsigned)P * (unsigned)P;
     const unsigned restart_grid = (unsigned)(sim->cu_count < (d.n + 3) / 4 ? sim->cu_count : (d.n + 3) / 4);
     if (rs && d.shadows) {
         // with shadows nearly every restart is a swap inside the retire half: the restart list holds only the envs whose shadow
@@ -192,10 +199,10 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
             (void)hipStreamWaitEvent(sim->aux_wave, sim->ev_fork, 0);
             launch_send_restart(d, tr, restart_grid, sim->aux_wave, read_buf, actions, actions_f64);
             (void)hipEventRecord(sim->ev_wave, sim->aux_wave);
-            pcc::launch_send(d, tr, light_grid, wave_grid, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+            pcc::launch_send(d, tr, light_grid, wave_grid, front, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
             (void)hipStreamWaitEvent(st, sim->ev_wave, 0);
         } else {
-            pcc::launch_send(d, tr, light_grid, wave_grid, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+            pcc::launch_send(d, tr, light_grid, wave_grid, front, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
             launch_send_restart(d, tr, restart_grid < 32u ? restart_grid : 32u, st, read_buf, actions, actions_f64);  // (a handful of items at most)
         }
     } else if (rs) {
@@ -205,12 +212,12 @@ int launch_send(pcc_sim_t *sim, int warm, uint32_t warm_mi, int gate, const void
         // dependency on a kernel that is just ending costs ~15 us, one that ended long ago next to nothing)
         if (hipEventRecord(sim->ev_fork, st) != hipSuccess) return fail(PCC_EHIP, "hipEventRecord failed");
         (void)hipStreamWaitEvent(sim->aux_wave, sim->ev_fork, 0);
-        pcc::launch_send(d, tr, light_grid, wave_grid, sim->aux_wave, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+        pcc::launch_send(d, tr, light_grid, wave_grid, front, sim->aux_wave, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
         (void)hipEventRecord(sim->ev_wave, sim->aux_wave);
         launch_send_restart(d, tr, restart_grid, st, read_buf, actions, actions_f64);
         (void)hipStreamWaitEvent(st, sim->ev_wave, 0);
     } else {
-        pcc::launch_send(d, tr, light_grid, wave_grid, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
+        pcc::launch_send(d, tr, light_grid, wave_grid, front, st, read_buf, zero_buf, warm, warm_mi, gate, actions, actions_f64);
     }
     if (rs && !warm) sim->restarts_pending = false;  // this launch runs what the restart list's envs were owed
     return check_hip(hipGetLastError(), "send kernel launch");
@@ -574,6 +581,7 @@ int pcc_create(int64_t n_envs, int n_senders, int history_len, const int32_t *fe
     sim->noise_sorted = 1;
     sim->fused = 0;   // (measured slower than the two launches at full size: profiles/r05_fused_experiments.json)
     { int x = 0; sim->xcc_count = hipDeviceGetAttribute(&x, hipDeviceAttributeNumberOfXccs, device) == hipSuccess ? x : 0; }
+    sim->light_front = 6;
     sim->fused_light_wgs = 32;   // light-first workgroups per partition (4 wavefronts each: a partition of 8 192 envs has ~105 light items)
     d.fused_acquire = 0u;
     d.fused_spin_ticks = 100000000u;   // 1 s of the 100 MHz clock
@@ -801,6 +809,10 @@ int pcc_set_tuning(pcc_sim_t *sim, int key, double value) {
         case PCC_TUNE_LIGHT_WGS:
             if (!(value >= 0.0 && value <= 65536.0)) return fail(PCC_EINVAL, "light_wgs out of range");
             sim->light_wgs = (uint32_t)value;
+            return PCC_OK;
+        case PCC_TUNE_LIGHT_FRONT:
+            if (!(value >= 0.0 && value <= 65536.0)) return fail(PCC_EINVAL, "light_front out of range");
+            sim->light_front = (uint32_t)value;
             return PCC_OK;
         case PCC_TUNE_NOISE_SORTED:
             if (value != 0.0 && value != 1.0 && value != 2.0) return fail(PCC_EINVAL, "noise_sorted must be 0, 1 or 2");

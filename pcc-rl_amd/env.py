@@ -195,7 +195,7 @@ class BatchedNetworkEnv(object):
                    retire_sorted=None, light_snake=None, wave_oldest_first=None, prio_level=None, prio_light_items=None,
                    prio_wave_items=None, prio_team=None, retire_grid_frac=None, restart_fork=None, parts=None, light_half_predict=None,
                    fused=None, fused_acquire=None, fused_light_wgs=None, fused_max_naps=None, fused_partial_naps=None, fused_debug=None, fused_light_front=None,
-                   noise_sorted=None, light_wgs=None):
+                   noise_sorted=None, light_wgs=None, light_front=None):
         """Performance knobs (results do not depend on them); see pcc_set_tuning in include/pcc_sim.h.  `parts` (the
         partitioning of the batch) must be followed by reset()."""
         for key, value in ((2, round_packets), (3, takeover_lanes), (4, send_envs_per_wave), (5, heavy_predict),
@@ -203,7 +203,7 @@ class BatchedNetworkEnv(object):
                            (13, retire_sorted), (14, light_snake), (15, wave_oldest_first), (16, prio_level), (17, prio_light_items),
                            (18, prio_wave_items), (19, prio_team), (22, retire_grid_frac), (23, restart_fork), (24, parts), (25, light_half_predict),
                            (26, fused), (27, fused_acquire), (28, fused_light_wgs), (29, fused_max_naps), (30, fused_partial_naps), (31, fused_debug), (32, fused_light_front),
-                           (33, noise_sorted), (34, light_wgs)):
+                           (33, noise_sorted), (34, light_wgs), (35, light_front)):
             if value is not None:
                 check(self._L.pcc_set_tuning(self._h, key, float(value)))
 

@@ -2,6 +2,7 @@
 """Randomized parity soak on the GPU box (not collected by pytest: run it by hand).
 
     python tests/soak_parity.py [cases] [first_seed] [senders: 1, 2 or 0 = both]
+    (PCC_SOAK_LISTS=1: small batches step by send_kernel + retire_kernel with work lists too; PCC_SOAK_BIG=1: 8 192+ envs only)
 
 Every case: a random batch size, episode stretch, action range (drifting rates up, down or both) and random speed knobs that
 move envs between the lane rounds, the wave path's passes and the small / full-size launches -- and the whole batch against the
@@ -25,6 +26,8 @@ DEV = "cuda:0"
 BIG = [8192, 9000, 12288, 16384]
 if os.environ.get("PCC_SOAK_BIG"):   # only batches that take the two-launch step
     BIG = [8192, 9000, 12288, 16384]
+if os.environ.get("PCC_SOAK_LISTS"):   # small batches through the work lists too (what tests/conftest.py does for the parity suite)
+    pcc_rl_amd.BatchedNetworkEnv.DEFAULT_LIST_MIN_ENVS = 0
 bad = 0
 for c in range(CASES):
     seed = SEED0 + c

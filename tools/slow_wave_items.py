@@ -61,6 +61,10 @@ for tt in range(400 * EPS):
         dur = (tl[one, 2] - tl[one, 0]) / 100.0
         chain = ((tl[one, 7] >> 24) & 0xFFFF).astype(np.float64)
         closed = (((tl[one, 7] >> 8) & 0xFF) + ((tl[one, 7] >> 16) & 0xFF)).astype(np.float64)
+        lrows = [{"start": round(float((tl[i, 0] - t0) / 100.0), 1), "rounds_end": round(float((tl[i, 1] - t0) / 100.0), 1), "finish": round(float(fin[i]), 1),
+                  "packets": int(tl[i, 4]), "longest_env": int(tl[i, 5] & 0xFFFFFFFF)} for i in light[np.argsort(-fin[light])[:6]]] if len(light) else []
+        print(json.dumps({"slowest_light_items": lrows, "light_items": int(len(light)),
+                          "light_items_running_at_us": {str(u): int(((tl[light, 0] - t0) / 100.0 <= u).sum() - (fin[light] <= u).sum()) for u in (20, 40, 60, 80, 100, 120)}}), flush=True)
         print(json.dumps({"episode": tt // 400, "step": t, "span_us": round(float(fin[live].max()), 1), "light_last_us": round(float(fin[light].max()), 1) if len(light) else None,
                           "wave_items": int(len(wave)), "single_env_items": int(len(one)),
                           "single_env_us_total": round(float(dur.sum()), 0), "single_env_us_in_items_with_chain": round(float(dur[chain > 0].sum()), 0),
