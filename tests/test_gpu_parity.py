@@ -684,7 +684,9 @@ def test_two_senders_out_of_lockstep_match_oracle():
 @pytest.mark.parametrize("knobs", [dict(), dict(parts=8), dict(parts=8, send_waves=1), dict(parts=8, retire_wide_predict=0.0),
                                    dict(parts=8, retire_sorted=0), dict(light_snake=0, wave_oldest_first=0),
                                    dict(parts=8, prio_level=2, prio_light_items=8, prio_wave_items=8, prio_team=1, team_predict=600.0),
-                                   dict(send_waves=1), dict(parts=8, send_waves=32, heavy_item_packets=0.0)])
+                                   dict(send_waves=1), dict(parts=8, send_waves=32, heavy_item_packets=0.0),
+                                   dict(light_front=0), dict(parts=8, light_front=1), dict(parts=8, light_front=3, send_waves=2),
+                                   dict(parts=8, light_front=10000, heavy_predict=64.0)])   # (more in front than there are: all of them)
 def test_launch_shape_of_the_send_half_does_not_matter(knobs):
     """The send half is one launch with two kinds of workgroup, every workgroup working for one partition of the batch (1 or
     8 of them); which workgroup or wavefront sends or retires an env, in which order and at which priority, must never change
