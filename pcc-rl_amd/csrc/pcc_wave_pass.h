@@ -1018,7 +1018,6 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                     const uint32_t a1n = (uint32_t)((total >> 32) & 0xFFFFu), d1n = (uint32_t)((total >> 48) & 0xFFFFu);
                     double last_q = 0.0, last_t = 0.0;
                     bool have_last = false;
-                    int j = jb;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const bool a = (acc4 >> i) & 1u;
@@ -1043,7 +1042,6 @@ __device__ __forceinline__ void heavy_mi2(const Dev &D, uint32_t lane, double dl
                             }
                             if ((m4 >> i) & 1u) { have_last = true; last_t = tk[i]; last_q = a ? x + (okb ? R : ebw) : x; }   // ns:75-82
                         }
-                        j += a ? 1 : 0;
                     }
                     const uint64_t lm = __ballot(have_last);
                     if (lm) {   // the link state behind the last committed packet that reached the queue
